@@ -1,0 +1,120 @@
+"""ctypes binding of libdsu_hip.so (C ABI in include/dsu_hip.h).
+
+There is no CPU fallback: if the shared library is missing, or a kernel is asked to run
+on a non-GPU tensor, the call raises.  `python -m drawingspinup_amd.build` (or
+`__graft_entry__.build()`) produces the library in-tree.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdsu_hip.so")
+MAX_LEVELS = 16
+
+c_i32, c_i64, c_u32, c_f32, c_vp = C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_void_p
+
+
+class HashGridCfg(C.Structure):
+    _fields_ = [("n_levels", c_u32), ("n_features", c_u32), ("log2_hashmap_size", c_u32),
+                ("base_resolution", c_u32), ("per_level_scale", C.c_double)]
+
+
+class HashGridLevels(C.Structure):
+    _fields_ = [("offsets", c_u32 * (MAX_LEVELS + 1)), ("resolution", c_u32 * MAX_LEVELS),
+                ("scale", c_f32 * MAX_LEVELS), ("hashed", c_u32 * MAX_LEVELS)]
+
+
+class SdfMlp(C.Structure):
+    _fields_ = [("w0", c_vp), ("b0", c_vp), ("w1", c_vp), ("b1", c_vp)]
+
+
+# name -> argtypes; every function returns int.  Kept in one table so that the CPU test
+# "the library exports every symbol the header declares" can walk it.
+P = c_vp
+_PROTOS = {
+    "dsu_abi_version": [],
+    "dsu_hashgrid_make_levels": [C.POINTER(HashGridCfg), C.POINTER(HashGridLevels)],
+    "dsu_hashgrid_encode_fwd": [C.POINTER(HashGridCfg), P, P, c_i64, c_u32, P, P],
+    "dsu_hashgrid_encode_bwd": [C.POINTER(HashGridCfg), P, P, c_i64, c_u32, P, P],
+    "dsu_sdf_fwd": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, c_i64, c_f32, c_u32, c_u32,
+                    P, P],
+    "dsu_sdf_fd_fwd": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, c_i64, c_f32, c_f32,
+                       c_u32, P, P, P, P, P],
+    "dsu_sdf_fd_bwd": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, c_i64, c_f32, c_f32,
+                       c_u32, P, P, P, P, P, P, P, P, P, P],
+    "dsu_ray_aabb": [P, P, c_i64, P, P, c_f32, P, P, P],
+    "dsu_ray_march_count": [P, P, P, P, c_i64, P, P, c_i32, c_f32, P, P],
+    "dsu_ray_march_fill": [P, P, P, P, c_i64, P, P, c_i32, c_f32, P, P, P, P, P],
+    "dsu_weights_from_alpha_fwd": [P, P, P, c_i64, P, P],
+    "dsu_weights_from_alpha_bwd": [P, P, P, P, P, c_i64, P, P],
+    "dsu_accumulate_fwd": [P, P, c_i32, P, P, c_i64, P, P],
+    "dsu_occgrid_ema": [P, P, P, c_i64, c_f32, P],
+    "dsu_occgrid_binarize": [P, c_i64, c_f32, P, P],
+    "dsu_ric_offsets": [c_i32, c_i32, P, P],
+    "dsu_deform_conv3x3_fwd": [P, P, c_i64, P, c_i32, c_i32, c_i32, c_i32, c_i32, P, P, c_i32,
+                               P, P, P],
+    "dsu_conv2d_fwd": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, P, P,
+                       c_i32, P, P, P],
+}
+
+_lib = None
+
+
+class DsuError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Raises if the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DsuError(
+                f"{LIB_PATH} is missing: the HIP extension is not built "
+                "(run `python -m drawingspinup_amd.build`). There is no CPU fallback.")
+        h = C.CDLL(LIB_PATH)
+        h.dsu_strerror.restype = C.c_char_p
+        h.dsu_strerror.argtypes = [C.c_int]
+        for name, args in _PROTOS.items():
+            fn = getattr(h, name)  # AttributeError here = header/library mismatch
+            fn.restype = C.c_int
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise DsuError(f"{what} failed: {lib().dsu_strerror(rc).decode()} ({rc})")
+
+
+def ptr(t, dtype=None):
+    """Device pointer of a contiguous CUDA(HIP) tensor; None -> NULL."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise DsuError("libdsu_hip kernels need device tensors (no CPU fallback)")
+    if not t.is_contiguous():
+        raise DsuError("libdsu_hip kernels need contiguous tensors")
+    if dtype is not None and t.dtype != dtype:
+        raise DsuError(f"expected dtype {dtype}, got {t.dtype}")
+    return C.c_void_p(t.data_ptr())
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def hashgrid_levels(cfg: HashGridCfg):
+    """Host-only level table (works without a GPU)."""
+    lv = HashGridLevels()
+    check(lib().dsu_hashgrid_make_levels(C.byref(cfg), C.byref(lv)), "dsu_hashgrid_make_levels")
+    n = cfg.n_levels
+    return {
+        "offsets": [lv.offsets[i] for i in range(n + 1)],
+        "resolution": [lv.resolution[i] for i in range(n)],
+        "scale": [lv.scale[i] for i in range(n)],
+        "hashed": [lv.hashed[i] for i in range(n)],
+    }

@@ -1,0 +1,25 @@
+// Shared host/device helpers for libdsu_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+#include "../../include/dsu_hip.h"
+
+#define DSU_WAVE 64
+
+#define DSU_CHECK_LAUNCH()                                   \
+  do {                                                       \
+    hipError_t e__ = hipGetLastError();                      \
+    if (e__ != hipSuccess) return DSU_ELAUNCH;               \
+  } while (0)
+
+static inline int dsu_blocks_for(int64_t n, int threads) {
+  return (int)((n + threads - 1) / threads);
+}
+
+// Memory-bound launches are capped at 256 CUs x 8 blocks and grid-stride the rest.
+static inline int dsu_capped_blocks(int64_t n, int threads, int cap = 2048) {
+  int64_t b = (n + threads - 1) / threads;
+  if (b < 1) b = 1;
+  return (int)(b > cap ? cap : b);
+}

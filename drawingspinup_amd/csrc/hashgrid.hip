@@ -1,0 +1,715 @@
+// Multi-resolution hash grid + fused SDF MLP for gfx950.
+//
+// Replaces tiny-cuda-nn's HashGrid encoding (reference call sites
+// 2_charactor_reconstructor/instant_nsr/models/network_utils.py:46,55) and fuses it with
+// the reference's own VanillaMLP geometry network (network_utils.py:94-138) and the
+// finite-difference normal/laplacian logic of VolumeSDF.forward (geometry.py:135-187).
+//
+// Arithmetic contract (the oracle in oracle/hashgrid.py restates exactly this):
+//   level l:  scale_l = (float)(exp2(l*log2(per_level_scale))*base_res - 1)   [double -> f32]
+//             res_l   = (uint32)ceilf(scale_l) + 1
+//             size_l  = min(round_up(res_l^3, 8), 2^log2_hashmap)   entries
+//   point x in [0,1]^3:  pos = fmaf(scale, x, 0.5f); cell = floorf(pos); frac = pos - cell
+//   corner c (bit d of c selects cell+1 in dim d), weight = prod_d (bit ? frac_d : 1-frac_d)
+//             (f32 product in dim order 0,1,2 starting from 1.0f)
+//   index:    dense  x + y*res + z*res^2   when res^3 <= size_l, else
+//             (x*1) ^ (y*2654435761) ^ (z*805459861)   (uint32), both taken mod size_l
+//   feature:  acc = fma((f16)weight, table[index], acc) in binary16 for c = 0..7 (f16 FMA,
+//             one rounding per step), exactly tcnn's half-precision accumulation.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+struct GridMeta {
+  uint32_t off[DSU_MAX_LEVELS + 1];
+  uint32_t res[DSU_MAX_LEVELS];
+  float scale[DSU_MAX_LEVELS];
+  uint32_t hashed[DSU_MAX_LEVELS];
+};
+
+constexpr int HID = 64;   // n_neurons (neuralangelo-ortho-wmask.yaml:66)
+constexpr int NOUT = 13;  // feature_dim (yaml:39)
+
+__device__ __forceinline__ uint32_t grid_index(uint32_t hashed, uint32_t hsize, uint32_t res,
+                                               uint32_t x, uint32_t y, uint32_t z) {
+  uint32_t idx;
+  if (hashed) {
+    idx = x ^ (y * 2654435761u) ^ (z * 805459861u);
+    return idx & (hsize - 1);  // hashed levels always have a power-of-two size
+  }
+  idx = x + y * res + z * res * res;
+  if (idx >= hsize) idx %= hsize;
+  return idx;
+}
+
+struct CellPos {
+  uint32_t c[3];
+  float f[3];
+};
+
+__device__ __forceinline__ CellPos cell_of(float scale, float x, float y, float z) {
+  CellPos p;
+  float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+  float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+  p.c[0] = (uint32_t)(int)fx;
+  p.c[1] = (uint32_t)(int)fy;
+  p.c[2] = (uint32_t)(int)fz;
+  p.f[0] = px - fx;
+  p.f[1] = py - fy;
+  p.f[2] = pz - fz;
+  return p;
+}
+
+__device__ __forceinline__ float corner_weight(const CellPos& p, int c) {
+  float w = 1.0f;
+  w *= (c & 1) ? p.f[0] : 1.0f - p.f[0];
+  w *= (c & 2) ? p.f[1] : 1.0f - p.f[1];
+  w *= (c & 4) ? p.f[2] : 1.0f - p.f[2];
+  return w;
+}
+
+// One level's trilinear lookup with tcnn's half-precision FMA chain.
+__device__ __forceinline__ __half2 lookup_level(const __half2* __restrict__ table,
+                                                const GridMeta& m, int l, float x, float y,
+                                                float z) {
+  const uint32_t hsize = m.off[l + 1] - m.off[l];
+  const __half2* lvl = table + m.off[l];
+  CellPos p = cell_of(m.scale[l], x, y, z);
+  uint32_t idx[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    idx[c] = grid_index(m.hashed[l], hsize, m.res[l], p.c[0] + (c & 1), p.c[1] + ((c >> 1) & 1),
+                        p.c[2] + ((c >> 2) & 1));
+  __half2 v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = lvl[idx[c]];  // 8 independent 4-byte gathers in flight
+  __half2 acc = __float2half2_rn(0.0f);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float wf = corner_weight(p, c);
+    // keep the f32 product rounded to f32 BEFORE the f16 conversion (tcnn: (T)weight); without
+    // this the compiler folds mul+cvt into one v_fma_mixlo_f16 with a single rounding.
+    asm volatile("" : "+v"(wf));
+    __half w = __float2half_rn(wf);
+    acc = __hfma2(__half2(w, w), v[c], acc);
+  }
+  return acc;
+}
+
+// ---------------------------------------------------------------- plain encode (tcnn shim)
+template <int NL>
+__global__ __launch_bounds__(256) void encode_fwd_kernel(const __half2* __restrict__ table,
+                                                         GridMeta m,
+                                                         const float* __restrict__ x, int64_t n,
+                                                         uint32_t active,
+                                                         __half2* __restrict__ out) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float px = x[i * 3 + 0], py = x[i * 3 + 1], pz = x[i * 3 + 2];
+    __half2* o = out + i * NL;
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      __half2 f = __float2half2_rn(0.0f);
+      if ((uint32_t)l < active) f = lookup_level(table, m, l, px, py, pz);
+      o[l] = f;
+    }
+  }
+}
+
+// grad wrt table: thread per (point, level); level = blockIdx.y keeps one level's slice of
+// the gradient table hot in L2 while it is being scattered into.
+__global__ __launch_bounds__(256) void encode_bwd_kernel(GridMeta m, int nl,
+                                                         const float* __restrict__ x,
+                                                         const float* __restrict__ dout,
+                                                         int64_t n, float* __restrict__ gtable) {
+  const int l = blockIdx.y;
+  const uint32_t hsize = m.off[l + 1] - m.off[l];
+  float* g = gtable + (size_t)m.off[l] * 2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float d0 = dout[i * (2 * nl) + 2 * l], d1 = dout[i * (2 * nl) + 2 * l + 1];
+    if (d0 == 0.0f && d1 == 0.0f) continue;
+    CellPos p = cell_of(m.scale[l], x[i * 3], x[i * 3 + 1], x[i * 3 + 2]);
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+      uint32_t idx = grid_index(m.hashed[l], hsize, m.res[l], p.c[0] + (c & 1),
+                                p.c[1] + ((c >> 1) & 1), p.c[2] + ((c >> 2) & 1));
+      float w = corner_weight(p, c);
+      unsafeAtomicAdd(g + (size_t)idx * 2, w * d0);
+      unsafeAtomicAdd(g + (size_t)idx * 2 + 1, w * d1);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- fused SDF network
+// LDS image of the MLP parameters (all f32):
+//   w0t [DIN][64]  (transposed so the 64 hidden units of one input are contiguous)
+//   b0  [64]
+//   w1  [13][64]
+//   b1  [16]
+template <int NL>
+struct MlpLds {
+  static constexpr int DIN = 3 + 2 * NL;
+  static constexpr int W0T = 0;
+  static constexpr int B0 = DIN * HID;
+  static constexpr int W1 = B0 + HID;
+  static constexpr int B1 = W1 + NOUT * HID;
+  static constexpr int TOTAL = B1 + 16;
+};
+
+template <int NL>
+__device__ __forceinline__ void load_mlp_to_lds(float* lds, const float* __restrict__ w0,
+                                                const float* __restrict__ b0,
+                                                const float* __restrict__ w1,
+                                                const float* __restrict__ b1) {
+  using L = MlpLds<NL>;
+  for (int t = threadIdx.x; t < L::DIN * HID; t += blockDim.x) {
+    int k = t / HID, j = t % HID;
+    lds[L::W0T + t] = w0[j * L::DIN + k];
+  }
+  for (int t = threadIdx.x; t < HID; t += blockDim.x) lds[L::B0 + t] = b0[t];
+  for (int t = threadIdx.x; t < NOUT * HID; t += blockDim.x) lds[L::W1 + t] = w1[t];
+  for (int t = threadIdx.x; t < 16; t += blockDim.x) lds[L::B1 + t] = t < NOUT ? b1[t] : 0.0f;
+  __syncthreads();
+}
+
+__device__ __forceinline__ float softplus100(float x) {
+  // nn.Softplus(beta=100, threshold=20)  (network_utils.py:134-136)
+  float bx = x * 100.0f;
+  return bx > 20.0f ? x : log1pf(expf(bx)) / 100.0f;
+}
+__device__ __forceinline__ float softplus100_grad(float x) {
+  float bx = x * 100.0f;
+  return bx > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-bx));
+}
+
+// Encode one contracted point into the MLP input vector (xyz*2-1, masked features).
+template <int NL>
+__device__ __forceinline__ void encode_input(const __half2* __restrict__ table,
+                                             const GridMeta& m, uint32_t active, float x,
+                                             float y, float z, float* in /*3+2NL*/) {
+  in[0] = x * 2.0f + -1.0f;
+  in[1] = y * 2.0f + -1.0f;
+  in[2] = z * 2.0f + -1.0f;
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    float2 f = make_float2(0.0f, 0.0f);
+    if ((uint32_t)l < active) f = __half22float2(lookup_level(table, m, l, x, y, z));
+    in[3 + 2 * l] = f.x;
+    in[4 + 2 * l] = f.y;
+  }
+}
+
+// hidden pre-activations: pre[j] = b0[j] + sum_k w0[j][k]*in[k], k < kmax
+template <int NL>
+__device__ __forceinline__ void layer0(const float* lds, const float* in, int kmax, float* pre) {
+  using L = MlpLds<NL>;
+  const float4* b4 = reinterpret_cast<const float4*>(lds + L::B0);
+#pragma unroll
+  for (int j4 = 0; j4 < HID / 4; ++j4) {
+    float4 b = b4[j4];
+    pre[4 * j4 + 0] = b.x;
+    pre[4 * j4 + 1] = b.y;
+    pre[4 * j4 + 2] = b.z;
+    pre[4 * j4 + 3] = b.w;
+  }
+#pragma unroll
+  for (int k = 0; k < L::DIN; ++k) {
+    if (k < kmax) {
+      const float4* w4 = reinterpret_cast<const float4*>(lds + L::W0T + k * HID);
+      const float v = in[k];
+#pragma unroll
+      for (int j4 = 0; j4 < HID / 4; ++j4) {
+        float4 w = w4[j4];  // wave-uniform address: LDS broadcast read
+        pre[4 * j4 + 0] = fmaf(w.x, v, pre[4 * j4 + 0]);
+        pre[4 * j4 + 1] = fmaf(w.y, v, pre[4 * j4 + 1]);
+        pre[4 * j4 + 2] = fmaf(w.z, v, pre[4 * j4 + 2]);
+        pre[4 * j4 + 3] = fmaf(w.w, v, pre[4 * j4 + 3]);
+      }
+    }
+  }
+}
+
+template <int NL>
+__device__ __forceinline__ float layer1_row(const float* lds, const float* h, int o) {
+  using L = MlpLds<NL>;
+  const float4* w4 = reinterpret_cast<const float4*>(lds + L::W1 + o * HID);
+  float acc = lds[L::B1 + o];
+#pragma unroll
+  for (int j4 = 0; j4 < HID / 4; ++j4) {
+    float4 w = w4[j4];
+    acc = fmaf(w.x, h[4 * j4 + 0], acc);
+    acc = fmaf(w.y, h[4 * j4 + 1], acc);
+    acc = fmaf(w.z, h[4 * j4 + 2], acc);
+    acc = fmaf(w.w, h[4 * j4 + 3], acc);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float contract(float p, float radius) {
+  // scale_anything(x, (-r, r), (0, 1))  (instant_nsr/models/utils.py:101-106)
+  float d = (p - (-radius)) / (radius - (-radius));
+  return d * (1.0f - 0.0f) + 0.0f;
+}
+
+template <int NL, int NO>
+__global__ __launch_bounds__(256) void sdf_fwd_kernel(const __half2* __restrict__ table,
+                                                      GridMeta m, dsu_sdf_mlp mlp,
+                                                      const float* __restrict__ pts, int64_t n,
+                                                      float radius, uint32_t active,
+                                                      float* __restrict__ out) {
+  using L = MlpLds<NL>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  load_mlp_to_lds<NL>(lds, mlp.w0, mlp.b0, mlp.w1, mlp.b1);
+  const int kmax = 3 + 2 * (int)active;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    float x = contract(pts[i * 3 + 0], radius);
+    float y = contract(pts[i * 3 + 1], radius);
+    float z = contract(pts[i * 3 + 2], radius);
+    float in[L::DIN];
+    encode_input<NL>(table, m, active, x, y, z, in);
+    float h[HID];
+    layer0<NL>(lds, in, kmax, h);
+#pragma unroll
+    for (int j = 0; j < HID; ++j) h[j] = softplus100(h[j]);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) out[i * NO + o] = layer1_row<NL>(lds, h, o);
+  }
+}
+
+// VolumeSDF.forward with finite differences: 7 evaluations per point.
+template <int NL>
+__global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
+    const __half2* __restrict__ table, GridMeta m, dsu_sdf_mlp mlp,
+    const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
+    uint32_t active, float* __restrict__ sdf, float* __restrict__ grad,
+    float* __restrict__ feature, float* __restrict__ laplace) {
+  using L = MlpLds<NL>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  load_mlp_to_lds<NL>(lds, mlp.w0, mlp.b0, mlp.w1, mlp.b1);
+  const int kmax = 3 + 2 * (int)active;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float p[3] = {pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2]};
+    float s[7];
+#pragma unroll 1
+    for (int e = 0; e < 7; ++e) {
+      float q[3] = {p[0], p[1], p[2]};
+      if (e > 0) {
+        const int ax = (e - 1) >> 1;
+        const float d = ((e - 1) & 1) ? -eps : eps;
+        // (points_ + offsets).clamp(-radius, radius)   (geometry.py:170)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          float v = q[a] + (a == ax ? d : 0.0f);
+          q[a] = fminf(fmaxf(v, -radius), radius);
+        }
+      }
+      float in[L::DIN];
+      encode_input<NL>(table, m, active, contract(q[0], radius), contract(q[1], radius),
+                       contract(q[2], radius), in);
+      float h[HID];
+      layer0<NL>(lds, in, kmax, h);
+#pragma unroll
+      for (int j = 0; j < HID; ++j) h[j] = softplus100(h[j]);
+      s[e] = layer1_row<NL>(lds, h, 0);
+      if (e == 0 && feature != nullptr) {
+        feature[i * NOUT] = s[0];
+#pragma unroll
+        for (int o = 1; o < NOUT; ++o) feature[i * NOUT + o] = layer1_row<NL>(lds, h, o);
+      }
+    }
+    sdf[i] = s[0];
+    if (grad != nullptr) {
+      // 0.5 * (sdf(+eps) - sdf(-eps)) / eps   (geometry.py:173)
+      grad[i * 3 + 0] = 0.5f * (s[1] - s[2]) / eps;
+      grad[i * 3 + 1] = 0.5f * (s[3] - s[4]) / eps;
+      grad[i * 3 + 2] = 0.5f * (s[5] - s[6]) / eps;
+    }
+    if (laplace != nullptr) {
+      // (sdf(+)+sdf(-)-2 sdf).sum(-1) / eps^2   (geometry.py:176)
+      float t0 = s[1] + s[2] - 2.0f * s[0];
+      float t1 = s[3] + s[4] - 2.0f * s[0];
+      float t2 = s[5] + s[6] - 2.0f * s[0];
+      laplace[i] = ((t0 + t1) + t2) / eps2;
+    }
+  }
+}
+
+// Backward of the 7-evaluation forward.  One point per lane; the per-wave outer products
+// for the MLP parameter gradients go through LDS so that lane j owns row j of g_w0 / column
+// j of g_w1 in registers for the whole grid-stride loop (no per-point atomics on the MLP).
+template <int NL>
+__global__ __launch_bounds__(256) void sdf_fd_bwd_kernel(
+    const __half2* __restrict__ table, GridMeta m, dsu_sdf_mlp mlp,
+    const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
+    uint32_t active, const float* __restrict__ d_sdf, const float* __restrict__ d_grad,
+    const float* __restrict__ d_feature, const float* __restrict__ d_laplace,
+    float* __restrict__ gtable, float* __restrict__ g_w0, float* __restrict__ g_b0,
+    float* __restrict__ g_w1, float* __restrict__ g_b1) {
+  using L = MlpLds<NL>;
+  constexpr int DIN = L::DIN;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  load_mlp_to_lds<NL>(lds, mlp.w0, mlp.b0, mlp.w1, mlp.b1);
+  // per-wave staging area behind the parameters, holding PB points at a time:
+  //   dpre[PB][65], h[PB][65], in[PB][DIN+1], dout[PB][NOUT+1]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  constexpr int PB = 16;
+  constexpr int STAGE = PB * 65 * 2 + PB * (DIN + 1) + PB * (NOUT + 1);
+  float* stage = lds + L::TOTAL + wave * STAGE;
+  float* s_dpre = stage;
+  float* s_h = s_dpre + PB * 65;
+  float* s_in = s_h + PB * 65;
+  float* s_do = s_in + PB * (DIN + 1);
+
+  const int kmax = 3 + 2 * (int)active;
+  float acc_w0[DIN];  // lane j: g_w0[j][:]
+  float acc_w1[NOUT]; // lane j: g_w1[:][j]
+  float acc_b0 = 0.0f;
+  float acc_b1 = 0.0f;  // lane o < NOUT: g_b1[o]
+#pragma unroll
+  for (int k = 0; k < DIN; ++k) acc_w0[k] = 0.0f;
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) acc_w1[o] = 0.0f;
+
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  // all lanes of a wave iterate together (inactive lanes contribute zeros)
+  const int64_t base0 = blockIdx.x * (int64_t)blockDim.x + (threadIdx.x & ~63);
+  for (int64_t base = base0; base < n; base += stride) {
+    const int64_t i = base + lane;
+    const bool valid = i < n;
+    float p[3] = {0.f, 0.f, 0.f};
+    float ds = 0.f, dl = 0.f, dg[3] = {0.f, 0.f, 0.f};
+    if (valid) {
+      p[0] = pts[i * 3 + 0];
+      p[1] = pts[i * 3 + 1];
+      p[2] = pts[i * 3 + 2];
+      if (d_sdf) ds = d_sdf[i];
+      if (d_laplace) dl = d_laplace[i];
+      if (d_grad) {
+        dg[0] = d_grad[i * 3 + 0];
+        dg[1] = d_grad[i * 3 + 1];
+        dg[2] = d_grad[i * 3 + 2];
+      }
+    }
+#pragma unroll 1
+    for (int e = 0; e < 7; ++e) {
+      float q[3] = {p[0], p[1], p[2]};
+      if (e > 0) {
+        const int ax = (e - 1) >> 1;
+        const float d = ((e - 1) & 1) ? -eps : eps;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+          float v = q[a] + (a == ax ? d : 0.0f);
+          q[a] = fminf(fmaxf(v, -radius), radius);
+        }
+      }
+      const float cx = contract(q[0], radius), cy = contract(q[1], radius),
+                  cz = contract(q[2], radius);
+      float in[DIN];
+      encode_input<NL>(table, m, active, cx, cy, cz, in);
+      float pre[HID];
+      layer0<NL>(lds, in, kmax, pre);
+      // upstream gradient on the 13 outputs of this evaluation
+      float dout[NOUT];
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) dout[o] = 0.0f;
+      if (valid) {
+        if (e == 0) {
+          if (d_feature) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) dout[o] = d_feature[i * NOUT + o];
+          }
+          dout[0] += ds - 6.0f * dl / eps2;
+        } else {
+          const int ax = (e - 1) >> 1;
+          const float sgn = ((e - 1) & 1) ? -1.0f : 1.0f;
+          dout[0] = sgn * 0.5f * dg[ax] / eps + dl / eps2;
+        }
+      }
+      // d_h = W1^T dout ; d_pre = d_h * softplus'(pre) ; h = softplus(pre)
+      float dpre[HID];
+#pragma unroll
+      for (int j = 0; j < HID; ++j) dpre[j] = 0.0f;
+      const int no = (e == 0) ? NOUT : 1;
+      for (int o = 0; o < no; ++o) {
+        const float4* w4 = reinterpret_cast<const float4*>(lds + L::W1 + o * HID);
+        const float dv = dout[o];
+#pragma unroll
+        for (int j4 = 0; j4 < HID / 4; ++j4) {
+          float4 w = w4[j4];
+          dpre[4 * j4 + 0] = fmaf(w.x, dv, dpre[4 * j4 + 0]);
+          dpre[4 * j4 + 1] = fmaf(w.y, dv, dpre[4 * j4 + 1]);
+          dpre[4 * j4 + 2] = fmaf(w.z, dv, dpre[4 * j4 + 2]);
+          dpre[4 * j4 + 3] = fmaf(w.w, dv, dpre[4 * j4 + 3]);
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < HID; ++j) {
+        dpre[j] *= softplus100_grad(pre[j]);
+        pre[j] = softplus100(pre[j]);  // pre now holds h
+      }
+
+      // d_in[k] = sum_j w0[j][k] dpre[j]  for feature inputs only, then scatter to the table
+      {
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          if ((uint32_t)l < active) {
+            float d0 = 0.f, d1 = 0.f;
+            const float4* wa = reinterpret_cast<const float4*>(lds + L::W0T + (3 + 2 * l) * HID);
+            const float4* wb = reinterpret_cast<const float4*>(lds + L::W0T + (4 + 2 * l) * HID);
+#pragma unroll
+            for (int j4 = 0; j4 < HID / 4; ++j4) {
+              float4 a = wa[j4], b = wb[j4];
+              d0 = fmaf(a.x, dpre[4 * j4 + 0], d0);
+              d0 = fmaf(a.y, dpre[4 * j4 + 1], d0);
+              d0 = fmaf(a.z, dpre[4 * j4 + 2], d0);
+              d0 = fmaf(a.w, dpre[4 * j4 + 3], d0);
+              d1 = fmaf(b.x, dpre[4 * j4 + 0], d1);
+              d1 = fmaf(b.y, dpre[4 * j4 + 1], d1);
+              d1 = fmaf(b.z, dpre[4 * j4 + 2], d1);
+              d1 = fmaf(b.w, dpre[4 * j4 + 3], d1);
+            }
+            if (valid && (d0 != 0.0f || d1 != 0.0f)) {
+              const uint32_t hsize = m.off[l + 1] - m.off[l];
+              float* g = gtable + (size_t)m.off[l] * 2;
+              CellPos cp = cell_of(m.scale[l], cx, cy, cz);
+#pragma unroll
+              for (int c = 0; c < 8; ++c) {
+                uint32_t idx = grid_index(m.hashed[l], hsize, m.res[l], cp.c[0] + (c & 1),
+                                          cp.c[1] + ((c >> 1) & 1), cp.c[2] + ((c >> 2) & 1));
+                float w = corner_weight(cp, c);
+                unsafeAtomicAdd(g + (size_t)idx * 2, w * d0);
+                unsafeAtomicAdd(g + (size_t)idx * 2 + 1, w * d1);
+              }
+            }
+          }
+        }
+      }
+      // wave-local outer products, PB points at a time (wave-synchronous: the LDS ops of
+      // one wave execute in order, the barriers only pin the compiler's schedule)
+#pragma unroll 1
+      for (int q = 0; q < 64 / PB; ++q) {
+        __builtin_amdgcn_wave_barrier();
+        if ((lane / PB) == q) {
+          const int r = lane % PB;
+#pragma unroll
+          for (int j = 0; j < HID; ++j) {
+            s_dpre[r * 65 + j] = dpre[j];
+            s_h[r * 65 + j] = pre[j];
+          }
+#pragma unroll
+          for (int k = 0; k < DIN; ++k) s_in[r * (DIN + 1) + k] = in[k];
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o) s_do[r * (NOUT + 1) + o] = dout[o];
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int pnt = 0; pnt < PB; ++pnt) {
+          const float dp = s_dpre[pnt * 65 + lane];
+          acc_b0 += dp;
+#pragma unroll
+          for (int k = 0; k < DIN; ++k)
+            if (k < kmax) acc_w0[k] = fmaf(dp, s_in[pnt * (DIN + 1) + k], acc_w0[k]);
+          const float hh = s_h[pnt * 65 + lane];
+          if (e == 0) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o)
+              acc_w1[o] = fmaf(s_do[pnt * (NOUT + 1) + o], hh, acc_w1[o]);
+            if (lane < NOUT) acc_b1 += s_do[pnt * (NOUT + 1) + lane];
+          } else {
+            acc_w1[0] = fmaf(s_do[pnt * (NOUT + 1)], hh, acc_w1[0]);
+            if (lane == 0) acc_b1 += s_do[pnt * (NOUT + 1)];
+          }
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+  // flush the per-lane parameter-gradient accumulators
+#pragma unroll
+  for (int k = 0; k < DIN; ++k)
+    if (acc_w0[k] != 0.0f) unsafeAtomicAdd(g_w0 + lane * DIN + k, acc_w0[k]);
+  if (acc_b0 != 0.0f) unsafeAtomicAdd(g_b0 + lane, acc_b0);
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o)
+    if (acc_w1[o] != 0.0f) unsafeAtomicAdd(g_w1 + o * HID + lane, acc_w1[o]);
+  if (lane < NOUT && acc_b1 != 0.0f) unsafeAtomicAdd(g_b1 + lane, acc_b1);
+}
+
+int make_meta(const dsu_hashgrid_cfg* cfg, GridMeta* m) {
+  dsu_hashgrid_levels lv;
+  int rc = dsu_hashgrid_make_levels(cfg, &lv);
+  if (rc) return rc;
+  for (uint32_t l = 0; l <= cfg->n_levels; ++l) m->off[l] = lv.offsets[l];
+  for (uint32_t l = 0; l < cfg->n_levels; ++l) {
+    m->res[l] = lv.resolution[l];
+    m->scale[l] = lv.scale[l];
+    m->hashed[l] = lv.hashed[l];
+  }
+  return DSU_OK;
+}
+
+template <int NL>
+size_t bwd_lds_bytes() {
+  constexpr int DIN = 3 + 2 * NL;
+  constexpr int STAGE = 16 * 65 * 2 + 16 * (DIN + 1) + 16 * (NOUT + 1);
+  return (size_t)(MlpLds<NL>::TOTAL + 4 * STAGE) * sizeof(float);
+}
+
+}  // namespace
+
+#define DSU_DISPATCH_NL(nl, ...)          \
+  switch (nl) {                            \
+    case 10: { constexpr int NL = 10; __VA_ARGS__ } break; \
+    case 12: { constexpr int NL = 12; __VA_ARGS__ } break; \
+    default: return DSU_EUNSUP;            \
+  }
+
+extern "C" {
+
+int dsu_hashgrid_make_levels(const dsu_hashgrid_cfg* cfg, dsu_hashgrid_levels* out) {
+  if (!cfg || !out) return DSU_EINVAL;
+  if (cfg->n_levels == 0 || cfg->n_levels > DSU_MAX_LEVELS) return DSU_EINVAL;
+  if (cfg->n_features != 2) return DSU_EUNSUP;
+  if (cfg->log2_hashmap_size < 3 || cfg->log2_hashmap_size > 28) return DSU_EINVAL;
+  const double l2 = log2(cfg->per_level_scale);
+  uint32_t offset = 0;
+  for (uint32_t l = 0; l < cfg->n_levels; ++l) {
+    const float scale = (float)(exp2((double)l * l2) * (double)cfg->base_resolution - 1.0);
+    const uint32_t res = (uint32_t)ceilf(scale) + 1u;
+    const uint32_t max_params = 0xFFFFFFFFu / 2;
+    const double cube = (double)res * (double)res * (double)res;
+    uint32_t params = cube > (double)max_params ? max_params : (uint32_t)cube;
+    params = (params + 7u) / 8u * 8u;
+    const uint32_t hsize = 1u << cfg->log2_hashmap_size;
+    if (params > hsize) params = hsize;
+    out->offsets[l] = offset;
+    out->resolution[l] = res;
+    out->scale[l] = scale;
+    out->hashed[l] = cube > (double)params ? 1u : 0u;
+    offset += params;
+  }
+  out->offsets[cfg->n_levels] = offset;
+  return DSU_OK;
+}
+
+int dsu_hashgrid_encode_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const float* x,
+                            int64_t n, uint32_t active_levels, void* out_f16, void* stream) {
+  if (!cfg || !table_f16 || (!x && n) || (!out_f16 && n) || n < 0) return DSU_EINVAL;
+  if (active_levels > cfg->n_levels) return DSU_EINVAL;
+  GridMeta m;
+  int rc = make_meta(cfg, &m);
+  if (rc) return rc;
+  if (n == 0) return DSU_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = dsu_capped_blocks(n, 256, 8192);
+  DSU_DISPATCH_NL(cfg->n_levels, {
+    encode_fwd_kernel<NL><<<dim3(blocks), dim3(256), 0, s>>>(
+        (const __half2*)table_f16, m, x, n, active_levels, (__half2*)out_f16);
+  });
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_hashgrid_encode_bwd(const dsu_hashgrid_cfg* cfg, const float* x, const float* dout,
+                            int64_t n, uint32_t active_levels, float* grad_table,
+                            void* stream) {
+  if (!cfg || (!x && n) || (!dout && n) || !grad_table || n < 0) return DSU_EINVAL;
+  if (active_levels > cfg->n_levels) return DSU_EINVAL;
+  GridMeta m;
+  int rc = make_meta(cfg, &m);
+  if (rc) return rc;
+  if (n == 0 || active_levels == 0) return DSU_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = dsu_capped_blocks(n, 256, 4096);
+  encode_bwd_kernel<<<dim3(blocks, active_levels), dim3(256), 0, s>>>(
+      m, (int)cfg->n_levels, x, dout, n, grad_table);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_sdf_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                const float* pts, int64_t n, float radius, uint32_t active_levels,
+                uint32_t n_out, float* out, void* stream) {
+  if (!cfg || !table_f16 || !mlp || (!pts && n) || (!out && n) || n < 0) return DSU_EINVAL;
+  if (!mlp->w0 || !mlp->b0 || !mlp->w1 || !mlp->b1) return DSU_EINVAL;
+  if (active_levels > cfg->n_levels) return DSU_EINVAL;
+  if (n_out != 1 && n_out != NOUT) return DSU_EUNSUP;
+  GridMeta m;
+  int rc = make_meta(cfg, &m);
+  if (rc) return rc;
+  if (n == 0) return DSU_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = dsu_capped_blocks(n, 256, 8192);
+  DSU_DISPATCH_NL(cfg->n_levels, {
+    const size_t shm = MlpLds<NL>::TOTAL * sizeof(float);
+    if (n_out == 1)
+      sdf_fwd_kernel<NL, 1><<<dim3(blocks), dim3(256), shm, s>>>(
+          (const __half2*)table_f16, m, *mlp, pts, n, radius, active_levels, out);
+    else
+      sdf_fwd_kernel<NL, NOUT><<<dim3(blocks), dim3(256), shm, s>>>(
+          (const __half2*)table_f16, m, *mlp, pts, n, radius, active_levels, out);
+  });
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_sdf_fd_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                   const float* pts, int64_t n, float radius, float eps,
+                   uint32_t active_levels, float* sdf, float* grad, float* feature,
+                   float* laplace, void* stream) {
+  if (!cfg || !table_f16 || !mlp || (!pts && n) || (!sdf && n) || n < 0) return DSU_EINVAL;
+  if (!mlp->w0 || !mlp->b0 || !mlp->w1 || !mlp->b1) return DSU_EINVAL;
+  if (active_levels > cfg->n_levels || !(eps > 0.0f)) return DSU_EINVAL;
+  GridMeta m;
+  int rc = make_meta(cfg, &m);
+  if (rc) return rc;
+  if (n == 0) return DSU_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const float eps2 = (float)((double)eps * (double)eps);
+  const int blocks = dsu_capped_blocks(n, 256, 8192);
+  DSU_DISPATCH_NL(cfg->n_levels, {
+    const size_t shm = MlpLds<NL>::TOTAL * sizeof(float);
+    sdf_fd_fwd_kernel<NL><<<dim3(blocks), dim3(256), shm, s>>>(
+        (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, sdf, grad,
+        feature, laplace);
+  });
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                   const float* pts, int64_t n, float radius, float eps,
+                   uint32_t active_levels, const float* d_sdf, const float* d_grad,
+                   const float* d_feature, const float* d_laplace, float* grad_table,
+                   float* g_w0, float* g_b0, float* g_w1, float* g_b1, void* stream) {
+  if (!cfg || !table_f16 || !mlp || (!pts && n) || n < 0) return DSU_EINVAL;
+  if (!mlp->w0 || !mlp->b0 || !mlp->w1 || !mlp->b1) return DSU_EINVAL;
+  if (!grad_table || !g_w0 || !g_b0 || !g_w1 || !g_b1) return DSU_EINVAL;
+  if (active_levels > cfg->n_levels || !(eps > 0.0f)) return DSU_EINVAL;
+  GridMeta m;
+  int rc = make_meta(cfg, &m);
+  if (rc) return rc;
+  if (n == 0) return DSU_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const float eps2 = (float)((double)eps * (double)eps);
+  const int blocks = dsu_capped_blocks(n, 256, 1024);
+  DSU_DISPATCH_NL(cfg->n_levels, {
+    const size_t shm = bwd_lds_bytes<NL>();
+    if (shm > 64 * 1024) {
+      if (hipFuncSetAttribute((const void*)sdf_fd_bwd_kernel<NL>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)shm) != hipSuccess)
+        return DSU_ELAUNCH;
+    }
+    sdf_fd_bwd_kernel<NL><<<dim3(blocks), dim3(256), shm, s>>>(
+        (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
+        d_grad, d_feature, d_laplace, grad_table, g_w0, g_b0, g_w1, g_b1);
+  });
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,311 @@
+// f32 implicit-GEMM convolution and fixed-offset deformable convolution on the gfx950
+// f32 MFMA (v_mfma_f32_32x32x2_f32: exact f32 products, f32 accumulate).
+//
+// Replaces, for the per-frame style-translator nets
+// (3_style_translator/training/models.py):
+//   * torchvision.ops.deform_conv2d (torchvision 0.15.1, un-vendored; call sites
+//     models.py:302,308,314,322,325,331,338,344,348,351) — bilinear im2col + GEMM,
+//   * nn.Conv2d / BatchNorm2d(eval) / LeakyReLU / ReLU / Tanh of GeneratorJ
+//     (models.py:41-129) — the cuDNN path in the reference.
+//
+// GEMM view:  out[o][pix] = sum_{c,tap} W[o][c][tap] * col[c][tap][pix]
+//   A operand (M = output channels) = weights, B operand (N = pixels) = im2col values, so
+//   that the 32x32 accumulator tile has a PIXEL per lane and stores are row-contiguous.
+// Per workgroup (256 threads = 4 waves): 128 consecutive output pixels x BN channels,
+// K walked in chunks of KC channels x KK taps staged through LDS (double buffered).
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BM = 128;  // pixels per workgroup
+
+struct ConvArgs {
+  const float* in;
+  const float* w;
+  const float* bias;
+  const float* offset;       // deform only: (18,H,W)
+  int64_t offset_bstride;    // elements between images' offset maps (0 = shared)
+  const float* ep_scale;
+  const float* ep_shift;
+  const float* residual;
+  float* out;
+  int B, C, H, W, O, OH, OW, pad;
+  int act;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case 1: return fmaxf(v, 0.0f);
+    case 2: return v > 0.0f ? v : 0.2f * v;
+    case 3: return tanhf(v);
+    default: return v;
+  }
+}
+
+// bilinear sampling state of one (pixel, tap): clamped row/col offsets + 4 weights with the
+// out-of-range corners zeroed (torchvision deform_conv2d bilinear_interpolate semantics).
+struct Tap {
+  int r0, r1, c0, c1;
+  float w00, w01, w10, w11;
+};
+
+__device__ __forceinline__ Tap make_tap(float h, float w, int H, int W) {
+  Tap t;
+  const bool inside = (h > -1.0f) && (w > -1.0f) && (h < (float)H) && (w < (float)W);
+  const float hl = floorf(h), wl = floorf(w);
+  const int h0 = (int)hl, w0 = (int)wl, h1 = h0 + 1, w1 = w0 + 1;
+  const float lh = h - hl, lw = w - wl, hh = 1.0f - lh, hw = 1.0f - lw;
+  const bool vh0 = inside && h0 >= 0, vh1 = inside && h1 <= H - 1;
+  const bool vw0 = w0 >= 0, vw1 = w1 <= W - 1;
+  t.w00 = (vh0 && vw0) ? hh * hw : 0.0f;
+  t.w01 = (vh0 && vw1) ? hh * lw : 0.0f;
+  t.w10 = (vh1 && vw0) ? lh * hw : 0.0f;
+  t.w11 = (vh1 && vw1) ? lh * lw : 0.0f;
+  t.r0 = min(max(h0, 0), H - 1) * W;
+  t.r1 = min(max(h1, 0), H - 1) * W;
+  t.c0 = min(max(w0, 0), W - 1);
+  t.c1 = min(max(w1, 0), W - 1);
+  return t;
+}
+
+__device__ __forceinline__ float sample_tap(const float* __restrict__ plane, const Tap& t) {
+  const float v00 = plane[t.r0 + t.c0], v01 = plane[t.r0 + t.c1];
+  const float v10 = plane[t.r1 + t.c0], v11 = plane[t.r1 + t.c1];
+  return t.w00 * v00 + t.w01 * v01 + t.w10 * v10 + t.w11 * v11;
+}
+
+// MODE 0: plain conv (KS x KS taps, stride STRIDE); MODE 1: 3x3 deformable, stride 1.
+template <int MODE, int KS, int STRIDE, int KC, int BN>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
+  constexpr int KK = KS * KS;
+  constexpr int KE = KC * KK;            // real K elements per chunk
+  constexpr int KP = (KE + 1) & ~1;      // padded to the MFMA's k=2
+  constexpr int NT = BN / 32;            // 32-channel MFMA row blocks per wave
+  __shared__ __attribute__((aligned(16))) float sB[2][KP][BM];   // im2col values
+  __shared__ __attribute__((aligned(16))) float sA[2][KP][BN];   // weights, k-major
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b = blockIdx.z;
+  const int o_base = blockIdx.y * BN;
+  const int npix = a.OH * a.OW;
+  const int pix0 = blockIdx.x * BM;
+
+  // ---- staging roles
+  const int sp = tid & (BM - 1);   // pixel this thread stages
+  const int sg = tid >> 7;         // which half of the chunk's K elements (0/1)
+  const int spix = pix0 + sp;
+  const bool spv = spix < npix;
+  const int oy = spv ? spix / a.OW : 0, ox = spv ? spix % a.OW : 0;
+  const float* in_b = a.in + (size_t)b * a.C * a.H * a.W;
+  const size_t plane = (size_t)a.H * a.W;
+
+  Tap taps[MODE == 1 ? 9 : 1];
+  if (MODE == 1) {
+    const float* off = a.offset + (size_t)b * a.offset_bstride;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+      float dh = 0.0f, dw = 0.0f;
+      if (spv) {
+        dh = off[(size_t)(2 * t) * npix + spix];
+        dw = off[(size_t)(2 * t + 1) * npix + spix];
+      }
+      const float h = (float)(oy - a.pad + t / 3) + dh;
+      const float w = (float)(ox - a.pad + t % 3) + dw;
+      taps[t] = make_tap(h, w, a.H, a.W);
+    }
+  }
+
+  f32x16 acc[NT];
+#pragma unroll
+  for (int n = 0; n < NT; ++n)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[n][r] = 0.0f;
+
+  const int nchunks = (a.C + KC - 1) / KC;
+
+  auto stage = [&](int chunk, int buf) {
+    const int c0 = chunk * KC;
+    // --- im2col values for pixel sp
+    if (MODE == 1) {
+      constexpr int CH = KC / 2;  // channels per staging half
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc) {
+        const int c = c0 + sg * CH + cc;
+        const bool cv = spv && c < a.C;
+        const float* pl = in_b + (size_t)(cv ? c : 0) * plane;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          float v = sample_tap(pl, taps[t]);
+          sB[buf][(sg * CH + cc) * 9 + t][sp] = cv ? v : 0.0f;
+        }
+      }
+    } else {
+      constexpr int EH = (KP + 1) / 2;
+      for (int e = sg * EH; e < min((sg + 1) * EH, KP); ++e) {
+        float v = 0.0f;
+        if (e < KE) {
+          const int cc = e / KK, t = e % KK;
+          const int c = c0 + cc;
+          const int iy = oy * STRIDE - a.pad + t / KS, ix = ox * STRIDE - a.pad + t % KS;
+          if (spv && c < a.C && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
+            v = in_b[(size_t)c * plane + (size_t)iy * a.W + ix];
+        }
+        sB[buf][e][sp] = v;
+      }
+    }
+    // --- weights: W[o][c0*KK .. c0*KK+KE) is contiguous per o
+    for (int idx = tid; idx < KP * BN; idx += 256) {
+      const int o = idx % BN, e = idx / BN;
+      float v = 0.0f;
+      const int c = c0 + e / KK;
+      if (e < KE && c < a.C && o_base + o < a.O)
+        v = a.w[((size_t)(o_base + o) * a.C + c0) * KK + e];
+      sA[buf][e][o] = v;
+    }
+  };
+
+  stage(0, 0);
+  __syncthreads();
+  for (int ch = 0; ch < nchunks; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
+    // wave `wave` owns pixels [32*wave, 32*wave+32) x all BN channels
+    const int kh = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int kp = 0; kp < KP / 2; ++kp) {
+      const float bv = sB[buf][2 * kp + kh][wave * 32 + l31];
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const float av = sA[buf][2 * kp + kh][n * 32 + l31];
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane -> pixel (lane&31), register r -> channel row
+  const int pix = pix0 + wave * 32 + (lane & 31);
+  if (pix < npix) {
+    float* out_b = a.out + (size_t)b * a.O * npix;
+    const float* res_b = a.residual ? a.residual + (size_t)b * a.O * npix : nullptr;
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int o = o_base + n * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (o < a.O) {
+          float v = acc[n][r];
+          if (a.bias) v += a.bias[o];
+          if (a.ep_scale) v = v * a.ep_scale[o] + a.ep_shift[o];
+          v = apply_act(v, a.act);
+          if (res_b) v += res_b[(size_t)o * npix + pix];
+          out_b[(size_t)o * npix + pix] = v;
+        }
+      }
+    }
+  }
+}
+
+// generate_coordinates (models.py:551-604): theta = atan2(col - cx, row - cy) mod 2pi,
+// rounded to 1e-4; tap k samples at p + (cos, sin)(theta + m_k*pi/4); centre tap offset 0.
+__global__ void ric_offsets_kernel(int H, int W, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= H * W) return;
+  const int row = idx / W, col = idx % W;
+  const float cy = (float)H / 2.0f - 0.5f, cx = (float)W / 2.0f - 0.5f;
+  const float two_pi = 3.14159274101257324f * 2.0f;  // torch.Tensor([math.pi]) * 2.0 in f32
+  const float dx = (float)row - cy, dy = (float)col - cx;
+  float th = atan2f(dy, dx);
+  // python-style modulo for tensors: result takes the sign of the divisor
+  th = fmodf(th, two_pi);
+  if (th < 0.0f) th += two_pi;
+  th = rintf(10000.0f * th) / 10000.0f;
+  const float step = two_pi / 8.0f;
+  const float bi[9] = {1.f, 1.f, 1.f, 0.f, 0.f, 0.f, -1.f, -1.f, -1.f};
+  const float bj[9] = {1.f, 0.f, -1.f, 1.f, 0.f, -1.f, 1.f, 0.f, -1.f};
+  const size_t n = (size_t)H * W;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    float oh = 0.0f, ow = 0.0f;
+    if (k != 4) {
+      const float m = (float)(k < 4 ? k : k - 1);
+      const float ang = th + step * m;
+      oh = cosf(ang) + bi[k];
+      ow = sinf(ang) + bj[k];
+    }
+    out[(size_t)(2 * k) * n + idx] = oh;
+    out[(size_t)(2 * k + 1) * n + idx] = ow;
+  }
+}
+
+template <int MODE, int KS, int STRIDE, int KC>
+int launch_conv(const ConvArgs& a, hipStream_t s) {
+  const int npix = a.OH * a.OW;
+  const int gx = (npix + BM - 1) / BM;
+  if (a.O > 64) {
+    dim3 grid(gx, (a.O + 127) / 128, a.B);
+    conv_igemm_kernel<MODE, KS, STRIDE, KC, 128><<<grid, 256, 0, s>>>(a);
+  } else if (a.O > 32) {
+    dim3 grid(gx, 1, a.B);
+    conv_igemm_kernel<MODE, KS, STRIDE, KC, 64><<<grid, 256, 0, s>>>(a);
+  } else {
+    dim3 grid(gx, 1, a.B);
+    conv_igemm_kernel<MODE, KS, STRIDE, KC, 32><<<grid, 256, 0, s>>>(a);
+  }
+  if (hipGetLastError() != hipSuccess) return DSU_ELAUNCH;
+  return DSU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsu_ric_offsets(int32_t H, int32_t W, float* offsets, void* stream) {
+  if (H <= 0 || W <= 0 || !offsets) return DSU_EINVAL;
+  ric_offsets_kernel<<<dsu_blocks_for((int64_t)H * W, 256), 256, 0, (hipStream_t)stream>>>(
+      H, W, offsets);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_deform_conv3x3_fwd(const float* input, const float* offset, int64_t offset_batch_stride,
+                           const float* weight, int32_t B, int32_t C, int32_t H, int32_t W,
+                           int32_t O, const float* ep_scale, const float* ep_shift, int32_t act,
+                           const float* residual, float* out, void* stream) {
+  if (!input || !offset || !weight || !out) return DSU_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || O <= 0 || act < 0 || act > 3) return DSU_EINVAL;
+  if ((ep_scale == nullptr) != (ep_shift == nullptr)) return DSU_EINVAL;
+  ConvArgs a{};
+  a.in = input; a.w = weight; a.bias = nullptr; a.offset = offset;
+  a.offset_bstride = offset_batch_stride;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.residual = residual; a.out = out;
+  a.B = B; a.C = C; a.H = H; a.W = W; a.O = O; a.OH = H; a.OW = W; a.pad = 1; a.act = act;
+  return launch_conv<1, 3, 1, 4>(a, (hipStream_t)stream);
+}
+
+int dsu_conv2d_fwd(const float* input, const float* weight, const float* bias, int32_t B,
+                   int32_t C, int32_t H, int32_t W, int32_t O, int32_t k, int32_t stride,
+                   int32_t pad, const float* ep_scale, const float* ep_shift, int32_t act,
+                   const float* residual, float* out, void* stream) {
+  if (!input || !weight || !out) return DSU_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || O <= 0 || act < 0 || act > 3 || pad < 0)
+    return DSU_EINVAL;
+  if ((ep_scale == nullptr) != (ep_shift == nullptr)) return DSU_EINVAL;
+  ConvArgs a{};
+  a.in = input; a.w = weight; a.bias = bias; a.offset = nullptr; a.offset_bstride = 0;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.residual = residual; a.out = out;
+  a.B = B; a.C = C; a.H = H; a.W = W; a.O = O; a.pad = pad; a.act = act;
+  a.OH = (H + 2 * pad - k) / stride + 1;
+  a.OW = (W + 2 * pad - k) / stride + 1;
+  if (a.OH <= 0 || a.OW <= 0) return DSU_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (k == 1 && stride == 1) return launch_conv<0, 1, 1, 32>(a, s);
+  if (k == 3 && stride == 1) return launch_conv<0, 3, 1, 4>(a, s);
+  if (k == 3 && stride == 2) return launch_conv<0, 3, 2, 4>(a, s);
+  if (k == 7 && stride == 1) return launch_conv<0, 7, 1, 1>(a, s);
+  return DSU_EUNSUP;
+}
+
+}  // extern "C"

@@ -1,0 +1,244 @@
+"""Thin tensor-level wrappers over the C ABI (one function per exported kernel).
+
+These only allocate outputs (torch caching allocator), pass raw device pointers and the
+current torch stream, and turn non-zero return codes into DsuError.  No arithmetic
+happens in Python.
+"""
+import ctypes as C
+from dataclasses import dataclass
+
+import torch
+
+from . import _lib
+from ._lib import HashGridCfg, SdfMlp, check, lib, ptr, stream
+
+
+@dataclass(frozen=True)
+class HashGridConfig:
+    """configs/neuralangelo-ortho-wmask.yaml:52-62 (xyz_encoding_config)."""
+    n_levels: int = 10
+    n_features_per_level: int = 2
+    log2_hashmap_size: int = 19
+    base_resolution: int = 32
+    per_level_scale: float = 1.3195079107728942
+
+    def c(self):
+        return HashGridCfg(self.n_levels, self.n_features_per_level, self.log2_hashmap_size,
+                           self.base_resolution, self.per_level_scale)
+
+    def levels(self):
+        return _lib.hashgrid_levels(self.c())
+
+    @property
+    def n_entries(self):
+        return self.levels()["offsets"][self.n_levels]
+
+    @property
+    def n_params(self):
+        return self.n_entries * self.n_features_per_level
+
+    @property
+    def n_output_dims(self):
+        return self.n_levels * self.n_features_per_level
+
+
+def _f32c(t):
+    return t.contiguous() if t.dtype == torch.float32 else t.float().contiguous()
+
+
+# ------------------------------------------------------------------ hash grid / SDF network
+def hashgrid_encode_fwd(cfg: HashGridConfig, table_f16, x, active_levels):
+    x = _f32c(x)
+    n = x.shape[0]
+    out = torch.empty((n, cfg.n_output_dims), dtype=torch.float16, device=x.device)
+    c = cfg.c()
+    check(lib().dsu_hashgrid_encode_fwd(C.byref(c), ptr(table_f16, torch.float16), ptr(x), n,
+                                        int(active_levels), ptr(out), stream()),
+          "dsu_hashgrid_encode_fwd")
+    return out
+
+
+def hashgrid_encode_bwd(cfg: HashGridConfig, x, dout, active_levels, grad_table=None):
+    x = _f32c(x)
+    dout = _f32c(dout)
+    n = x.shape[0]
+    if grad_table is None:
+        grad_table = torch.zeros(cfg.n_params, dtype=torch.float32, device=x.device)
+    c = cfg.c()
+    check(lib().dsu_hashgrid_encode_bwd(C.byref(c), ptr(x), ptr(dout), n, int(active_levels),
+                                        ptr(grad_table, torch.float32), stream()),
+          "dsu_hashgrid_encode_bwd")
+    return grad_table
+
+
+def _mlp_struct(w0, b0, w1, b1):
+    for t in (w0, b0, w1, b1):
+        ptr(t, torch.float32)
+    return SdfMlp(w0.data_ptr(), b0.data_ptr(), w1.data_ptr(), b1.data_ptr())
+
+
+def sdf_fwd(cfg, table_f16, mlp, pts, radius, active_levels, n_out=1):
+    """mlp = (w0 (64,3+2L), b0 (64), w1 (13,64), b1 (13)) effective f32 weights."""
+    pts = _f32c(pts)
+    n = pts.shape[0]
+    out = torch.empty((n, n_out), dtype=torch.float32, device=pts.device)
+    c, m = cfg.c(), _mlp_struct(*mlp)
+    check(lib().dsu_sdf_fwd(C.byref(c), ptr(table_f16, torch.float16), C.byref(m), ptr(pts), n,
+                            float(radius), int(active_levels), int(n_out), ptr(out), stream()),
+          "dsu_sdf_fwd")
+    return out
+
+
+def sdf_fd_fwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, with_grad=True,
+               with_feature=True, with_laplace=True):
+    pts = _f32c(pts)
+    n = pts.shape[0]
+    dev = pts.device
+    sdf = torch.empty(n, dtype=torch.float32, device=dev)
+    grad = torch.empty((n, 3), dtype=torch.float32, device=dev) if with_grad else None
+    feat = torch.empty((n, 13), dtype=torch.float32, device=dev) if with_feature else None
+    lap = torch.empty(n, dtype=torch.float32, device=dev) if with_laplace else None
+    c, m = cfg.c(), _mlp_struct(*mlp)
+    check(lib().dsu_sdf_fd_fwd(C.byref(c), ptr(table_f16, torch.float16), C.byref(m), ptr(pts),
+                               n, float(radius), float(eps), int(active_levels), ptr(sdf),
+                               ptr(grad), ptr(feat), ptr(lap), stream()), "dsu_sdf_fd_fwd")
+    return sdf, grad, feat, lap
+
+
+def sdf_fd_bwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, d_sdf, d_grad, d_feature,
+               d_laplace, grad_table=None):
+    pts = _f32c(pts)
+    n = pts.shape[0]
+    dev = pts.device
+    w0, b0, w1, b1 = mlp
+    if grad_table is None:
+        grad_table = torch.zeros(cfg.n_params, dtype=torch.float32, device=dev)
+    g = [torch.zeros_like(t) for t in (w0, b0, w1, b1)]
+    c, m = cfg.c(), _mlp_struct(*mlp)
+    d = [None if t is None else _f32c(t) for t in (d_sdf, d_grad, d_feature, d_laplace)]
+    check(lib().dsu_sdf_fd_bwd(C.byref(c), ptr(table_f16, torch.float16), C.byref(m), ptr(pts),
+                               n, float(radius), float(eps), int(active_levels), ptr(d[0]),
+                               ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(grad_table), ptr(g[0]),
+                               ptr(g[1]), ptr(g[2]), ptr(g[3]), stream()), "dsu_sdf_fd_bwd")
+    return grad_table, g
+
+
+# ------------------------------------------------------------------ nerfacc replacements
+def ray_aabb(rays_o, rays_d, aabb6, jitter=None, step=0.0):
+    rays_o, rays_d = _f32c(rays_o), _f32c(rays_d)
+    n = rays_o.shape[0]
+    t_min = torch.empty(n, dtype=torch.float32, device=rays_o.device)
+    t_max = torch.empty_like(t_min)
+    a = (C.c_float * 6)(*[float(v) for v in aabb6])
+    check(lib().dsu_ray_aabb(ptr(rays_o), ptr(rays_d), n, a, ptr(jitter), float(step),
+                             ptr(t_min), ptr(t_max), stream()), "dsu_ray_aabb")
+    return t_min, t_max
+
+
+def ray_march(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step):
+    """Two-pass marching.  Returns ray_indices (int64), t_starts, t_ends (n,), and the per-ray
+    (offsets, counts) int32 packing the compositing kernels consume."""
+    rays_o, rays_d = _f32c(rays_o), _f32c(rays_d)
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    a = (C.c_float * 6)(*[float(v) for v in aabb6])
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    occp = ptr(occ_binary, torch.uint8) if occ_binary is not None else None
+    check(lib().dsu_ray_march_count(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), n, a, occp,
+                                    int(res), float(step), ptr(counts), stream()),
+          "dsu_ray_march_count")
+    csum = torch.cumsum(counts, 0, dtype=torch.int32)
+    offsets = (csum - counts).contiguous()
+    total = int(csum[-1].item()) if n > 0 else 0
+    ray_indices = torch.empty(total, dtype=torch.int64, device=dev)
+    t_starts = torch.empty(total, dtype=torch.float32, device=dev)
+    t_ends = torch.empty(total, dtype=torch.float32, device=dev)
+    if total > 0:
+        check(lib().dsu_ray_march_fill(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), n, a,
+                                       occp, int(res), float(step), ptr(offsets),
+                                       ptr(ray_indices), ptr(t_starts), ptr(t_ends), stream()),
+              "dsu_ray_march_fill")
+    return ray_indices, t_starts, t_ends, offsets, counts
+
+
+def weights_from_alpha_fwd(alpha, offsets, counts):
+    alpha = _f32c(alpha)
+    w = torch.empty_like(alpha)
+    check(lib().dsu_weights_from_alpha_fwd(ptr(alpha), ptr(offsets, torch.int32),
+                                           ptr(counts, torch.int32), offsets.shape[0], ptr(w),
+                                           stream()), "dsu_weights_from_alpha_fwd")
+    return w
+
+
+def weights_from_alpha_bwd(alpha, weights, d_weights, offsets, counts):
+    d_alpha = torch.empty_like(alpha)
+    check(lib().dsu_weights_from_alpha_bwd(ptr(_f32c(alpha)), ptr(_f32c(weights)),
+                                           ptr(_f32c(d_weights)), ptr(offsets, torch.int32),
+                                           ptr(counts, torch.int32), offsets.shape[0],
+                                           ptr(d_alpha), stream()), "dsu_weights_from_alpha_bwd")
+    return d_alpha
+
+
+def accumulate_fwd(weights, values, offsets, counts):
+    weights = _f32c(weights)
+    n_rays = offsets.shape[0]
+    ch = 1 if values is None else values.shape[-1]
+    v = None if values is None else _f32c(values)
+    out = torch.empty((n_rays, ch), dtype=torch.float32, device=weights.device)
+    check(lib().dsu_accumulate_fwd(ptr(weights), ptr(v), ch, ptr(offsets, torch.int32),
+                                   ptr(counts, torch.int32), n_rays, ptr(out), stream()),
+          "dsu_accumulate_fwd")
+    return out
+
+
+def occgrid_ema(occs, idx, occ, decay):
+    check(lib().dsu_occgrid_ema(ptr(occs, torch.float32), ptr(idx, torch.int64) if idx is not None
+                                else None, ptr(_f32c(occ)), occ.shape[0], float(decay), stream()),
+          "dsu_occgrid_ema")
+
+
+def occgrid_binarize(occs, thre):
+    out = torch.empty(occs.shape[0], dtype=torch.uint8, device=occs.device)
+    check(lib().dsu_occgrid_binarize(ptr(occs, torch.float32), occs.shape[0], float(thre),
+                                     ptr(out), stream()), "dsu_occgrid_binarize")
+    return out
+
+
+# ------------------------------------------------------------------ style translator
+ACT = {"none": 0, None: 0, "relu": 1, "leaky_relu": 2, "tanh": 3}
+
+
+def ric_offsets(H, W, device):
+    out = torch.empty((18, H, W), dtype=torch.float32, device=device)
+    check(lib().dsu_ric_offsets(H, W, ptr(out), stream()), "dsu_ric_offsets")
+    return out
+
+
+def deform_conv3x3(x, offset, weight, ep_scale=None, ep_shift=None, act=None, residual=None):
+    """offset: (18,H,W) shared by the batch, or (B,18,H,W)."""
+    x, weight, offset = _f32c(x), _f32c(weight), _f32c(offset)
+    B, Cin, H, W = x.shape
+    O = weight.shape[0]
+    assert weight.shape[1:] == (Cin, 3, 3), "dsu deform conv: 3x3, groups=1 only"
+    bstride = 0 if offset.dim() == 3 or offset.shape[0] == 1 else 18 * H * W
+    out = torch.empty((B, O, H, W), dtype=torch.float32, device=x.device)
+    check(lib().dsu_deform_conv3x3_fwd(ptr(x), ptr(offset), bstride, ptr(weight), B, Cin, H, W, O,
+                                       ptr(ep_scale), ptr(ep_shift), ACT[act],
+                                       ptr(residual), ptr(out), stream()),
+          "dsu_deform_conv3x3_fwd")
+    return out
+
+
+def conv2d(x, weight, bias=None, stride=1, padding=0, ep_scale=None, ep_shift=None, act=None,
+           residual=None):
+    x, weight = _f32c(x), _f32c(weight)
+    B, Cin, H, W = x.shape
+    O, Cw, k, k2 = weight.shape
+    assert Cw == Cin and k == k2
+    OH = (H + 2 * padding - k) // stride + 1
+    OW = (W + 2 * padding - k) // stride + 1
+    out = torch.empty((B, O, OH, OW), dtype=torch.float32, device=x.device)
+    check(lib().dsu_conv2d_fwd(ptr(x), ptr(weight), ptr(bias), B, Cin, H, W, O, k, stride,
+                               padding, ptr(ep_scale), ptr(ep_shift), ACT[act], ptr(residual),
+                               ptr(out), stream()), "dsu_conv2d_fwd")
+    return out

@@ -1,0 +1,192 @@
+/*
+ * dsu_hip.h — C ABI of libdsu_hip.so, the MI355X (gfx950) hot path of DrawingSpinUp.
+ *
+ * Every entry point replaces one third-party native op that the reference reaches
+ * through a Python import (the reference ships no native code of its own).  The
+ * reference call site each function stands in for is cited as
+ * `<path under /root/reference>:<line>`.
+ *
+ * Conventions
+ *   - plain C, no torch types: device pointers, element counts, a hipStream_t passed
+ *     as void*.  The caller owns every buffer; nothing is allocated inside.
+ *   - all kernels are stream-ordered on `stream`; no internal synchronisation.
+ *   - return value: 0 = ok, <0 = DSU_E* error code (dsu_strerror gives the text).
+ *   - "f16" buffers hold IEEE binary16, "f32" IEEE binary32, row-major, contiguous.
+ */
+#ifndef DSU_HIP_H
+#define DSU_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSU_OK 0
+#define DSU_EINVAL (-1)   /* bad argument (null pointer, unsupported size) */
+#define DSU_ELAUNCH (-2)  /* hipLaunch / runtime error */
+#define DSU_EUNSUP (-3)   /* configuration not supported by the kernels */
+
+#define DSU_MAX_LEVELS 16
+
+const char* dsu_strerror(int code);
+/* ABI version of this header; bumped on any signature change. */
+int dsu_abi_version(void);
+
+/* ------------------------------------------------------------------------------------
+ * Multi-resolution hash grid (replaces tiny-cuda-nn `tcnn.Encoding(3, {otype:HashGrid})`
+ * constructed at 2_charactor_reconstructor/instant_nsr/models/network_utils.py:46 and
+ * called at :55; hyper-parameters from configs/neuralangelo-ortho-wmask.yaml:52-62).
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  uint32_t n_levels;           /* 10 */
+  uint32_t n_features;         /* 2 (the kernels are specialised for 2) */
+  uint32_t log2_hashmap_size;  /* 19 */
+  uint32_t base_resolution;    /* 32 */
+  double per_level_scale;      /* 1.3195079107728942 */
+} dsu_hashgrid_cfg;
+
+/* Per-level derived quantities.  offsets[l] = first table ENTRY of level l (an entry is
+ * n_features values); offsets[n_levels] = total entries.  scale/resolution follow
+ * tcnn's grid_scale()/grid_resolution(); hashed[l]=1 when the level is addressed by the
+ * coherent-prime hash instead of the dense x+y*res+z*res^2 index. */
+typedef struct {
+  uint32_t offsets[DSU_MAX_LEVELS + 1];
+  uint32_t resolution[DSU_MAX_LEVELS];
+  float scale[DSU_MAX_LEVELS];
+  uint32_t hashed[DSU_MAX_LEVELS];
+} dsu_hashgrid_levels;
+
+/* Host-only: fill `out` for `cfg`.  Pure function; safe without a GPU. */
+int dsu_hashgrid_make_levels(const dsu_hashgrid_cfg* cfg, dsu_hashgrid_levels* out);
+
+/* tcnn.Encoding.__call__ (network_utils.py:55) fused with the progressive level mask
+ * (network_utils.py:56): out[n, 2*l..2*l+1] = trilinear lookup for l < active_levels,
+ * 0 for the masked levels.  x: (n,3) f32 in [0,1]; table: (total_entries,2) f16;
+ * out: (n, 2*n_levels) f16. */
+int dsu_hashgrid_encode_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16,
+                            const float* x, int64_t n, uint32_t active_levels,
+                            void* out_f16, void* stream);
+
+/* Backward of the above w.r.t. the table only (the reference never needs dL/dx:
+ * grad_type=finite_difference, neuralangelo-ortho-wmask.yaml:42).  dout: (n, 2*n_levels)
+ * f32; grad_table: (total_entries,2) f32, ACCUMULATED into (caller zeroes it). */
+int dsu_hashgrid_encode_bwd(const dsu_hashgrid_cfg* cfg, const float* x, const float* dout,
+                            int64_t n, uint32_t active_levels, float* grad_table,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Fused SDF network: contract -> hash grid -> cat(xyz*2-1, enc*mask) -> Linear(23,64) ->
+ * Softplus(beta=100) -> Linear(64,13).  Replaces VolumeSDF.forward_level
+ * (instant_nsr/models/geometry.py:189-194) and the per-point body of VolumeSDF.forward
+ * (geometry.py:135-187): N1-N5 of SURVEY.md §8(a).
+ * Weights are the EFFECTIVE (weight-norm already applied) row-major nn.Linear matrices.
+ * ---------------------------------------------------------------------------------- */
+typedef struct {
+  const float* w0; /* (64, 23) */
+  const float* b0; /* (64) */
+  const float* w1; /* (13, 64) */
+  const float* b1; /* (13) */
+} dsu_sdf_mlp;
+
+/* pts: (n,3) f32 world coordinates in [-radius, radius]; out: (n, n_out) f32 where
+ * n_out = 1 (sdf only: forward_level / occupancy / export) or 13 (sdf + feature). */
+int dsu_sdf_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                const float* pts, int64_t n, float radius, uint32_t active_levels,
+                uint32_t n_out, float* out, void* stream);
+
+/* VolumeSDF.forward(points, with_grad, with_feature, with_laplace) with
+ * grad_type=finite_difference (geometry.py:158-176): 7 network evaluations per point
+ * (centre + 6 clamped +-eps offsets).  Outputs (any may be NULL except sdf):
+ *   sdf (n), grad (n,3), feature (n,13), laplace (n). */
+int dsu_sdf_fd_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                   const float* pts, int64_t n, float radius, float eps,
+                   uint32_t active_levels, float* sdf, float* grad, float* feature,
+                   float* laplace, void* stream);
+
+/* Backward of dsu_sdf_fd_fwd w.r.t. table and MLP parameters.  Upstream gradients
+ * (NULL = zero): d_sdf (n), d_grad (n,3), d_feature (n,13), d_laplace (n).
+ * Accumulates into grad_table (entries,2) f32 and g_w0 (64,23), g_b0 (64), g_w1 (13,64),
+ * g_b1 (13) f32 — caller zeroes them. */
+int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                   const float* pts, int64_t n, float radius, float eps,
+                   uint32_t active_levels, const float* d_sdf, const float* d_grad,
+                   const float* d_feature, const float* d_laplace, float* grad_table,
+                   float* g_w0, float* g_b0, float* g_w1, float* g_b1, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * nerfacc 0.3.3 replacements (call sites instant_nsr/models/neus.py:53-57,84,119-129,
+ * 147-152).
+ * ---------------------------------------------------------------------------------- */
+
+/* ray_aabb_intersect + optional stratified jitter: t_min += jitter*step (jitter may be
+ * NULL).  rays_o/rays_d (n,3) f32; aabb 6 floats (host values). */
+int dsu_ray_aabb(const float* rays_o, const float* rays_d, int64_t n_rays, const float* aabb6,
+                 const float* jitter, float step, float* t_min, float* t_max, void* stream);
+
+/* Pass 1 of ray_marching: count samples per ray through the binary occupancy grid
+ * (res^3 uint8, index x*res*res + y*res + z).  num_steps: (n_rays) int32. */
+int dsu_ray_march_count(const float* rays_o, const float* rays_d, const float* t_min,
+                        const float* t_max, int64_t n_rays, const float* aabb6,
+                        const uint8_t* occ_binary, int32_t res, float step,
+                        int32_t* num_steps, void* stream);
+
+/* Pass 2: fill.  offsets: (n_rays) int32 exclusive prefix sum of num_steps.
+ * ray_indices: (n_samples) int64; t_starts/t_ends: (n_samples) f32. */
+int dsu_ray_march_fill(const float* rays_o, const float* rays_d, const float* t_min,
+                       const float* t_max, int64_t n_rays, const float* aabb6,
+                       const uint8_t* occ_binary, int32_t res, float step,
+                       const int32_t* offsets, int64_t* ray_indices, float* t_starts,
+                       float* t_ends, void* stream);
+
+/* render_weight_from_alpha (neus.py:147): per ray segment [offsets[r], offsets[r]+cnt[r])
+ * w_i = alpha_i * prod_{j<i}(1-alpha_j).  One ray per thread. */
+int dsu_weights_from_alpha_fwd(const float* alpha, const int32_t* offsets, const int32_t* counts,
+                               int64_t n_rays, float* weights, void* stream);
+int dsu_weights_from_alpha_bwd(const float* alpha, const float* weights, const float* d_weights,
+                               const int32_t* offsets, const int32_t* counts, int64_t n_rays,
+                               float* d_alpha, void* stream);
+
+/* accumulate_along_rays (neus.py:148-152): out[r, c] = sum_i w_i * v[i, c]  (v NULL -> 1). */
+int dsu_accumulate_fwd(const float* weights, const float* values, int32_t channels,
+                       const int32_t* offsets, const int32_t* counts, int64_t n_rays,
+                       float* out, void* stream);
+
+/* OccupancyGrid._update tail (nerfacc 0.3.3 grid.py): occs[idx] = max(occs[idx]*decay, occ).
+ * idx may be NULL (= all cells, warm-up). */
+int dsu_occgrid_ema(float* occs, const int64_t* idx, const float* occ, int64_t n, float decay,
+                    void* stream);
+/* binary = occs > thre  (thre = min(mean(occs), occ_thre) computed by the caller). */
+int dsu_occgrid_binarize(const float* occs, int64_t n_cells, float thre, uint8_t* binary,
+                         void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Style translator (3_style_translator/training/models.py).
+ * ---------------------------------------------------------------------------------- */
+
+/* generate_coordinates (models.py:551-604): the 18-channel fixed offset map for an (H,W)
+ * image, written as (18,H,W) f32 (batch broadcast is the caller's view). */
+int dsu_ric_offsets(int32_t H, int32_t W, float* offsets, void* stream);
+
+/* torchvision.ops.deform_conv2d(input, offset, weight, padding=(1,1)) for a 3x3 kernel,
+ * stride 1, dilation 1, one offset group, no bias, no mask (call sites models.py:302-351).
+ * input (B,C,H,W) f32; offset (18,H,W) f32 shared over the batch (offset_batch_stride=0)
+ * or per image; weight (O,C,3,3); out (B,O,H,W).
+ * Optional fused epilogue (scale/shift per output channel = folded eval BatchNorm, then
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 tanh), optional residual added last. */
+int dsu_deform_conv3x3_fwd(const float* input, const float* offset, int64_t offset_batch_stride,
+                           const float* weight, int32_t B, int32_t C, int32_t H, int32_t W,
+                           int32_t O, const float* ep_scale, const float* ep_shift, int32_t act,
+                           const float* residual, float* out, void* stream);
+
+/* nn.Conv2d forward, NCHW f32, square kernel k in {1,3,7}, stride in {1,2}, zero padding,
+ * same fused epilogue (GeneratorJ, models.py:41-129).  bias may be NULL. */
+int dsu_conv2d_fwd(const float* input, const float* weight, const float* bias, int32_t B,
+                   int32_t C, int32_t H, int32_t W, int32_t O, int32_t k, int32_t stride,
+                   int32_t pad, const float* ep_scale, const float* ep_shift, int32_t act,
+                   const float* residual, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DSU_HIP_H */

@@ -1,0 +1,165 @@
+"""HIP hash-grid / fused SDF kernels vs the CPU oracle (through the C ABI)."""
+import numpy as np
+import pytest
+import torch
+
+from drawingspinup_amd import ops
+from oracle import hashgrid as oh
+
+pytestmark = pytest.mark.gpu
+
+CFG = ops.HashGridConfig()
+LV = oh.make_levels()
+
+
+def _table(seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return ((torch.rand(CFG.n_entries, 2, generator=g) * 2 - 1) * scale).half()
+
+
+def _mlp(seed, din=23):
+    g = torch.Generator().manual_seed(seed)
+    w0 = torch.randn(64, din, generator=g) * 0.3
+    b0 = torch.randn(64, generator=g) * 0.05
+    w1 = torch.randn(13, 64, generator=g) * 0.2
+    b1 = torch.randn(13, generator=g) * 0.1
+    return [w0, b0, w1, b1]
+
+
+def _pts(n, seed, lo=0.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(n, 3, generator=g) * (hi - lo) + lo
+
+
+@pytest.mark.parametrize("active", [0, 4, 7, 10])
+def test_encode_fwd_bit_exact(dev, active):
+    tab = _table(1)
+    x = _pts(4099, 2)
+    # exercise the domain edges too
+    x[0] = 0.0
+    x[1] = 1.0
+    x[2] = torch.tensor([1.0, 0.0, 0.5])
+    ref = oh.encode(tab.numpy(), x.numpy(), LV, active)
+    out = ops.hashgrid_encode_fwd(CFG, tab.to(dev), x.to(dev), active).cpu().numpy()
+    assert out.dtype == np.float16 and out.shape == (4099, 20)
+    # f16 FMA chain restated exactly -> bit-exact
+    assert np.array_equal(out.view(np.uint16), ref.view(np.uint16))
+
+
+def test_encode_empty(dev):
+    tab = _table(1).to(dev)
+    out = ops.hashgrid_encode_fwd(CFG, tab, torch.empty(0, 3, device=dev), 4)
+    assert out.shape == (0, 20)
+
+
+def test_encode_bwd(dev):
+    x = _pts(3001, 3)
+    g = torch.Generator().manual_seed(4)
+    dout = torch.randn(3001, 20, generator=g)
+    active = 6
+    ref = oh.encode_bwd(x.numpy(), dout.numpy().astype(np.float64), LV, active).reshape(-1)
+    got = ops.hashgrid_encode_bwd(CFG, x.to(dev), dout.to(dev), active).cpu().numpy()
+    # same set of touched entries (integer indexing) ...
+    assert np.array_equal(ref != 0, got != 0)
+    # ... and values to f32 atomic-order rounding
+    np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5)
+    # masked levels receive nothing
+    assert not got[LV["offsets"][active] * 2:].any()
+
+
+@pytest.mark.parametrize("active,n_out", [(4, 1), (4, 13), (10, 13), (6, 1)])
+def test_sdf_fwd(dev, active, n_out):
+    tab = _table(5, 0.5)
+    mlp = _mlp(6)
+    pts = _pts(5000, 7, -1.0, 1.0)
+    ref = oh.sdf_network(tab.numpy(), [m.numpy() for m in mlp], pts.numpy(), 1.0, LV, active)
+    out = ops.sdf_fwd(CFG, tab.to(dev), [m.to(dev) for m in mlp], pts.to(dev), 1.0, active,
+                      n_out).cpu().numpy()
+    np.testing.assert_allclose(out, ref[:, :n_out], rtol=2e-5, atol=2e-5)
+
+
+def test_sdf_fd_fwd(dev):
+    tab = _table(8, 0.5)
+    mlp = _mlp(9)
+    pts = _pts(3000, 10, -1.0, 1.0)
+    pts[0] = torch.tensor([1.0, -1.0, 0.999])   # clamp path of the +-eps offsets
+    eps, active = 0.0213, 5
+    sdf, grad, feat, lap = oh.sdf_fd(tab.numpy(), [m.numpy() for m in mlp], pts.numpy(), 1.0,
+                                     eps, LV, active)
+    o = ops.sdf_fd_fwd(CFG, tab.to(dev), [m.to(dev) for m in mlp], pts.to(dev), 1.0, eps, active)
+    np.testing.assert_allclose(o[0].cpu().numpy(), sdf, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(o[2].cpu().numpy(), feat, rtol=2e-5, atol=2e-5)
+    # differences of f32 sdf values divided by eps / eps^2 amplify rounding
+    np.testing.assert_allclose(o[1].cpu().numpy(), grad, rtol=1e-3, atol=2e-5 / eps)
+    np.testing.assert_allclose(o[3].cpu().numpy(), lap, rtol=1e-3, atol=8e-5 / eps ** 2)
+
+
+def _torch_fd_loss(tab64, mlp64, pts, eps, active, radius, d):
+    """Differentiable float64 restatement (indices/weights from the oracle) for gradients."""
+    def net(p):
+        xc = oh.contract(p, radius)
+        feats = []
+        for l in range(active):
+            idx, w = oh.corner_indices_weights(LV, l, xc)
+            t = tab64[LV["offsets"][l]:LV["offsets"][l + 1]]
+            f = (t[torch.from_numpy(idx)] * torch.from_numpy(w).double().unsqueeze(-1)).sum(1)
+            feats.append(f)
+        nl = len(LV["resolution"])
+        feats.append(torch.zeros(p.shape[0], 2 * (nl - active), dtype=torch.float64))
+        xyz = torch.from_numpy(xc.astype(np.float32) * np.float32(2) + np.float32(-1)).double()
+        inp = torch.cat([xyz] + feats, 1)
+        h = torch.nn.functional.softplus(inp @ mlp64[0].T + mlp64[1], beta=100)
+        return h @ mlp64[2].T + mlp64[3]
+    out = net(pts)
+    sdf = out[:, 0]
+    e = np.float32(eps)
+    offs = np.array([[e, 0, 0], [-e, 0, 0], [0, e, 0], [0, -e, 0], [0, 0, e], [0, 0, -e]],
+                    np.float32)
+    pd = np.clip(pts[:, None, :] + offs[None], -np.float32(radius), np.float32(radius))
+    sd = net(pd.reshape(-1, 3).astype(np.float32))[:, 0].view(-1, 6)
+    grad = 0.5 * (sd[:, 0::2] - sd[:, 1::2]) / float(e)
+    lap = (sd[:, 0::2] + sd[:, 1::2] - 2 * sdf[:, None]).sum(-1) / float(e) ** 2
+    return (sdf * d[0]).sum() + (grad * d[1]).sum() + (out * d[2]).sum() + (lap * d[3]).sum()
+
+
+def test_sdf_fd_bwd(dev):
+    tab = _table(11, 0.5)
+    mlp = _mlp(12)
+    n = 777   # not a multiple of 64: exercises the inactive-lane path
+    pts = _pts(n, 13, -1.0, 1.0)
+    eps, active, radius = 0.031, 5, 1.0
+    g = torch.Generator().manual_seed(14)
+    d = [torch.randn(n, generator=g), torch.randn(n, 3, generator=g) * 0.1,
+         torch.randn(n, 13, generator=g), torch.randn(n, generator=g) * 1e-3]
+    tab64 = tab.double().requires_grad_(True)
+    mlp64 = [m.double().requires_grad_(True) for m in mlp]
+    loss = _torch_fd_loss(tab64, mlp64, pts.numpy(), eps, active, radius, [x.double() for x in d])
+    loss.backward()
+    gt, gm = ops.sdf_fd_bwd(CFG, tab.to(dev), [m.to(dev) for m in mlp], pts.to(dev), radius, eps,
+                            active, *[x.to(dev) for x in d])
+    gt = gt.cpu().numpy().reshape(-1, 2)
+    ref_t = tab64.grad.numpy()
+    assert np.array_equal(ref_t != 0, gt != 0)          # same entries touched
+    scale = np.abs(ref_t).max()
+    np.testing.assert_allclose(gt, ref_t, rtol=2e-3, atol=2e-5 * scale)
+    for got, ref in zip(gm, mlp64):
+        r = ref.grad.numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), r, rtol=2e-3, atol=2e-5 * np.abs(r).max())
+
+
+def test_sdf_full_size_linearity(dev):
+    """BASELINE size (2^21-point export chunk): property check instead of the slow oracle.
+    The network is affine in the second-layer bias: out(b1 + c) - out(b1) == c."""
+    tab = _table(15, 0.5).to(dev)
+    mlp = [m.to(dev) for m in _mlp(16)]
+    pts = _pts(2097152, 17, -1.0, 1.0).to(dev)
+    a = ops.sdf_fwd(CFG, tab, mlp, pts, 1.0, 7, 1)
+    mlp2 = [mlp[0], mlp[1], mlp[2], mlp[3] + 0.25]
+    b = ops.sdf_fwd(CFG, tab, mlp2, pts, 1.0, 7, 1)
+    assert torch.isfinite(a).all()
+    torch.testing.assert_close(b - a, torch.full_like(a, 0.25), rtol=0, atol=1e-5)
+    # and a sampled subset against the oracle
+    sel = torch.arange(0, 2097152, 4099)
+    ref = oh.sdf_network(tab.cpu().numpy(), [m.cpu().numpy() for m in mlp],
+                         pts[sel].cpu().numpy(), 1.0, LV, 7)[:, :1]
+    np.testing.assert_allclose(a[sel].cpu().numpy(), ref, rtol=2e-5, atol=2e-5)

@@ -1,0 +1,89 @@
+"""HIP f32-MFMA conv / fixed-offset deformable conv vs the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from drawingspinup_amd import ops
+from oracle import style_ref as sr
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, s=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * s
+
+
+def test_ric_offsets(dev):
+    for H, W in [(32, 32), (64, 48), (128, 128)]:
+        ref = sr.generate_coordinates(H, W)
+        got = ops.ric_offsets(H, W, dev).cpu()
+        assert torch.equal(got[8:10], torch.zeros(2, H, W))       # centre tap: exactly 0
+        # cos/sin/atan2 differ by an ulp between host libm and the device; where that flips
+        # round(1e4*theta) the angle moves by 1e-4 (the reference computes this map on the
+        # host; the product path does too, see style/generators.py — this kernel is the
+        # on-device variant)
+        d = (got - ref).abs()
+        assert d.max() <= 1.5e-4
+        assert (d > 3e-6).float().mean() < 2e-3
+
+
+@pytest.mark.parametrize("C,O,H,W", [(6, 32, 32, 32), (32, 64, 24, 40), (128, 128, 16, 16),
+                                     (166, 64, 20, 20), (5, 3, 9, 7)])
+def test_deform_conv_vs_oracle(dev, C, O, H, W):
+    x = _rand((2, C, H, W), 1)
+    w = _rand((O, C, 3, 3), 2, 0.1)
+    off = _rand((1, 18, H, W), 3, 1.5)            # includes samples that leave the image
+    ref = sr.deform_conv2d(x, off.expand(2, -1, -1, -1), w)
+    got = ops.deform_conv3x3(x.to(dev), off[0].to(dev), w.to(dev)).cpu().double()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    # per-image offsets
+    off2 = _rand((2, 18, H, W), 4, 1.0)
+    ref2 = sr.deform_conv2d(x, off2, w)
+    got2 = ops.deform_conv3x3(x.to(dev), off2.to(dev), w.to(dev)).cpu().double()
+    torch.testing.assert_close(got2, ref2, rtol=1e-4, atol=1e-4)
+
+
+def test_deform_conv_zero_offset_is_conv(dev):
+    x = _rand((1, 16, 33, 31), 5)
+    w = _rand((32, 16, 3, 3), 6, 0.1)
+    off = torch.zeros(18, 33, 31)
+    got = ops.deform_conv3x3(x.to(dev), off.to(dev), w.to(dev)).cpu()
+    torch.testing.assert_close(got, F.conv2d(x, w, padding=1), rtol=1e-4, atol=1e-4)
+
+
+def test_deform_conv_ric_epilogue(dev):
+    H = W = 64
+    x = _rand((1, 64, H, W), 7)
+    w = _rand((128, 64, 3, 3), 8, 0.05)
+    off = sr.generate_coordinates(H, W)
+    scale, shift = _rand((128,), 9).abs() + 0.5, _rand((128,), 10)
+    res = _rand((1, 128, H, W), 11)
+    ref = sr.deform_conv2d(x, off[None], w)
+    ref = F.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)) + res.double()
+    got = ops.deform_conv3x3(x.to(dev), off.to(dev), w.to(dev), scale.to(dev), shift.to(dev),
+                             "relu", res.to(dev)).cpu().double()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("k,s,p,C,O,H,W,bias,act", [
+    (7, 1, 3, 6, 32, 40, 40, False, "leaky_relu"),
+    (3, 2, 1, 32, 64, 40, 40, False, "leaky_relu"),
+    (3, 2, 1, 64, 128, 21, 19, False, "relu"),
+    (3, 1, 1, 128, 128, 16, 16, False, None),
+    (3, 1, 1, 192, 128, 24, 24, False, "relu"),
+    (7, 1, 3, 166, 64, 24, 24, False, "relu"),
+    (1, 1, 0, 64, 3, 32, 32, True, "tanh"),
+])
+def test_conv2d_vs_oracle(dev, k, s, p, C, O, H, W, bias, act):
+    x = _rand((2, C, H, W), 1)
+    w = _rand((O, C, k, k), 2, 1.0 / np.sqrt(C * k * k))
+    b = _rand((O,), 3) if bias else None
+    g, beta = _rand((O,), 4).abs() + 0.5, _rand((O,), 5)
+    mean, var = _rand((O,), 6, 0.1), _rand((O,), 7).abs() + 0.5
+    ref = sr.conv_bn_act(x, w, b, s, p, (g, beta, mean, var, 1e-5), act)
+    scale = g / torch.sqrt(var + 1e-5)
+    shift = beta - mean * scale
+    got = ops.conv2d(x.to(dev), w.to(dev), None if b is None else b.to(dev), s, p, scale.to(dev),
+                     shift.to(dev), act).cpu().double()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
