@@ -43,7 +43,8 @@ _PROTOS = {
     "dsu_sdf_fd_fwd": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, c_i64, c_f32, c_f32,
                        c_u32, P, P, P, P, P],
     "dsu_sdf_fd_bwd": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, c_i64, c_f32, c_f32,
-                       c_u32, P, P, P, P, P, P, P, P, P, P],
+                       c_u32, P, P, P, P, P, P, P, P, P, P, c_i64, P],
+    "dsu_sdf_fd_bwd_workspace_bytes": [C.POINTER(HashGridCfg), c_i64],
     "dsu_ray_aabb": [P, P, c_i64, P, P, c_f32, P, P, P],
     "dsu_ray_march_count": [P, P, P, P, c_i64, P, P, c_i32, c_f32, P, P],
     "dsu_ray_march_fill": [P, P, P, P, c_i64, P, P, c_i32, c_f32, P, P, P, P, P],
@@ -79,7 +80,7 @@ def lib():
         h.dsu_strerror.argtypes = [C.c_int]
         for name, args in _PROTOS.items():
             fn = getattr(h, name)  # AttributeError here = header/library mismatch
-            fn.restype = C.c_int
+            fn.restype = C.c_int64 if name.endswith("_bytes") else C.c_int
             fn.argtypes = args
         _lib = h
     return _lib

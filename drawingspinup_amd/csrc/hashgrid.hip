@@ -338,6 +338,55 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
   }
 }
 
+constexpr int GC_LOG2 = 12;
+constexpr int GC_SLOTS = 1 << GC_LOG2;
+constexpr uint32_t GC_EMPTY = 0xFFFFFFFFu;
+
+__device__ __forceinline__ void grad_cache_add(uint32_t* keys, float* vals,
+                                               float* __restrict__ gtable, uint32_t entry,
+                                               float v0, float v1) {
+  uint32_t slot = (entry * 2654435761u) >> (32 - GC_LOG2);
+#pragma unroll
+  for (int probe = 0; probe < 3; ++probe) {
+    const uint32_t old = atomicCAS(&keys[slot], GC_EMPTY, entry);
+    if (old == GC_EMPTY || old == entry) {
+      atomicAdd(&vals[2 * slot], v0);       // ds_add_f32
+      atomicAdd(&vals[2 * slot + 1], v1);
+      return;
+    }
+    slot = (slot + 1) & (GC_SLOTS - 1);
+  }
+  unsafeAtomicAdd(gtable + (size_t)entry * 2, v0);
+  unsafeAtomicAdd(gtable + (size_t)entry * 2 + 1, v1);
+}
+
+// LDS carve-up of the backward kernel (floats): MLP image | 4 per-wave staging areas | cache
+template <int NL>
+struct BwdLds {
+  static constexpr int DIN = 3 + 2 * NL;
+  static constexpr int PB = 8;
+  static constexpr int DINP = (DIN + 3) & ~3;
+  static constexpr int DOP = 16;
+  static constexpr int STAGE = PB * 65 * 2 + PB * DINP + PB * DOP;
+  static constexpr int RED = 4 * (DIN + 1 + NOUT + 1) * 64;
+  static constexpr int CACHE_OFF = MlpLds<NL>::TOTAL + 4 * STAGE;
+  static constexpr int CACHE = 3 * GC_SLOTS;
+  // the final block reduction reuses staging + cache space
+  static constexpr int EXTRA = (4 * STAGE + CACHE) > RED ? (4 * STAGE + CACHE) : RED;
+  static constexpr int TOTAL = MlpLds<NL>::TOTAL + EXTRA;
+};
+
+template <int NL>
+struct PartialLayout {
+  static constexpr int DIN = 3 + 2 * NL;
+  static constexpr int W0 = 0;
+  static constexpr int B0 = HID * DIN;
+  static constexpr int W1 = B0 + HID;
+  static constexpr int B1 = W1 + NOUT * HID;
+  static constexpr int USED = B1 + NOUT;
+  static constexpr int STRIDE = (USED + 63) & ~63;
+};
+
 // Backward of the 7-evaluation forward.  One point per lane; the per-wave outer products
 // for the MLP parameter gradients go through LDS so that lane j owns row j of g_w0 / column
 // j of g_w1 in registers for the whole grid-stride loop (no per-point atomics on the MLP).
@@ -347,8 +396,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_kernel(
     const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
     uint32_t active, const float* __restrict__ d_sdf, const float* __restrict__ d_grad,
     const float* __restrict__ d_feature, const float* __restrict__ d_laplace,
-    float* __restrict__ gtable, float* __restrict__ g_w0, float* __restrict__ g_b0,
-    float* __restrict__ g_w1, float* __restrict__ g_b1) {
+    float* __restrict__ gtable, float* __restrict__ partials) {
   using L = MlpLds<NL>;
   constexpr int DIN = L::DIN;
   extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -356,13 +404,27 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_kernel(
   // per-wave staging area behind the parameters, holding PB points at a time:
   //   dpre[PB][65], h[PB][65], in[PB][DIN+1], dout[PB][NOUT+1]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  constexpr int PB = 16;
-  constexpr int STAGE = PB * 65 * 2 + PB * (DIN + 1) + PB * (NOUT + 1);
+  constexpr int PB = BwdLds<NL>::PB;
+  constexpr int DINP = BwdLds<NL>::DINP;   // rows padded so they can be read back as float4
+  constexpr int DOP = BwdLds<NL>::DOP;
+  constexpr int STAGE = BwdLds<NL>::STAGE;
   float* stage = lds + L::TOTAL + wave * STAGE;
+  // workgroup-private gradient cache (open addressing, <=3 probes, overflow -> global atomic):
+  // the 7x8 corner contributions of neighbouring samples of a ray hit the same few hundred
+  // table entries, so they are summed with LDS atomics and each touched entry costs ONE
+  // global atomic pair per workgroup pass instead of one per contribution.
+  uint32_t* c_keys = reinterpret_cast<uint32_t*>(lds + BwdLds<NL>::CACHE_OFF);
+  float* c_vals = lds + BwdLds<NL>::CACHE_OFF + GC_SLOTS;
+  for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
+    c_keys[t] = GC_EMPTY;
+    c_vals[2 * t] = 0.0f;
+    c_vals[2 * t + 1] = 0.0f;
+  }
+  __syncthreads();
   float* s_dpre = stage;
   float* s_h = s_dpre + PB * 65;
   float* s_in = s_h + PB * 65;
-  float* s_do = s_in + PB * (DIN + 1);
+  float* s_do = s_in + PB * DINP;
 
   const int kmax = 3 + 2 * (int)active;
   float acc_w0[DIN];  // lane j: g_w0[j][:]
@@ -375,10 +437,9 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_kernel(
   for (int o = 0; o < NOUT; ++o) acc_w1[o] = 0.0f;
 
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  // all lanes of a wave iterate together (inactive lanes contribute zeros)
-  const int64_t base0 = blockIdx.x * (int64_t)blockDim.x + (threadIdx.x & ~63);
-  for (int64_t base = base0; base < n; base += stride) {
-    const int64_t i = base + lane;
+  // the whole workgroup iterates together (inactive lanes contribute zeros)
+  for (int64_t bbase = blockIdx.x * (int64_t)blockDim.x; bbase < n; bbase += stride) {
+    const int64_t i = bbase + threadIdx.x;
     const bool valid = i < n;
     float p[3] = {0.f, 0.f, 0.f};
     float ds = 0.f, dl = 0.f, dg[3] = {0.f, 0.f, 0.f};
@@ -474,15 +535,13 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_kernel(
             }
             if (valid && (d0 != 0.0f || d1 != 0.0f)) {
               const uint32_t hsize = m.off[l + 1] - m.off[l];
-              float* g = gtable + (size_t)m.off[l] * 2;
               CellPos cp = cell_of(m.scale[l], cx, cy, cz);
 #pragma unroll
               for (int c = 0; c < 8; ++c) {
                 uint32_t idx = grid_index(m.hashed[l], hsize, m.res[l], cp.c[0] + (c & 1),
                                           cp.c[1] + ((c >> 1) & 1), cp.c[2] + ((c >> 2) & 1));
                 float w = corner_weight(cp, c);
-                unsafeAtomicAdd(g + (size_t)idx * 2, w * d0);
-                unsafeAtomicAdd(g + (size_t)idx * 2 + 1, w * d1);
+                grad_cache_add(c_keys, c_vals, gtable, m.off[l] + idx, w * d0, w * d1);
               }
             }
           }
@@ -501,41 +560,110 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_kernel(
             s_h[r * 65 + j] = pre[j];
           }
 #pragma unroll
-          for (int k = 0; k < DIN; ++k) s_in[r * (DIN + 1) + k] = in[k];
+          for (int k = 0; k < DINP; ++k) s_in[r * DINP + k] = k < DIN ? in[k] : 0.0f;
 #pragma unroll
-          for (int o = 0; o < NOUT; ++o) s_do[r * (NOUT + 1) + o] = dout[o];
+          for (int o = 0; o < DOP; ++o) s_do[r * DOP + o] = o < NOUT ? dout[o] : 0.0f;
         }
         __builtin_amdgcn_wave_barrier();
         for (int pnt = 0; pnt < PB; ++pnt) {
           const float dp = s_dpre[pnt * 65 + lane];
           acc_b0 += dp;
+          const float4* in4 = reinterpret_cast<const float4*>(s_in + pnt * DINP);
 #pragma unroll
-          for (int k = 0; k < DIN; ++k)
-            if (k < kmax) acc_w0[k] = fmaf(dp, s_in[pnt * (DIN + 1) + k], acc_w0[k]);
+          for (int k4 = 0; k4 < DINP / 4; ++k4) {
+            if (4 * k4 < kmax) {
+              const float4 v = in4[k4];   // wave-uniform address: broadcast
+              acc_w0[4 * k4 + 0] = fmaf(dp, v.x, acc_w0[4 * k4 + 0]);
+              if (4 * k4 + 1 < DIN) acc_w0[4 * k4 + 1] = fmaf(dp, v.y, acc_w0[4 * k4 + 1]);
+              if (4 * k4 + 2 < DIN) acc_w0[4 * k4 + 2] = fmaf(dp, v.z, acc_w0[4 * k4 + 2]);
+              if (4 * k4 + 3 < DIN) acc_w0[4 * k4 + 3] = fmaf(dp, v.w, acc_w0[4 * k4 + 3]);
+            }
+          }
           const float hh = s_h[pnt * 65 + lane];
+          const float4* do4 = reinterpret_cast<const float4*>(s_do + pnt * DOP);
           if (e == 0) {
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o)
-              acc_w1[o] = fmaf(s_do[pnt * (NOUT + 1) + o], hh, acc_w1[o]);
-            if (lane < NOUT) acc_b1 += s_do[pnt * (NOUT + 1) + lane];
+            for (int o4 = 0; o4 < 4; ++o4) {
+              const float4 v = do4[o4];
+              acc_w1[4 * o4 + 0] = fmaf(v.x, hh, acc_w1[4 * o4 + 0]);
+              if (4 * o4 + 1 < NOUT) acc_w1[4 * o4 + 1] = fmaf(v.y, hh, acc_w1[4 * o4 + 1]);
+              if (4 * o4 + 2 < NOUT) acc_w1[4 * o4 + 2] = fmaf(v.z, hh, acc_w1[4 * o4 + 2]);
+              if (4 * o4 + 3 < NOUT) acc_w1[4 * o4 + 3] = fmaf(v.w, hh, acc_w1[4 * o4 + 3]);
+            }
+            if (lane < NOUT) acc_b1 += s_do[pnt * DOP + lane];
           } else {
-            acc_w1[0] = fmaf(s_do[pnt * (NOUT + 1)], hh, acc_w1[0]);
-            if (lane == 0) acc_b1 += s_do[pnt * (NOUT + 1)];
+            const float d0v = s_do[pnt * DOP];
+            acc_w1[0] = fmaf(d0v, hh, acc_w1[0]);
+            if (lane == 0) acc_b1 += d0v;
           }
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
+    // flush the gradient cache: one global atomic pair per touched entry, then reset
+    __syncthreads();
+    for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
+      const uint32_t key = c_keys[t];
+      if (key != GC_EMPTY) {
+        unsafeAtomicAdd(gtable + (size_t)key * 2, c_vals[2 * t]);
+        unsafeAtomicAdd(gtable + (size_t)key * 2 + 1, c_vals[2 * t + 1]);
+        c_keys[t] = GC_EMPTY;
+        c_vals[2 * t] = 0.0f;
+        c_vals[2 * t + 1] = 0.0f;
+      }
+    }
+    __syncthreads();
   }
-  // flush the per-lane parameter-gradient accumulators
+  // block-level reduction of the per-lane parameter-gradient accumulators through LDS, then
+  // ONE plain-store partial vector per workgroup (summed by reduce_partials_kernel): no
+  // same-address atomics on the 2.4k MLP gradient words.
+  constexpr int NQ = DIN + 1 + NOUT + 1;
+  __syncthreads();
+  float* red = lds + L::TOTAL;  // [4 waves][NQ][64], fits in the 4 staging areas
+  {
+    float* r = red + wave * NQ * 64;
 #pragma unroll
-  for (int k = 0; k < DIN; ++k)
-    if (acc_w0[k] != 0.0f) unsafeAtomicAdd(g_w0 + lane * DIN + k, acc_w0[k]);
-  if (acc_b0 != 0.0f) unsafeAtomicAdd(g_b0 + lane, acc_b0);
+    for (int k = 0; k < DIN; ++k) r[k * 64 + lane] = acc_w0[k];
+    r[DIN * 64 + lane] = acc_b0;
 #pragma unroll
-  for (int o = 0; o < NOUT; ++o)
-    if (acc_w1[o] != 0.0f) unsafeAtomicAdd(g_w1 + o * HID + lane, acc_w1[o]);
-  if (lane < NOUT && acc_b1 != 0.0f) unsafeAtomicAdd(g_b1 + lane, acc_b1);
+    for (int o = 0; o < NOUT; ++o) r[(DIN + 1 + o) * 64 + lane] = acc_w1[o];
+    r[(DIN + 1 + NOUT) * 64 + lane] = acc_b1;
+  }
+  __syncthreads();
+  float* part = partials + (size_t)blockIdx.x * PartialLayout<NL>::STRIDE;
+  for (int v = threadIdx.x; v < NQ * 64; v += blockDim.x) {
+    const float sum = (red[v] + red[NQ * 64 + v]) + (red[2 * NQ * 64 + v] + red[3 * NQ * 64 + v]);
+    const int q = v >> 6, ln = v & 63;
+    int dst;
+    if (q < DIN) dst = PartialLayout<NL>::W0 + ln * DIN + q;
+    else if (q == DIN) dst = PartialLayout<NL>::B0 + ln;
+    else if (q < DIN + 1 + NOUT) dst = PartialLayout<NL>::W1 + (q - DIN - 1) * HID + ln;
+    else dst = ln < NOUT ? PartialLayout<NL>::B1 + ln : -1;
+    if (dst >= 0) part[dst] = sum;
+  }
+}
+
+template <int NL>
+__global__ void reduce_partials_kernel(const float* __restrict__ partials, int nblocks,
+                                       float* __restrict__ g_w0, float* __restrict__ g_b0,
+                                       float* __restrict__ g_w1, float* __restrict__ g_b1) {
+  using P = PartialLayout<NL>;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= P::USED) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblocks; b += 4) {
+    s0 += partials[(size_t)b * P::STRIDE + i];
+    s1 += partials[(size_t)(b + 1) * P::STRIDE + i];
+    s2 += partials[(size_t)(b + 2) * P::STRIDE + i];
+    s3 += partials[(size_t)(b + 3) * P::STRIDE + i];
+  }
+  for (; b < nblocks; ++b) s0 += partials[(size_t)b * P::STRIDE + i];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (i < P::B0) g_w0[i] += s;
+  else if (i < P::W1) g_b0[i - P::B0] += s;
+  else if (i < P::B1) g_w1[i - P::W1] += s;
+  else g_b1[i - P::B1] += s;
 }
 
 int make_meta(const dsu_hashgrid_cfg* cfg, GridMeta* m) {
@@ -553,9 +681,7 @@ int make_meta(const dsu_hashgrid_cfg* cfg, GridMeta* m) {
 
 template <int NL>
 size_t bwd_lds_bytes() {
-  constexpr int DIN = 3 + 2 * NL;
-  constexpr int STAGE = 16 * 65 * 2 + 16 * (DIN + 1) + 16 * (NOUT + 1);
-  return (size_t)(MlpLds<NL>::TOTAL + 4 * STAGE) * sizeof(float);
+  return (size_t)BwdLds<NL>::TOTAL * sizeof(float);
 }
 
 }  // namespace
@@ -680,11 +806,24 @@ int dsu_sdf_fd_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu
   return DSU_OK;
 }
 
+constexpr int BWD_MAX_BLOCKS = 768;
+
+int64_t dsu_sdf_fd_bwd_workspace_bytes(const dsu_hashgrid_cfg* cfg, int64_t n) {
+  if (!cfg || n < 0) return DSU_EINVAL;
+  const int blocks = dsu_capped_blocks(n, 256, BWD_MAX_BLOCKS);
+  switch (cfg->n_levels) {
+    case 10: return (int64_t)blocks * PartialLayout<10>::STRIDE * sizeof(float);
+    case 12: return (int64_t)blocks * PartialLayout<12>::STRIDE * sizeof(float);
+    default: return DSU_EUNSUP;
+  }
+}
+
 int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
                    const float* pts, int64_t n, float radius, float eps,
                    uint32_t active_levels, const float* d_sdf, const float* d_grad,
                    const float* d_feature, const float* d_laplace, float* grad_table,
-                   float* g_w0, float* g_b0, float* g_w1, float* g_b1, void* stream) {
+                   float* g_w0, float* g_b0, float* g_w1, float* g_b1, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
   if (!cfg || !table_f16 || !mlp || (!pts && n) || n < 0) return DSU_EINVAL;
   if (!mlp->w0 || !mlp->b0 || !mlp->w1 || !mlp->b1) return DSU_EINVAL;
   if (!grad_table || !g_w0 || !g_b0 || !g_w1 || !g_b1) return DSU_EINVAL;
@@ -693,9 +832,12 @@ int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu
   int rc = make_meta(cfg, &m);
   if (rc) return rc;
   if (n == 0) return DSU_OK;
+  const int64_t need = dsu_sdf_fd_bwd_workspace_bytes(cfg, n);
+  if (need < 0) return (int)need;
+  if (!workspace || workspace_bytes < need) return DSU_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const float eps2 = (float)((double)eps * (double)eps);
-  const int blocks = dsu_capped_blocks(n, 256, 1024);
+  const int blocks = dsu_capped_blocks(n, 256, BWD_MAX_BLOCKS);
   DSU_DISPATCH_NL(cfg->n_levels, {
     const size_t shm = bwd_lds_bytes<NL>();
     if (shm > 64 * 1024) {
@@ -706,7 +848,9 @@ int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu
     }
     sdf_fd_bwd_kernel<NL><<<dim3(blocks), dim3(256), shm, s>>>(
         (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
-        d_grad, d_feature, d_laplace, grad_table, g_w0, g_b0, g_w1, g_b1);
+        d_grad, d_feature, d_laplace, grad_table, (float*)workspace);
+    reduce_partials_kernel<NL><<<dim3((PartialLayout<NL>::USED + 255) / 256), dim3(256), 0, s>>>(
+        (const float*)workspace, blocks, g_w0, g_b0, g_w1, g_b1);
   });
   DSU_CHECK_LAUNCH();
   return DSU_OK;

@@ -1,0 +1,266 @@
+"""Training / export loop of the NSR stage (recon.py + systems/neus_ortho.py).
+
+Mirrors OrthoNeuSSystem (2_charactor_reconstructor/instant_nsr/systems/neus_ortho.py:13-200)
+without PyTorch-Lightning: same per-step order — preprocess_data (random view / pixel ray
+batch), update_step (level schedule, eps, occupancy refresh), forward, the 7 loss terms,
+dynamic ray count, AdamW with the three parameter groups and the Constant->Exponential LR
+schedule of configs/neuralangelo-ortho-wmask.yaml:101-127.
+"""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .model import Cfg, NeuSModel
+
+DEFAULT_SYSTEM_CONFIG = Cfg({     # configs/neuralangelo-ortho-wmask.yaml:86-141
+    "loss": {"lambda_rgb_mse": 0.5, "lambda_rgb_l1": 0.0, "lambda_mask": 1.0,
+             "lambda_eikonal": 0.2, "lambda_normal": 1.0, "lambda_3d_normal_smooth": 1.0,
+             "lambda_sparsity": 0.5, "sparsity_scale": 100.0, "geo_aware": True,
+             "rgb_p_ratio": 0.8, "normal_p_ratio": 0.8, "mask_p_ratio": 0.9},
+    "optimizer": {"lr": 0.01, "betas": (0.9, 0.99), "eps": 1e-15,
+                  "params": {"geometry": 0.001, "texture": 0.01, "variance": 0.001}},
+    "constant_steps": 500, "max_steps": 3000,
+})
+
+VIEWS = ["front", "front_right", "right", "back", "left", "front_left"]
+_AZIMUTH = {"front": 0.0, "front_right": 45.0, "right": 90.0, "back": 180.0, "left": 270.0,
+            "front_left": 315.0}
+
+
+def ideal_w2c(view):
+    """Axis-aligned orthographic world->camera pose with the structure of
+    instant_nsr/datasets/fixed_poses/000_<view>_RT.txt (synthetic stand-in: exact cos/sin, no
+    f32 residue; diagonal views sit at distance 1.3*sqrt(2) as in those files)."""
+    a = math.radians(_AZIMUTH[view])
+    c, s = round(math.cos(a), 12), round(math.sin(a), 12)
+    dist = 1.3 * (math.sqrt(2.0) if view.startswith(("front_", "back_")) else 1.0)
+    return np.array([[c, s, 0.0, 0.0], [0.0, 0.0, 1.0, 0.0], [s, -c, 0.0, -dist]], np.float64)
+
+
+def rt_opengl2opencv(RT):                      # datasets/ortho.py:31-38
+    R_bcam2cv = np.asarray([[1, 0, 0], [0, -1, 0], [0, 0, -1]], np.float32)
+    return np.concatenate([R_bcam2cv @ RT[:3, :3], (R_bcam2cv @ RT[:3, 3])[:, None]], 1)
+
+
+def inv_rt(RT):                                # datasets/ortho.py:48-51
+    return np.linalg.inv(np.concatenate([RT, np.array([[0, 0, 0, 1]])], 0))[:3, :]
+
+
+def ortho_rays_hw(W, H):                       # models/ray_utils.py:20-33
+    i, j = np.meshgrid(np.arange(W, dtype=np.float32) + 0.5, np.arange(H, dtype=np.float32) + 0.5,
+                       indexing="xy")
+    i, j = torch.from_numpy(i), torch.from_numpy(j)
+    origins = torch.stack([(i / W - 0.5) * 2, (j / H - 0.5) * 2, torch.zeros_like(i)], -1)
+    directions = torch.stack([torch.zeros_like(i), torch.zeros_like(j), torch.ones_like(i)], -1)
+    return origins, directions
+
+
+def get_ortho_rays(origins, directions, c2w):  # models/ray_utils.py:36-58, (N,3) case
+    rays_d = torch.matmul(c2w[:, :3, :3], directions[:, :, None]).squeeze(-1)
+    rays_o = torch.matmul(c2w[:, :3, :3], origins[:, :, None]).squeeze(-1)
+    return c2w[:, :3, 3].expand(rays_d.shape) + rays_o, rays_d
+
+
+class OrthoData:
+    """The tensors OrthoDatasetBase.setup keeps resident on the GPU (datasets/ortho.py:99-151)."""
+
+    def __init__(self, images, masks, normals_world, c2w, device):
+        self.all_images = images.float().to(device)             # (V,H,W,3) in [0,1]
+        self.all_masks = masks.float().to(device)               # (V,H,W)
+        self.all_normals_world = normals_world.float().to(device)
+        self.all_c2w = c2w.float().to(device)                   # (V,3,4)
+        V, H, W = self.all_masks.shape
+        self.h, self.w = H, W
+        o, d = ortho_rays_hw(W, H)
+        self.origins = o[None].expand(V, -1, -1, -1).contiguous().to(device)
+        self.directions = d[None].expand(V, -1, -1, -1).contiguous().to(device)
+        self.view_weights = torch.ones(V, H, W, device=device)
+        self.has_mask = True
+        self.front_mask = None
+
+    @staticmethod
+    def synthetic_sphere(size=1024, radius=0.5, device="cuda", views=VIEWS):
+        """6 orthographic views of a sphere; analytic normals in the
+        front camera's frame, disc masks, smooth colour."""
+        H = W = size
+        o, _ = ortho_rays_hw(W, H)
+        x, y = o[..., 0], o[..., 1]
+        r2 = x * x + y * y
+        mask = r2 <= radius * radius
+        z = -torch.sqrt(torch.clamp(radius * radius - r2, min=0.0))   # towards the camera
+        n_cam = torch.stack([x, y, z], -1) / radius                    # OpenCV camera frame
+        n_cam = n_cam * mask[..., None]
+        front_c2w = inv_rt(rt_opengl2opencv(ideal_w2c("front")))
+        imgs, masks, normals, poses = [], [], [], []
+        for v in views:
+            c2w = inv_rt(rt_opengl2opencv(ideal_w2c(v)))
+            R = torch.from_numpy(c2w[:3, :3]).float()
+            n_world_true = n_cam @ R.T
+            # stored normals are expressed in the FRONT view's system (load_a_prediction,
+            # normal_system='front'): what mv diffusion predicts for this view, rotated by the
+            # front c2w -> equals the true world normal for a consistent prediction
+            normals.append(n_world_true)
+            col = 0.5 + 0.4 * torch.stack([n_world_true[..., 0], n_world_true[..., 1],
+                                           n_world_true[..., 2]], -1)
+            imgs.append(col * mask[..., None] + (~mask[..., None]) * 1.0)
+            masks.append(mask)
+            poses.append(torch.from_numpy(c2w).float())
+        del front_c2w
+        return OrthoData(torch.stack(imgs), torch.stack(masks), torch.stack(normals),
+                         torch.stack(poses), device)
+
+
+def binary_cross_entropy(inp, target):         # systems/criterions.py:4-13 (reduction='none')
+    return -(target * torch.log(inp) + (1 - target) * torch.log(1 - inp))
+
+
+def ranking_loss(error, penalize_ratio=0.7, extra_weights=None, type="mean"):
+    error, indices = torch.sort(error)         # systems/criterions.py:16-27
+    k = int(penalize_ratio * indices.shape[0])
+    s_error = torch.index_select(error, 0, index=indices[:k])
+    if extra_weights is not None:
+        s_error = s_error * torch.index_select(extra_weights, 0, index=indices[:k])
+    return torch.mean(s_error) if type == "mean" else torch.sum(s_error)
+
+
+class OrthoNeuSSystem:
+    def __init__(self, model_config=None, system_config=None, device="cuda", seed=123456):
+        torch.manual_seed(seed)
+        np.random.seed(seed)
+        self.device = torch.device(device)
+        self.model = NeuSModel(model_config).to(self.device)
+        self.config = Cfg(system_config) if system_config is not None else DEFAULT_SYSTEM_CONFIG
+        mc = self.model.config
+        self.train_num_samples = mc.train_num_rays * mc.num_samples_per_ray
+        self.train_num_rays = mc.train_num_rays
+        self.global_step = 0
+        oc = self.config.optimizer
+        groups = [{"params": list(getattr(self.model, n).parameters()), "name": n, "lr": lr}
+                  for n, lr in oc.params.items()]
+        self.optimizer = torch.optim.AdamW(groups, lr=oc.lr, betas=tuple(oc.betas), eps=oc.eps)
+        self._base_lrs = [g["lr"] for g in groups]
+        # ExponentialLR gamma = 0.1 ** (1 / (max_steps - constant_steps))  (recon.py:13)
+        self._gamma = 0.1 ** (1.0 / (self.config.max_steps - self.config.constant_steps))
+        self.dataset = None
+        self.last = {}
+
+    # ----------------------------------------------------------------- data
+    def preprocess_data(self, index=None, x=None, y=None):
+        ds, n = self.dataset, self.train_num_rays
+        dev = self.device
+        if index is None:
+            index = torch.randint(0, len(ds.all_masks), size=(n,), device=dev)
+            x = torch.randint(0, ds.w, size=(n,), device=dev)
+            y = torch.randint(0, ds.h, size=(n,), device=dev)
+        c2w = ds.all_c2w[index]
+        directions, origins = ds.directions[index, y, x], ds.origins[index, y, x]
+        rays_o, rays_d = get_ortho_rays(origins, directions, c2w)
+        rgb = ds.all_images[index, y, x].view(-1, ds.all_images.shape[-1])
+        normal = ds.all_normals_world[index, y, x].view(-1, 3)
+        mask = ds.all_masks[index, y, x].view(-1)
+        view_weights = ds.view_weights[index, y, x].view(-1)
+        cosines = F.cosine_similarity(rays_d, normal, dim=-1, eps=1e-6)
+        rays = torch.cat([rays_o, F.normalize(rays_d, p=2, dim=-1)], -1)
+        return {"rays": rays, "rgb": rgb, "normal": normal, "mask": mask, "cosines": cosines,
+                "view_weights": view_weights}
+
+    # ----------------------------------------------------------------- losses
+    def losses(self, out, batch):
+        L = self.config.loss
+        cosines = batch["cosines"].clone()
+        view_weights = batch["view_weights"]
+        cosines[cosines > -0.1] = 0
+        mask = (batch["mask"] > 0) & (cosines < -0.1)
+        terms = {}
+        err = F.mse_loss(out["comp_rgb"][mask], batch["rgb"][mask], reduction="none")
+        terms["rgb_mse"] = ranking_loss(err.sum(1), L.rgb_p_ratio, type="mean") * L.lambda_rgb_mse
+        if L.lambda_rgb_l1:
+            l1 = F.l1_loss(out["comp_rgb"][mask], batch["rgb"][mask], reduction="none")
+            terms["rgb_l1"] = ranking_loss(l1.sum(1), L.rgb_p_ratio) * L.lambda_rgb_l1
+        normal_errors = 1 - F.cosine_similarity(out["comp_normal"], batch["normal"], dim=1)
+        if L.geo_aware:
+            e = torch.exp(cosines.abs())
+            normal_errors = normal_errors * e / e.sum()
+            ln = ranking_loss(normal_errors[mask], L.normal_p_ratio, view_weights[mask], "sum")
+        else:
+            ln = ranking_loss(normal_errors[mask], L.normal_p_ratio, view_weights[mask], "mean")
+        terms["normal"] = ln * L.lambda_normal
+        terms["eikonal"] = ((torch.linalg.norm(out["sdf_grad_samples"], ord=2, dim=-1) - 1.0) ** 2
+                            ).mean() * L.lambda_eikonal
+        opacity = torch.clamp(out["opacity"].squeeze(-1), 1e-3, 1 - 1e-3)
+        lm = ranking_loss(binary_cross_entropy(opacity, batch["mask"].float()), L.mask_p_ratio,
+                          view_weights)
+        terms["mask"] = lm * (L.lambda_mask if self.dataset.has_mask else 0.0)
+        terms["sparsity"] = torch.exp(-L.sparsity_scale * out["random_sdf"].abs()).mean() \
+            * L.lambda_sparsity
+        if L.lambda_3d_normal_smooth > 0:
+            terms["normal_smooth"] = (out["random_sdf_grad"] - out["normal_perturb"]).abs().mean() \
+                * L.lambda_3d_normal_smooth
+        return terms
+
+    # ----------------------------------------------------------------- one optimisation step
+    def _set_lr(self):
+        s = self.global_step
+        f = 1.0 if s < self.config.constant_steps else self._gamma ** (s - self.config.constant_steps)
+        for g, base in zip(self.optimizer.param_groups, self._base_lrs):
+            g["lr"] = base * f
+
+    def training_step(self, inject=None):
+        """One step.  `inject` (tests) = dict(index,x,y,jitter,pts_random,perturb) replaces the
+        device RNG draws so that a step is reproducible against the oracle."""
+        self.model.train()
+        inject = inject or {}
+        batch = self.preprocess_data(inject.get("index"), inject.get("x"), inject.get("y"))
+        self.model.update_step(0, self.global_step)
+        out = self.model(batch["rays"], jitter=inject.get("jitter"),
+                         pts_random=inject.get("pts_random"), perturb=inject.get("perturb"))
+        n_samples = int(out["num_samples"].sum().item())        # neus_ortho.py:91 host sync
+        if self.model.config.dynamic_ray_sampling and n_samples > 0:
+            tr = int(self.train_num_rays * (self.train_num_samples / n_samples))
+            self.train_num_rays = min(int(self.train_num_rays * 0.9 + tr * 0.1),
+                                      self.model.config.max_train_num_rays)
+        terms = self.losses(out, batch)
+        loss = sum(terms.values())
+        self._set_lr()
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.optimizer.step()
+        self.global_step += 1
+        self.last = {"loss": loss.detach(), "n_samples": n_samples,
+                     "n_rays": batch["rays"].shape[0], **{k: v.detach() for k, v in terms.items()}}
+        return self.last
+
+    def fit(self, dataset, max_steps=None, log_every=0):
+        self.dataset = dataset
+        for _ in range(max_steps or self.config.max_steps):
+            r = self.training_step()
+            if log_every and self.global_step % log_every == 0:
+                print(f"[nsr] step {self.global_step} loss {float(r['loss']):.4f} "
+                      f"rays {r['n_rays']} samples {r['n_samples']}", flush=True)
+
+    # ----------------------------------------------------------------- export (SDF volumes)
+    @torch.no_grad()
+    def export_levels(self, resolution=None):
+        """model.export's device work (geometry.py:108-117): coarse 512^3 SDF over the whole
+        box, bounding box of the inside region padded by 10 %, fine 512^3 SDF in it.  Returns
+        (coarse, fine, vmin, vmax).  Marching cubes / mesh post-processing stay on the host
+        (not part of this path)."""
+        self.model.eval()
+        r = self.model.config.radius
+        coarse = self.model.isosurface_levels((-r, -r, -r), (r, r, r), resolution)
+        res = coarse.shape[0]
+        inside = coarse <= 0
+        if bool(inside.any()):
+            idx = torch.nonzero(inside)
+            lo = idx.min(0).values.float() / (res - 1) * 2 * r - r
+            hi = idx.max(0).values.float() / (res - 1) * 2 * r - r
+        else:
+            lo = torch.full((3,), -r, device=coarse.device)
+            hi = torch.full((3,), r, device=coarse.device)
+        vmin = (lo - (hi - lo) * 0.1).clamp(-r, r)
+        vmax = (hi + (hi - lo) * 0.1).clamp(-r, r)
+        fine = self.model.isosurface_levels(vmin.tolist(), vmax.tolist(), resolution)
+        return coarse, fine, vmin, vmax

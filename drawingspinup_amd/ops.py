@@ -116,10 +116,15 @@ def sdf_fd_bwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, d_sdf, d_gr
     g = [torch.zeros_like(t) for t in (w0, b0, w1, b1)]
     c, m = cfg.c(), _mlp_struct(*mlp)
     d = [None if t is None else _f32c(t) for t in (d_sdf, d_grad, d_feature, d_laplace)]
+    wbytes = lib().dsu_sdf_fd_bwd_workspace_bytes(C.byref(c), n)
+    if wbytes < 0:
+        check(int(wbytes), "dsu_sdf_fd_bwd_workspace_bytes")
+    ws = torch.empty(max(int(wbytes), 4) // 4, dtype=torch.float32, device=dev)
     check(lib().dsu_sdf_fd_bwd(C.byref(c), ptr(table_f16, torch.float16), C.byref(m), ptr(pts),
                                n, float(radius), float(eps), int(active_levels), ptr(d[0]),
                                ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(grad_table), ptr(g[0]),
-                               ptr(g[1]), ptr(g[2]), ptr(g[3]), stream()), "dsu_sdf_fd_bwd")
+                               ptr(g[1]), ptr(g[2]), ptr(g[3]), ptr(ws), int(wbytes), stream()),
+          "dsu_sdf_fd_bwd")
     return grad_table, g
 
 

@@ -107,12 +107,17 @@ int dsu_sdf_fd_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu
 /* Backward of dsu_sdf_fd_fwd w.r.t. table and MLP parameters.  Upstream gradients
  * (NULL = zero): d_sdf (n), d_grad (n,3), d_feature (n,13), d_laplace (n).
  * Accumulates into grad_table (entries,2) f32 and g_w0 (64,23), g_b0 (64), g_w1 (13,64),
- * g_b1 (13) f32 — caller zeroes them. */
+ * g_b1 (13) f32 — caller zeroes them.  `workspace` is caller-owned device scratch of at
+ * least dsu_sdf_fd_bwd_workspace_bytes(cfg, n) bytes (contents undefined on return). */
 int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
                    const float* pts, int64_t n, float radius, float eps,
                    uint32_t active_levels, const float* d_sdf, const float* d_grad,
                    const float* d_feature, const float* d_laplace, float* grad_table,
-                   float* g_w0, float* g_b0, float* g_w1, float* g_b1, void* stream);
+                   float* g_w0, float* g_b0, float* g_w1, float* g_b1, void* workspace,
+                   int64_t workspace_bytes, void* stream);
+/* Bytes of device scratch dsu_sdf_fd_bwd needs for n points (per-workgroup partial MLP
+ * gradients, summed by a second kernel: deterministic, no same-address atomics).  <0 = error. */
+int64_t dsu_sdf_fd_bwd_workspace_bytes(const dsu_hashgrid_cfg* cfg, int64_t n);
 
 /* ------------------------------------------------------------------------------------
  * nerfacc 0.3.3 replacements (call sites instant_nsr/models/neus.py:53-57,84,119-129,
