@@ -7,13 +7,24 @@
 // the stepping rule below restates its published ray_marching kernel
 // (nerfacc/cuda/csrc/ray_marching.cu @ v0.3.3) and is mirrored by oracle/nerfacc_ref.py.
 #include "common.h"
+#include <math.h>
 
 namespace {
 
 struct Aabb {
   float mn[3];
   float mx[3];
+  float inv_ext[3];  // 1/(mx-mn), only used when pow2 != 0
+  int pow2;          // every extent and the grid resolution are powers of two: x/ext == x*(1/ext)
+                     // bit for bit, so the serial marching chain can avoid IEEE divisions
 };
+
+__device__ __forceinline__ float div_ext(float x, const Aabb& a, int d) {
+  return a.pow2 ? x * a.inv_ext[d] : x / (a.mx[d] - a.mn[d]);
+}
+__device__ __forceinline__ float div_res(float x, const Aabb& a, int res, float inv_res) {
+  return a.pow2 ? x * inv_res : x / (float)res;
+}
 
 __device__ __forceinline__ float signf1(float x) { return copysignf(1.0f, x); }
 
@@ -25,7 +36,7 @@ __device__ __forceinline__ bool occupied_at(const float p[3], const Aabb& a,
   int ix[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    float u = (p[d] - a.mn[d]) / (a.mx[d] - a.mn[d]);
+    float u = div_ext(p[d] - a.mn[d], a, d);
     int i = (int)(u * (float)res);
     ix[d] = min(max(i, 0), res - 1);
   }
@@ -36,11 +47,12 @@ __device__ __forceinline__ float dist_to_next_voxel(const float p[3], const floa
                                                     const float inv_dir[3], const Aabb& a,
                                                     int res) {
   float t = INFINITY;
+  const float inv_res = 1.0f / (float)res;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    float g = ((p[d] - a.mn[d]) / (a.mx[d] - a.mn[d])) * (float)res;
-    float td = ((floorf(g + 0.5f + 0.5f * signf1(dir[d])) - g) * inv_dir[d]) / (float)res *
-               (a.mx[d] - a.mn[d]);
+    float g = div_ext(p[d] - a.mn[d], a, d) * (float)res;
+    float td = div_res((floorf(g + 0.5f + 0.5f * signf1(dir[d])) - g) * inv_dir[d], a, res,
+                       inv_res) * (a.mx[d] - a.mn[d]);
     t = fminf(t, td);
   }
   return fmaxf(t, 0.0f);
@@ -196,11 +208,20 @@ __global__ void occ_bin_kernel(const float* __restrict__ occs, int64_t n, float 
     bin[i] = occs[i] > thre ? 1 : 0;
 }
 
-Aabb make_aabb(const float* a6) {
+bool is_pow2f(float x) {
+  int e;
+  return x > 0.0f && frexpf(x, &e) == 0.5f;
+}
+
+Aabb make_aabb(const float* a6, int res = 1) {
   Aabb a;
+  a.pow2 = (res > 0 && (res & (res - 1)) == 0) ? 1 : 0;
   for (int d = 0; d < 3; ++d) {
     a.mn[d] = a6[d];
     a.mx[d] = a6[3 + d];
+    const float ext = a.mx[d] - a.mn[d];
+    a.inv_ext[d] = 1.0f / ext;
+    if (!is_pow2f(ext)) a.pow2 = 0;
   }
   return a;
 }
@@ -228,7 +249,7 @@ int dsu_ray_march_count(const float* rays_o, const float* rays_d, const float* t
   if (n_rays && (!rays_o || !rays_d || !t_min || !t_max || !num_steps)) return DSU_EINVAL;
   if (n_rays == 0) return DSU_OK;
   ray_march_kernel<false><<<dsu_blocks_for(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
-      rays_o, rays_d, t_min, t_max, n_rays, make_aabb(aabb6), occ_binary, res, step, nullptr,
+      rays_o, rays_d, t_min, t_max, n_rays, make_aabb(aabb6, occ_binary ? res : 1), occ_binary, res, step, nullptr,
       num_steps, nullptr, nullptr, nullptr);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
@@ -243,7 +264,7 @@ int dsu_ray_march_fill(const float* rays_o, const float* rays_d, const float* t_
   if (n_rays && (!rays_o || !rays_d || !t_min || !t_max || !offsets)) return DSU_EINVAL;
   if (n_rays == 0) return DSU_OK;
   ray_march_kernel<true><<<dsu_blocks_for(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
-      rays_o, rays_d, t_min, t_max, n_rays, make_aabb(aabb6), occ_binary, res, step, offsets,
+      rays_o, rays_d, t_min, t_max, n_rays, make_aabb(aabb6, occ_binary ? res : 1), occ_binary, res, step, offsets,
       nullptr, ray_indices, t_starts, t_ends);
   DSU_CHECK_LAUNCH();
   return DSU_OK;

@@ -358,8 +358,26 @@ class NeuSModel(nn.Module):
         midpoints = (t_starts + t_ends) / 2.0
         positions = t_origins + t_dirs * midpoints
         dists = t_ends - t_starts
-        sdf, sdf_grad, feature, sdf_laplace = self.geometry(positions, with_grad=True,
-                                                            with_feature=True, with_laplace=True)
+        n_s = positions.shape[0]
+        if self.training:
+            # the reference evaluates geometry three times per step (samples, 2048 random
+            # points, their perturbed copies: neus.py:139,155-162); same arithmetic, ONE
+            # fused launch forward and one backward for all of them
+            if pts_random is None:
+                pts_random = torch.rand([1024 * 2, 3], device=positions.device) * 2 - 1
+            if perturb is None:
+                perturb = torch.randn_like(pts_random)
+            n_r = pts_random.shape[0]
+            allp = torch.cat([positions, pts_random, pts_random + perturb * 1e-2], 0)
+            a_sdf, a_grad, a_feat, a_lap = self.geometry(allp, with_grad=True, with_feature=True,
+                                                         with_laplace=True)
+            sdf, sdf_grad, feature, sdf_laplace = a_sdf[:n_s], a_grad[:n_s], a_feat[:n_s], a_lap[:n_s]
+            random_sdf, random_sdf_grad = a_sdf[n_s:n_s + n_r], a_grad[n_s:n_s + n_r]
+            normal_perturb = a_grad[n_s + n_r:]
+        else:
+            sdf, sdf_grad, feature, sdf_laplace = self.geometry(positions, with_grad=True,
+                                                                with_feature=True,
+                                                                with_laplace=True)
         normal = F.normalize(sdf_grad, p=2, dim=-1)
         alpha = self.get_alpha(sdf, normal, t_dirs, dists)[..., None]
         rgb = self.texture(feature, t_dirs, normal)
@@ -374,14 +392,6 @@ class NeuSModel(nn.Module):
                "num_samples": torch.as_tensor([len(t_starts)], dtype=torch.int32,
                                               device=rays.device)}
         if self.training:
-            if pts_random is None:
-                pts_random = torch.rand([1024 * 2, 3], device=sdf.device) * 2 - 1
-            if perturb is None:
-                perturb = torch.randn_like(pts_random)
-            random_sdf, random_sdf_grad, _ = self.geometry(pts_random, with_grad=True,
-                                                           with_feature=False, with_laplace=True)
-            _, normal_perturb, _ = self.geometry(pts_random + perturb * 1e-2, with_grad=True,
-                                                 with_feature=False, with_laplace=True)
             out.update({"sdf_samples": sdf, "sdf_grad_samples": sdf_grad,
                         "random_sdf": random_sdf, "random_sdf_grad": random_sdf_grad,
                         "normal_perturb": normal_perturb, "weights": weights.view(-1),
