@@ -54,10 +54,10 @@ _PROTOS = {
     "dsu_occgrid_ema": [P, P, P, c_i64, c_f32, P],
     "dsu_occgrid_binarize": [P, c_i64, c_f32, P, P],
     "dsu_ric_offsets": [c_i32, c_i32, P, P],
-    "dsu_deform_conv3x3_fwd": [P, P, c_i64, P, c_i32, c_i32, c_i32, c_i32, c_i32, P, P, c_i32,
-                               P, P, P],
-    "dsu_conv2d_fwd": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, P, P,
-                       c_i32, P, P, P],
+    "dsu_deform_conv3x3_fwd": [P, P, c_i64, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, P, P,
+                               c_i32, P, P, P],
+    "dsu_conv2d_fwd": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                       P, P, c_i32, P, P, P],
 }
 
 _lib = None

@@ -33,6 +33,7 @@ struct ConvArgs {
   float* out;
   int B, C, H, W, O, OH, OW, pad;
   int act;
+  int in_relu;   // apply ReLU to the input values as they are read (resnet pre-activation)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -70,9 +71,14 @@ __device__ __forceinline__ Tap make_tap(float h, float w, int H, int W) {
   return t;
 }
 
-__device__ __forceinline__ float sample_tap(const float* __restrict__ plane, const Tap& t) {
-  const float v00 = plane[t.r0 + t.c0], v01 = plane[t.r0 + t.c1];
-  const float v10 = plane[t.r1 + t.c0], v11 = plane[t.r1 + t.c1];
+__device__ __forceinline__ float sample_tap(const float* __restrict__ plane, const Tap& t,
+                                            bool in_relu) {
+  float v00 = plane[t.r0 + t.c0], v01 = plane[t.r0 + t.c1];
+  float v10 = plane[t.r1 + t.c0], v11 = plane[t.r1 + t.c1];
+  if (in_relu) {
+    v00 = fmaxf(v00, 0.0f); v01 = fmaxf(v01, 0.0f);
+    v10 = fmaxf(v10, 0.0f); v11 = fmaxf(v11, 0.0f);
+  }
   return t.w00 * v00 + t.w01 * v01 + t.w10 * v10 + t.w11 * v11;
 }
 
@@ -137,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         const float* pl = in_b + (size_t)(cv ? c : 0) * plane;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          float v = sample_tap(pl, taps[t]);
+          float v = sample_tap(pl, taps[t], a.in_relu != 0);
           sB[buf][(sg * CH + cc) * 9 + t][sp] = cv ? v : 0.0f;
         }
       }
@@ -151,6 +157,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
           const int iy = oy * STRIDE - a.pad + t / KS, ix = ox * STRIDE - a.pad + t % KS;
           if (spv && c < a.C && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
             v = in_b[(size_t)c * plane + (size_t)iy * a.W + ix];
+          if (a.in_relu) v = fmaxf(v, 0.0f);
         }
         sB[buf][e][sp] = v;
       }
@@ -272,8 +279,9 @@ int dsu_ric_offsets(int32_t H, int32_t W, float* offsets, void* stream) {
 
 int dsu_deform_conv3x3_fwd(const float* input, const float* offset, int64_t offset_batch_stride,
                            const float* weight, int32_t B, int32_t C, int32_t H, int32_t W,
-                           int32_t O, const float* ep_scale, const float* ep_shift, int32_t act,
-                           const float* residual, float* out, void* stream) {
+                           int32_t O, int32_t in_relu, const float* ep_scale,
+                           const float* ep_shift, int32_t act, const float* residual, float* out,
+                           void* stream) {
   if (!input || !offset || !weight || !out) return DSU_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || O <= 0 || act < 0 || act > 3) return DSU_EINVAL;
   if ((ep_scale == nullptr) != (ep_shift == nullptr)) return DSU_EINVAL;
@@ -281,14 +289,14 @@ int dsu_deform_conv3x3_fwd(const float* input, const float* offset, int64_t offs
   a.in = input; a.w = weight; a.bias = nullptr; a.offset = offset;
   a.offset_bstride = offset_batch_stride;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.residual = residual; a.out = out;
-  a.B = B; a.C = C; a.H = H; a.W = W; a.O = O; a.OH = H; a.OW = W; a.pad = 1; a.act = act;
+  a.B = B; a.C = C; a.H = H; a.W = W; a.O = O; a.OH = H; a.OW = W; a.pad = 1; a.act = act; a.in_relu = in_relu;
   return launch_conv<1, 3, 1, 4>(a, (hipStream_t)stream);
 }
 
 int dsu_conv2d_fwd(const float* input, const float* weight, const float* bias, int32_t B,
                    int32_t C, int32_t H, int32_t W, int32_t O, int32_t k, int32_t stride,
-                   int32_t pad, const float* ep_scale, const float* ep_shift, int32_t act,
-                   const float* residual, float* out, void* stream) {
+                   int32_t pad, int32_t in_relu, const float* ep_scale, const float* ep_shift,
+                   int32_t act, const float* residual, float* out, void* stream) {
   if (!input || !weight || !out) return DSU_EINVAL;
   if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || O <= 0 || act < 0 || act > 3 || pad < 0)
     return DSU_EINVAL;
@@ -296,7 +304,7 @@ int dsu_conv2d_fwd(const float* input, const float* weight, const float* bias, i
   ConvArgs a{};
   a.in = input; a.w = weight; a.bias = bias; a.offset = nullptr; a.offset_bstride = 0;
   a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.residual = residual; a.out = out;
-  a.B = B; a.C = C; a.H = H; a.W = W; a.O = O; a.pad = pad; a.act = act;
+  a.B = B; a.C = C; a.H = H; a.W = W; a.O = O; a.pad = pad; a.act = act; a.in_relu = in_relu;
   a.OH = (H + 2 * pad - k) / stride + 1;
   a.OW = (W + 2 * pad - k) / stride + 1;
   if (a.OH <= 0 || a.OW <= 0) return DSU_EINVAL;

@@ -219,7 +219,8 @@ def ric_offsets(H, W, device):
     return out
 
 
-def deform_conv3x3(x, offset, weight, ep_scale=None, ep_shift=None, act=None, residual=None):
+def deform_conv3x3(x, offset, weight, ep_scale=None, ep_shift=None, act=None, residual=None,
+                   in_relu=False):
     """offset: (18,H,W) shared by the batch, or (B,18,H,W)."""
     x, weight, offset = _f32c(x), _f32c(weight), _f32c(offset)
     B, Cin, H, W = x.shape
@@ -228,14 +229,14 @@ def deform_conv3x3(x, offset, weight, ep_scale=None, ep_shift=None, act=None, re
     bstride = 0 if offset.dim() == 3 or offset.shape[0] == 1 else 18 * H * W
     out = torch.empty((B, O, H, W), dtype=torch.float32, device=x.device)
     check(lib().dsu_deform_conv3x3_fwd(ptr(x), ptr(offset), bstride, ptr(weight), B, Cin, H, W, O,
-                                       ptr(ep_scale), ptr(ep_shift), ACT[act],
+                                       int(in_relu), ptr(ep_scale), ptr(ep_shift), ACT[act],
                                        ptr(residual), ptr(out), stream()),
           "dsu_deform_conv3x3_fwd")
     return out
 
 
 def conv2d(x, weight, bias=None, stride=1, padding=0, ep_scale=None, ep_shift=None, act=None,
-           residual=None):
+           residual=None, in_relu=False):
     x, weight = _f32c(x), _f32c(weight)
     B, Cin, H, W = x.shape
     O, Cw, k, k2 = weight.shape
@@ -244,6 +245,7 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, ep_scale=None, ep_shift=No
     OW = (W + 2 * padding - k) // stride + 1
     out = torch.empty((B, O, OH, OW), dtype=torch.float32, device=x.device)
     check(lib().dsu_conv2d_fwd(ptr(x), ptr(weight), ptr(bias), B, Cin, H, W, O, k, stride,
-                               padding, ptr(ep_scale), ptr(ep_shift), ACT[act], ptr(residual),
+                               padding, int(in_relu), ptr(ep_scale), ptr(ep_shift), ACT[act],
+                               ptr(residual),
                                ptr(out), stream()), "dsu_conv2d_fwd")
     return out

@@ -178,18 +178,21 @@ int dsu_ric_offsets(int32_t H, int32_t W, float* offsets, void* stream);
  * input (B,C,H,W) f32; offset (18,H,W) f32 shared over the batch (offset_batch_stride=0)
  * or per image; weight (O,C,3,3); out (B,O,H,W).
  * Optional fused epilogue (scale/shift per output channel = folded eval BatchNorm, then
- * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 tanh), optional residual added last. */
+ * act: 0 none, 1 ReLU, 2 LeakyReLU(0.2), 3 tanh), optional residual added last.
+ * in_relu != 0 applies ReLU to the input as it is read (the resnet blocks' leading
+ * nonlinearity_0, models.py:321) without a separate pass. */
 int dsu_deform_conv3x3_fwd(const float* input, const float* offset, int64_t offset_batch_stride,
                            const float* weight, int32_t B, int32_t C, int32_t H, int32_t W,
-                           int32_t O, const float* ep_scale, const float* ep_shift, int32_t act,
-                           const float* residual, float* out, void* stream);
+                           int32_t O, int32_t in_relu, const float* ep_scale,
+                           const float* ep_shift, int32_t act, const float* residual, float* out,
+                           void* stream);
 
 /* nn.Conv2d forward, NCHW f32, square kernel k in {1,3,7}, stride in {1,2}, zero padding,
  * same fused epilogue (GeneratorJ, models.py:41-129).  bias may be NULL. */
 int dsu_conv2d_fwd(const float* input, const float* weight, const float* bias, int32_t B,
                    int32_t C, int32_t H, int32_t W, int32_t O, int32_t k, int32_t stride,
-                   int32_t pad, const float* ep_scale, const float* ep_shift, int32_t act,
-                   const float* residual, float* out, void* stream);
+                   int32_t pad, int32_t in_relu, const float* ep_scale, const float* ep_shift,
+                   int32_t act, const float* residual, float* out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -87,3 +87,49 @@ def test_conv2d_vs_oracle(dev, k, s, p, C, O, H, W, bias, act):
     got = ops.conv2d(x.to(dev), w.to(dev), None if b is None else b.to(dev), s, p, scale.to(dev),
                      shift.to(dev), act).cpu().double()
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+
+
+# ------------------------------------------------------------------ whole generators vs golden
+import os  # noqa: E402
+
+from drawingspinup_amd.style import generators as G  # noqa: E402
+
+GOLD = np.load(os.path.join(os.path.dirname(__file__), "golden", "style_reference.npz"))
+ARGS = dict(use_bias=False, tanh=True, append_smoothers=True, resnet_blocks=2,
+            filters=[8, 16, 24, 24, 24, 16], input_channels=6)
+
+
+def _to_image_space(x):     # training/custom_transforms.py:8-9
+    return ((np.clip(x, -1, 1) + 1) / 2 * 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("name", ["GeneratorJ", "GeneratorJ_RIC"])
+def test_generator_matches_reference_fixture(dev, name):
+    net = G.build_model(name, ARGS)
+    sd = {k.split(".sd.")[1]: torch.from_numpy(GOLD[k]) for k in GOLD.files
+          if k.startswith(name + ".sd.")}
+    net.load_state_dict(sd)
+    net = net.to(dev).eval()
+    x = torch.from_numpy(GOLD[name + ".x"]).to(dev)
+    with torch.no_grad():
+        y = net(x).cpu().numpy()
+    ref = GOLD[name + ".y"]
+    np.testing.assert_allclose(y, ref, rtol=0, atol=2e-4)       # f32 end to end
+    q, qr = _to_image_space(y).astype(int), _to_image_space(ref).astype(int)
+    assert (np.abs(q - qr) <= 1).mean() >= 0.999               # stylised RGB: <= 1/255
+
+
+@pytest.mark.parametrize("name", ["GeneratorJ", "GeneratorJ_RIC"])
+def test_generator_full_size_runs(dev, name):
+    """Shipped config (configs/config_stage{1,2}.yaml) at 512x512: finite, in [-1,1], and
+    deterministic across two runs (size-independent properties at BASELINE size)."""
+    torch.manual_seed(0)
+    net = G.build_model(name, dict(use_bias=False, tanh=True, append_smoothers=True,
+                                   resnet_blocks=7, filters=[32, 64, 128, 128, 128, 64],
+                                   input_channels=6)).to(dev).eval()
+    x = torch.rand(1, 6, 512, 512, device=dev) * 2 - 1
+    with torch.no_grad():
+        y1 = net(x)
+        y2 = net(x)
+    assert y1.shape == (1, 3, 512, 512) and torch.isfinite(y1).all()
+    assert float(y1.abs().max()) <= 1.0 and torch.equal(y1, y2)
