@@ -56,6 +56,9 @@ _PROTOS = {
     "dsu_ric_offsets": [c_i32, c_i32, P, P],
     "dsu_deform_conv3x3_fwd": [P, P, c_i64, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, P, P,
                                c_i32, P, P, P],
+    "dsu_mv_attention_fwd": [P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                             C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64),
+                             C.POINTER(c_i64), c_f32, P],
     "dsu_conv2d_fwd": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                        P, P, c_i32, P, P, P],
 }

@@ -249,3 +249,29 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, ep_scale=None, ep_shift=No
                                ptr(residual),
                                ptr(out), stream()), "dsu_conv2d_fwd")
     return out
+
+
+# ------------------------------------------------------------------ multi-view attention
+def _i64x3(a, b, c):
+    return (C.c_int64 * 3)(int(a), int(b), int(c))
+
+
+def mv_attention(q, k, vt, seg_batch, heads, seg_len, scale=None):
+    """q (Bq,Nq,H*d) f16; k (Bk,Nk,H*d) f16; vt (Bk,H*d,Nk) f16 (V transposed);
+    seg_batch (Bq,S) int32: batch index of each seg_len-token K/V segment of query batch b.
+    Returns (Bq,Nq,H*d) f16."""
+    Bq, Nq, Cq = q.shape
+    d = Cq // heads
+    S = seg_batch.shape[1]
+    assert q.dtype == torch.float16 and k.dtype == torch.float16 and vt.dtype == torch.float16
+    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    out = torch.empty((Bq, Nq, Cq), dtype=torch.float16, device=q.device)
+    if scale is None:
+        scale = d ** -0.5
+    check(lib().dsu_mv_attention_fwd(
+        C.c_void_p(q.data_ptr()), C.c_void_p(k.data_ptr()), C.c_void_p(vt.data_ptr()), ptr(out),
+        ptr(seg_batch, torch.int32), Bq, heads, Nq, d, S, int(seg_len),
+        _i64x3(q.stride(0), q.stride(1), d), _i64x3(k.stride(0), k.stride(1), d),
+        _i64x3(vt.stride(0), d * vt.stride(1), vt.stride(1)),
+        _i64x3(out.stride(0), out.stride(1), d), float(scale), stream()), "dsu_mv_attention_fwd")
+    return out

@@ -194,6 +194,26 @@ int dsu_conv2d_fwd(const float* input, const float* weight, const float* bias, i
                    int32_t pad, int32_t in_relu, const float* ep_scale, const float* ep_shift,
                    int32_t act, const float* residual, float* out, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Multi-view diffusion UNet (2_charactor_reconstructor/mvdiffusion/models).
+ * ---------------------------------------------------------------------------------- */
+
+/* xformers.ops.memory_efficient_attention(q, k, v, attn_bias=None) as called by
+ * XFormersMVAttnProcessor (transformer_mv2d.py:802) and XFormersJointAttnProcessor (:890),
+ * WITHOUT materialising the repeated / concatenated K,V (transformer_mv2d.py:785-786,
+ * 878-883): the key/value sequence of query batch b is the concatenation of S segments of
+ * seg_len tokens; segment s of query batch b lives at batch index seg_batch[b*S + s] of K/Vt.
+ *   q, out : f16, element strides q_strides/o_strides = {batch, token, head}, d contiguous
+ *   k      : f16, strides {batch, token, head}, d contiguous
+ *   vt     : f16 V TRANSPOSED per head, strides {batch, head, d}, token contiguous
+ *   d in {40, 64, 80, 160}; scale = softmax scale (1/sqrt(d) for xformers' default).
+ * f32 accumulation, f16 output. */
+int dsu_mv_attention_fwd(const void* q, const void* k, const void* vt, void* out,
+                         const int32_t* seg_batch, int32_t Bq, int32_t H, int32_t Nq, int32_t d,
+                         int32_t S, int32_t seg_len, const int64_t* q_strides,
+                         const int64_t* k_strides, const int64_t* vt_strides,
+                         const int64_t* o_strides, float scale, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
