@@ -59,6 +59,11 @@ _PROTOS = {
     "dsu_mv_attention_fwd": [P, P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                              C.POINTER(c_i64), C.POINTER(c_i64), C.POINTER(c_i64),
                              C.POINTER(c_i64), c_f32, P],
+    "dsu_conv2d_nhwc_f16_fwd": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                c_i32, P, P, P, P],
+    "dsu_groupnorm_nhwc_f16": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, P, P, P],
+    "dsu_layernorm_f16": [P, P, P, c_i64, c_i32, c_f32, P, P],
+    "dsu_geglu_f16": [P, c_i64, c_i32, P, P],
     "dsu_conv2d_fwd": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                        P, P, c_i32, P, P, P],
 }

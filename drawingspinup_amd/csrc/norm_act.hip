@@ -1,0 +1,221 @@
+// GroupNorm(+SiLU) on NHWC f16, LayerNorm, GEGLU for the diffusion UNet (K4 of SURVEY.md
+// §2.3: the GroupNorm/SiLU/LayerNorm/GEGLU kernels the reference runs through diffusers'
+// ResnetBlock2D (norm1/norm2 + nonlinearity), TransformerMV2DModel.norm
+// (mvdiffusion/models/transformer_mv2d.py:304), BasicMVTransformerBlock.norm1/2/3/norm_joint_mid
+// (:532-625) and FeedForward(GEGLU) (:483)).  All HBM-bound: every kernel reads its input once
+// with 16-byte accesses and keeps statistics in f32.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 f16;
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+// ---- GroupNorm statistics: per (image, channel) partial sums over a slab of pixels, folded
+// to per-(image, group) sum / sum-of-squares with one atomic pair per workgroup and group.
+// grid = (pixel slabs, B); block = 256 threads; thread t owns 8-channel group (t % C8) of
+// pixels t / C8, t / C8 + 256 / C8 ...   (C8 = C/8 <= 256)
+__global__ __launch_bounds__(256) void gn_stats_kernel(const f16* __restrict__ x, int HW, int C,
+                                                       int G, int pix_per_block,
+                                                       float* __restrict__ stats /*(B,G,2)*/) {
+  extern __shared__ float sh[];   // [2][C]
+  const int n = blockIdx.y;
+  const int C8 = C >> 3;
+  const int nsplit = (C8 + 255) / 256;               // channel range split when C/8 > 256
+  const int lanes_per_pix = C8 / nsplit;             // host guarantees divisibility
+  const int pix_par = 256 / lanes_per_pix;           // pixels processed concurrently
+  const int pl = threadIdx.x / lanes_per_pix;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) sh[i] = 0.0f;
+  __syncthreads();
+  const int p0 = blockIdx.x * pix_per_block;
+  const int p1 = min(p0 + pix_per_block, HW);
+  for (int sp = 0; sp < nsplit; ++sp) {
+    const int cg = sp * lanes_per_pix + threadIdx.x % lanes_per_pix;
+    float s[8], q[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = q[e] = 0.0f;
+    if (pl < pix_par) {
+      for (int p = p0 + pl; p < p1; p += pix_par) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(x + ((size_t)n * HW + p) * C + cg * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float f = (float)v[e];
+          s[e] += f;
+          q[e] += f * f;
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        atomicAdd(&sh[cg * 8 + e], s[e]);
+        atomicAdd(&sh[C + cg * 8 + e], q[e]);
+      }
+    }
+  }
+  __syncthreads();
+  const int cpg = C / G;
+  for (int g = threadIdx.x; g < G; g += 256) {
+    float ss = 0.0f, qq = 0.0f;
+    for (int c = 0; c < cpg; ++c) {
+      ss += sh[g * cpg + c];
+      qq += sh[C + g * cpg + c];
+    }
+    unsafeAtomicAdd(&stats[((size_t)n * G + g) * 2], ss);
+    unsafeAtomicAdd(&stats[((size_t)n * G + g) * 2 + 1], qq);
+  }
+}
+
+__device__ __forceinline__ float silu(float v) { return v / (1.0f + __expf(-v)); }
+
+__global__ __launch_bounds__(256) void gn_apply_kernel(const f16* __restrict__ x,
+                                                       const float* __restrict__ stats,
+                                                       const f16* __restrict__ gamma,
+                                                       const f16* __restrict__ beta, int HW,
+                                                       int C, int G, float eps, int do_silu,
+                                                       int64_t total8, f16* __restrict__ out) {
+  const int cpg = C / G;
+  const float inv_cnt = 1.0f / ((float)HW * (float)cpg);
+  const int C8 = C >> 3;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total8;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int c0 = (int)(i % C8) * 8;
+    const int n = (int)(i / ((int64_t)C8 * HW));
+    const f16x8 v = *reinterpret_cast<const f16x8*>(x + i * 8);
+    const f16x8 gm = *reinterpret_cast<const f16x8*>(gamma + c0);
+    const f16x8 bt = *reinterpret_cast<const f16x8*>(beta + c0);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int g = (c0 + e) / cpg;
+      const float mean = stats[((size_t)n * G + g) * 2] * inv_cnt;
+      const float var = fmaxf(stats[((size_t)n * G + g) * 2 + 1] * inv_cnt - mean * mean, 0.0f);
+      float y = ((float)v[e] - mean) * rsqrtf(var + eps) * (float)gm[e] + (float)bt[e];
+      if (do_silu) y = silu(y);
+      o[e] = (f16)y;
+    }
+    *reinterpret_cast<f16x8*>(out + i * 8) = o;
+  }
+}
+
+// ---- LayerNorm over the last dimension: one wave per row, C % 8 == 0, C <= 64*8*4
+__global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x,
+                                                        const f16* __restrict__ gamma,
+                                                        const f16* __restrict__ beta,
+                                                        int64_t rows, int C, float eps,
+                                                        f16* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const int C8 = C >> 3;
+  f16x8 v[4];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int g = lane + 64 * i;
+    if (g < C8) {
+      v[i] = *reinterpret_cast<const f16x8*>(x + row * C + g * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += (float)v[i][e];
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  const float mean = s / (float)C;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int g = lane + 64 * i;
+    if (g < C8) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float d = (float)v[i][e] - mean;
+        q += d * d;
+      }
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+  const float rstd = rsqrtf(q / (float)C + eps);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int g = lane + 64 * i;
+    if (g < C8) {
+      const f16x8 gm = *reinterpret_cast<const f16x8*>(gamma + g * 8);
+      const f16x8 bt = *reinterpret_cast<const f16x8*>(beta + g * 8);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        o[e] = (f16)(((float)v[i][e] - mean) * rstd * (float)gm[e] + (float)bt[e]);
+      *reinterpret_cast<f16x8*>(out + row * C + g * 8) = o;
+    }
+  }
+}
+
+// ---- GEGLU: out[r][j] = h[r][j] * gelu(h[r][D + j])   (diffusers GEGLU: exact erf GELU)
+__global__ __launch_bounds__(256) void geglu_kernel(const f16* __restrict__ h, int64_t rows,
+                                                    int D, f16* __restrict__ out) {
+  const int D8 = D >> 3;
+  const int64_t total = rows * D8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / D8;
+    const int j = (int)(i % D8) * 8;
+    const f16x8 a = *reinterpret_cast<const f16x8*>(h + r * 2 * D + j);
+    const f16x8 g = *reinterpret_cast<const f16x8*>(h + r * 2 * D + D + j);
+    f16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gv = (float)g[e];
+      const float gelu = 0.5f * gv * (1.0f + erff(gv * 0.70710678118654752f));
+      o[e] = (f16)((float)a[e] * gelu);
+    }
+    *reinterpret_cast<f16x8*>(out + r * D + j) = o;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsu_groupnorm_nhwc_f16(const void* x, const void* gamma, const void* beta, int32_t B,
+                           int32_t HW, int32_t C, int32_t G, float eps, int32_t silu,
+                           float* stats_ws, void* out, void* stream) {
+  if (!x || !gamma || !beta || !stats_ws || !out) return DSU_EINVAL;
+  if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G != 0) return DSU_EINVAL;
+  if (C % 8 != 0 || C / 8 > 1024 || (C / 8) % ((C / 8 + 255) / 256) != 0) return DSU_EUNSUP;
+  hipStream_t s = (hipStream_t)stream;
+  if (hipMemsetAsync(stats_ws, 0, (size_t)B * G * 2 * sizeof(float), s) != hipSuccess)
+    return DSU_ELAUNCH;
+  const int pix_per_block = 64;
+  dim3 grid((HW + pix_per_block - 1) / pix_per_block, B);
+  gn_stats_kernel<<<grid, 256, 2 * C * sizeof(float), s>>>((const f16*)x, HW, C, G,
+                                                           pix_per_block, stats_ws);
+  const int64_t total8 = (int64_t)B * HW * (C / 8);
+  gn_apply_kernel<<<dsu_capped_blocks(total8, 256, 4096), 256, 0, s>>>(
+      (const f16*)x, stats_ws, (const f16*)gamma, (const f16*)beta, HW, C, G, eps, silu, total8,
+      (f16*)out);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_layernorm_f16(const void* x, const void* gamma, const void* beta, int64_t rows,
+                      int32_t C, float eps, void* out, void* stream) {
+  if (!x || !gamma || !beta || !out || rows < 0 || C <= 0) return DSU_EINVAL;
+  if (C % 8 != 0 || C > 2048) return DSU_EUNSUP;
+  if (rows == 0) return DSU_OK;
+  layernorm_kernel<<<(unsigned)((rows + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      (const f16*)x, (const f16*)gamma, (const f16*)beta, rows, C, eps, (f16*)out);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_geglu_f16(const void* h, int64_t rows, int32_t D, void* out, void* stream) {
+  if (!h || !out || rows < 0 || D <= 0) return DSU_EINVAL;
+  if (D % 8 != 0) return DSU_EUNSUP;
+  if (rows == 0) return DSU_OK;
+  geglu_kernel<<<dsu_capped_blocks(rows * (D / 8), 256, 4096), 256, 0, (hipStream_t)stream>>>(
+      (const f16*)h, rows, D, (f16*)out);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+}  // extern "C"

@@ -275,3 +275,59 @@ def mv_attention(q, k, vt, seg_batch, heads, seg_len, scale=None):
         _i64x3(vt.stride(0), d * vt.stride(1), vt.stride(1)),
         _i64x3(out.stride(0), out.stride(1), d), float(scale), stream()), "dsu_mv_attention_fwd")
     return out
+
+
+# ------------------------------------------------------------------ f16 NHWC convolution
+def conv_weight_okc(weight):
+    """(O,C,k,k) nn.Conv2d weight -> (O,k*k,C) f16 contiguous (K ordered tap-major)."""
+    O, Cin, k, _ = weight.shape
+    return weight.detach().permute(0, 2, 3, 1).reshape(O, k * k, Cin).to(torch.float16).contiguous()
+
+
+def conv2d_nhwc_f16(x_nhwc, w_okc, bias=None, k=3, stride=1, pad=1, upsample2x=False, addvec=None,
+                    residual=None):
+    """x_nhwc (B,H,W,C) f16 contiguous -> (B,OH,OW,O) f16."""
+    B, H, W, Cin = x_nhwc.shape
+    O = w_okc.shape[0]
+    assert w_okc.shape[1] == k * k and w_okc.shape[2] == Cin
+    IH, IW = (2 * H, 2 * W) if upsample2x else (H, W)
+    OH, OW = (IH + 2 * pad - k) // stride + 1, (IW + 2 * pad - k) // stride + 1
+    out = torch.empty((B, OH, OW, O), dtype=torch.float16, device=x_nhwc.device)
+    f16 = torch.float16
+    check(lib().dsu_conv2d_nhwc_f16_fwd(ptr(x_nhwc, f16), ptr(w_okc, f16), ptr(bias, f16), B, H, W,
+                                        Cin, O, k, stride, pad, int(upsample2x), ptr(addvec, f16),
+                                        ptr(residual, f16), ptr(out), stream()),
+          "dsu_conv2d_nhwc_f16_fwd")
+    return out
+
+
+# ------------------------------------------------------------------ norms / activations (f16)
+def groupnorm_nhwc_f16(x, gamma, beta, groups, eps=1e-5, silu=False):
+    """x (B,H,W,C) or (B,HW,C) f16 contiguous."""
+    B, Cc = x.shape[0], x.shape[-1]
+    HW = x.numel() // (B * Cc)
+    out = torch.empty_like(x)
+    ws = torch.empty(B * groups * 2, dtype=torch.float32, device=x.device)
+    f16 = torch.float16
+    check(lib().dsu_groupnorm_nhwc_f16(ptr(x, f16), ptr(gamma, f16), ptr(beta, f16), B, HW, Cc,
+                                       groups, float(eps), int(silu), ptr(ws), ptr(out), stream()),
+          "dsu_groupnorm_nhwc_f16")
+    return out
+
+
+def layernorm_f16(x, gamma, beta, eps=1e-5):
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    out = torch.empty_like(x)
+    f16 = torch.float16
+    check(lib().dsu_layernorm_f16(ptr(x, f16), ptr(gamma, f16), ptr(beta, f16), rows, Cc,
+                                  float(eps), ptr(out), stream()), "dsu_layernorm_f16")
+    return out
+
+
+def geglu_f16(h):
+    D = h.shape[-1] // 2
+    rows = h.numel() // (2 * D)
+    out = torch.empty(h.shape[:-1] + (D,), dtype=torch.float16, device=h.device)
+    check(lib().dsu_geglu_f16(ptr(h, torch.float16), rows, D, ptr(out), stream()), "dsu_geglu_f16")
+    return out

@@ -214,6 +214,37 @@ int dsu_mv_attention_fwd(const void* q, const void* k, const void* vt, void* out
                          const int64_t* k_strides, const int64_t* vt_strides,
                          const int64_t* o_strides, float scale, void* stream);
 
+/* nn.Conv2d forward on NHWC f16 activations with f32 accumulation (diffusers ResnetBlock2D /
+ * Downsample2D / Upsample2D / conv_in / conv_out convolutions, unet_mv2d_blocks.py:528,649,
+ * 688,798,839; unet_mv2d_condition.py:290,623).
+ *   input (B,H,W,C) f16; weight_okc (O, k*k, C) f16 = the nn.Conv2d weight (O,C,k,k)
+ *   permuted to (O,k,k,C) once by the caller; bias (O) f16 or NULL.
+ *   upsample2x != 0: the convolution reads the nearest-neighbour x2 upsampled input
+ *   (Upsample2D = F.interpolate(scale 2, nearest) + conv) without materialising it.
+ *   addvec (B,O) f16 or NULL: added per image and channel (time-embedding projection of
+ *   ResnetBlock2D); residual (B,OH,OW,O) f16 or NULL: added last.  C % 8 == 0. */
+int dsu_conv2d_nhwc_f16_fwd(const void* input, const void* weight_okc, const void* bias,
+                            int32_t B, int32_t H, int32_t W, int32_t C, int32_t O, int32_t k,
+                            int32_t stride, int32_t pad, int32_t upsample2x, const void* addvec,
+                            const void* residual, void* out, void* stream);
+
+/* nn.GroupNorm(G, C, eps) on NHWC f16 (+ optional fused SiLU): diffusers ResnetBlock2D
+ * norm1/norm2 + nonlinearity, TransformerMV2DModel.norm (transformer_mv2d.py:304),
+ * conv_norm_out + conv_act (unet_mv2d_condition.py:1046-1048).  x/out (B,HW,C) f16;
+ * gamma/beta (C) f16; stats_ws: caller-owned f32 scratch of B*G*2 floats. */
+int dsu_groupnorm_nhwc_f16(const void* x, const void* gamma, const void* beta, int32_t B,
+                           int32_t HW, int32_t C, int32_t G, float eps, int32_t silu,
+                           float* stats_ws, void* out, void* stream);
+
+/* nn.LayerNorm(C) over the last dimension of (rows, C) f16 (BasicMVTransformerBlock
+ * norm1 / norm_joint_mid / norm2 / norm3, transformer_mv2d.py:447-519). */
+int dsu_layernorm_f16(const void* x, const void* gamma, const void* beta, int64_t rows,
+                      int32_t C, float eps, void* out, void* stream);
+
+/* diffusers GEGLU (FeedForward activation_fn="geglu", transformer_mv2d.py:483):
+ * h (rows, 2*D) f16 = proj output; out[r][j] = h[r][j] * gelu_erf(h[r][D+j]). */
+int dsu_geglu_f16(const void* h, int64_t rows, int32_t D, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif
