@@ -1,0 +1,87 @@
+"""One process per GPU; drawings / frames shard embarrassingly.
+
+The only collectives on the path: an RCCL broadcast of the shared read-only weights once
+(root 0) and a gather of the small per-rank outputs.  There is no per-step collective: every
+drawing owns its diffusion sample, its NSR optimisation and its per-character generators.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init(backend=None):
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def shard(items, rank, world):
+    """Static round-robin partition: item i -> rank i % world (uids / frames)."""
+    return [it for i, it in enumerate(items) if i % world == rank]
+
+
+@torch.no_grad()
+def broadcast_module(module, src=0, bucket_bytes=256 << 20):
+    """Broadcast every parameter and buffer of `module` from rank `src`, coalesced into large
+    flat buckets (xGMI is point-to-point: few big messages, not one per tensor)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return 0
+    tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.numel() > 0]
+    total = 0
+    by_dtype = {}
+    for t in tensors:
+        by_dtype.setdefault((t.dtype, t.device), []).append(t)
+    for (dtype, device), ts in by_dtype.items():
+        bucket, size = [], 0
+        for t in ts + [None]:
+            if t is not None and (size + t.numel() * t.element_size() <= bucket_bytes or not bucket):
+                bucket.append(t)
+                size += t.numel() * t.element_size()
+                continue
+            flat = torch.cat([b.detach().reshape(-1) for b in bucket])
+            dist.broadcast(flat, src)
+            off = 0
+            for b in bucket:
+                b.detach().copy_(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()
+            total += size
+            bucket, size = ([t], t.numel() * t.element_size()) if t is not None else ([], 0)
+    return total
+
+
+def gather_tensor(t, dst=0):
+    """Gather equally-shaped per-rank tensors on `dst` (list on dst, None elsewhere)."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return [t]
+    world = dist.get_world_size()
+    out = [torch.empty_like(t) for _ in range(world)] if dist.get_rank() == dst else None
+    if dist.get_backend() == "nccl":
+        # gather is implemented on top of all_gather for NCCL/RCCL in older stacks
+        buf = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(buf, t)
+        return buf if dist.get_rank() == dst else None
+    dist.gather(t, out, dst)
+    return out
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    t = torch.tensor([float(value)], device=device, dtype=torch.float64)
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -1,0 +1,131 @@
+"""One drawing through the hot path: 6-view diffusion -> NSR reconstruction -> 24-frame
+stylisation (mv.py -> recon.py -> test_stage1.py -> test_stage2.py of the reference), with the
+stages handing tensors over in memory instead of PNG/OBJ files.
+
+Synthetic inputs: a 512x512 RGBA "drawing" (low-pass random colour inside an
+ellipse), random-init weights of the reference architectures.  Blender/Mixamo rigging between
+recon and stylisation is an external manual tool in the reference (README.md:183-186); the
+stylisation frames are synthetic colour / position / edge maps of the stated shapes.
+"""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from .mv.pipeline import build_random_pipeline
+from .nsr.system import OrthoData, OrthoNeuSSystem, VIEWS, inv_rt, rt_opengl2opencv, ideal_w2c
+from .style.generators import build_model
+
+STYLE_ARGS = dict(use_bias=False, tanh=True, append_smoothers=True, resnet_blocks=7,
+                  filters=[32, 64, 128, 128, 128, 64], input_channels=6)   # config_stage{1,2}.yaml
+
+
+def synthetic_drawing(seed, size=512, device="cuda"):
+    """(4,size,size) float RGBA in [0,1]: 8x8-block colour noise inside a filled ellipse."""
+    g = torch.Generator().manual_seed(seed)
+    blocks = torch.rand(3, size // 8, size // 8, generator=g)
+    rgb = F.interpolate(blocks[None], size=(size, size), mode="nearest")[0]
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, size), torch.linspace(-1, 1, size), indexing="ij")
+    alpha = ((xx / 0.55) ** 2 + (yy / 0.8) ** 2 <= 1.0).float()
+    return torch.cat([rgb * alpha + (1 - alpha), alpha[None]], 0).to(device)
+
+
+def synthetic_frames(seed, n_frames=24, size=512, device="cuda"):
+    """DatasetFullImages tensors (training/data.py:23-47): (n,6,H,W) = RGB[-1,1] + mask + pos-XY."""
+    g = torch.Generator().manual_seed(seed + 1000)
+    yy, xx = torch.meshgrid(torch.linspace(-1, 1, size), torch.linspace(-1, 1, size), indexing="ij")
+    tex = F.interpolate(torch.rand(1, 3, 16, 16, generator=g), size=(size, size), mode="bilinear",
+                        align_corners=False)[0]
+    frames = []
+    for f in range(n_frames):
+        cx = 0.3 * np.sin(2 * np.pi * f / n_frames)
+        mask = (((xx - cx) / 0.5) ** 2 + (yy / 0.75) ** 2 <= 1.0).float()
+        rgb = (tex * 2 - 1) * mask + (1 - mask)
+        pos = torch.stack([xx, yy]) * mask + (1 - mask)
+        frames.append(torch.cat([rgb, mask[None], pos], 0))
+    return torch.stack(frames).to(device)
+
+
+def to_image_space(x):
+    """custom_transforms.py:8-9 on the device: clip -> uint8."""
+    return ((x.clamp(-1, 1) + 1) / 2 * 255).to(torch.uint8)
+
+
+class DrawingPipeline:
+    """Holds the shared read-only weights (diffusion UNet/VAE/CLIP) and runs drawings."""
+
+    def __init__(self, device="cuda", seed=0, mv_steps=75, nsr_steps=3000, n_frames=24,
+                 with_clip=True, export_resolution=512):
+        self.device = torch.device(device)
+        self.mv_steps, self.nsr_steps, self.n_frames = mv_steps, nsr_steps, n_frames
+        self.export_resolution = export_resolution
+        self.mv = build_random_pipeline(self.device, seed, with_clip=with_clip)
+        torch.manual_seed(seed + 1)
+        self.gen1 = build_model("GeneratorJ_RIC", STYLE_ARGS, self.device).eval()
+        self.gen2 = build_model("GeneratorJ", STYLE_ARGS, self.device).eval()
+
+    def shared_modules(self):
+        mods = [self.mv.unet, self.mv.vae, self.gen1, self.gen2]
+        if self.mv.image_encoder is not None:
+            mods.append(self.mv.image_encoder)
+        return mods
+
+    # ---------------------------------------------------------------- stage 2a: mv.py
+    @torch.no_grad()
+    def multiview(self, drawing_rgba, seed):
+        """SingleImageDataset (white-background 256x256 x6 views) -> 12-sample batch ->
+        pipeline (mv.py:70-86).  Returns normals (6,3,256,256), colours (6,3,256,256) in [0,1]."""
+        rgb, a = drawing_rgba[:3], drawing_rgba[3:4]
+        img = F.interpolate((rgb * a + (1 - a))[None], size=(256, 256), mode="bicubic",
+                            align_corners=False).clamp(0, 1)
+        imgs_in = img.expand(12, -1, -1, -1).contiguous()
+        g = torch.Generator(device=self.device).manual_seed(seed)
+        out = self.mv(imgs_in, generator=g, guidance_scale=1.0, output_type="pt", eta=1.0,
+                      num_inference_steps=self.mv_steps)
+        return out[:6], out[6:]
+
+    # ---------------------------------------------------------------- stage 2b: recon.py
+    def reconstruct(self, normals, colors, drawing_rgba, seed):
+        """OrthoDatasetBase from in-memory mv outputs (ortho.py:54-97: 1024^2 images, normals
+        from the normal maps rotated to the front camera's world frame, masks), then the NSR
+        optimisation and the 2 x 512^3 SDF export."""
+        dev = self.device
+        size = 1024
+        up = lambda t: F.interpolate(t.float(), size=(size, size), mode="bicubic",
+                                     align_corners=False).clamp(0, 1)
+        col = up(colors).permute(0, 2, 3, 1)
+        nrm = up(normals).permute(0, 2, 3, 1) * 2 - 1                      # img2normal
+        alpha = F.interpolate(drawing_rgba[3:4][None], size=(size, size), mode="nearest")[0, 0]
+        masks = torch.stack([alpha, alpha, alpha, alpha.flip(1), alpha, alpha]) > 0.5
+        nrm = nrm * masks[..., None]
+        front = torch.from_numpy(inv_rt(rt_opengl2opencv(ideal_w2c("front")))[:3, :3]).float().to(dev)
+        n_cv = nrm * torch.tensor([1.0, -1.0, -1.0], device=dev)           # normal_opengl2opencv
+        n_world = n_cv @ front.T
+        poses = torch.stack([torch.from_numpy(inv_rt(rt_opengl2opencv(ideal_w2c(v)))).float()
+                             for v in VIEWS])
+        data = OrthoData(col, masks, n_world, poses, dev)
+        system = OrthoNeuSSystem(device=dev, seed=seed)
+        system.fit(data, max_steps=self.nsr_steps)
+        coarse, fine, vmin, vmax = system.export_levels(self.export_resolution)
+        return system, (fine <= 0)
+
+    # ---------------------------------------------------------------- stage 3: test_stage1/2.py
+    @torch.no_grad()
+    def stylize(self, frames):
+        """frames (n,6,H,W).  Stage 1 per frame, quantised to uint8 like the PNG hand-off, then
+        stage 2 on the re-normalised stage-1 RGB (+ mask + pos)."""
+        outs = []
+        for f in frames:
+            x = f[None]
+            s1 = self.gen1(x)[0]
+            q = to_image_space(s1).float() / 255.0 * 2 - 1                 # PNG round trip
+            x2 = torch.cat([q, x[0, 3:]], 0)[None]
+            s2 = self.gen2(x2)[0]
+            outs.append(torch.cat([to_image_space(s2), (x[0, 3:4] * 255).to(torch.uint8)], 0))
+        return torch.stack(outs)
+
+    def run(self, seed):
+        drawing = synthetic_drawing(seed, device=self.device)
+        normals, colors = self.multiview(drawing, 123456 + seed)
+        system, inside = self.reconstruct(normals, colors, drawing, 123456 + seed)
+        frames = self.stylize(synthetic_frames(seed, self.n_frames, device=self.device))
+        return {"views": colors, "inside_voxels": inside.sum(), "frames": frames}
