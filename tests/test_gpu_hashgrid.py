@@ -169,3 +169,25 @@ def test_sdf_full_size_linearity(dev):
     ref = oh.sdf_network(tab.cpu().numpy(), [m.cpu().numpy() for m in mlp],
                          pts[sel].cpu().numpy(), 1.0, LV, 7)[:, :1]
     np.testing.assert_allclose(a[sel].cpu().numpy(), ref, rtol=2e-5, atol=2e-5)
+
+
+def test_fused_sdf_matches_reference_volume_sdf_fixture(dev):
+    """The fused kernel against outputs of the reference's own VolumeSDF.forward
+    (tests/golden/nsr_reference.npz, tests/golden/make_nsr_golden.py)."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "nsr_reference.npz"))
+    g = torch.Generator().manual_seed(int(gold["table_seed"]))
+    tab = ((torch.rand(CFG.n_params, generator=g) * 2 - 1) * float(gold["table_scale"])).half()
+    tab = tab.view(-1, 2).to(dev)
+    mlp = [torch.from_numpy(gold[k]).to(dev) for k in ("w0", "b0", "w1", "b1")]
+    for step, level in ((0, 4), (1500, 5), (2999, 6)):
+        k = f"s{step}."
+        eps = float(gold[k + "eps"])
+        pts = torch.from_numpy(gold[k + "pts"]).to(dev)
+        sdf, grad, feat, lap = ops.sdf_fd_fwd(CFG, tab, mlp, pts, 1.0, eps, level)
+        np.testing.assert_allclose(sdf.cpu().numpy(), gold[k + "sdf"], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(feat.cpu().numpy(), gold[k + "feature"], rtol=0, atol=5e-6)
+        np.testing.assert_allclose(grad.cpu().numpy(), gold[k + "grad"], rtol=0, atol=2e-6 / eps)
+        np.testing.assert_allclose(lap.cpu().numpy(), gold[k + "laplace"], rtol=0, atol=2e-5 / eps ** 2)
+        s1 = ops.sdf_fwd(CFG, tab, mlp, pts, 1.0, level, 1)[:, 0]
+        np.testing.assert_allclose(s1.cpu().numpy(), gold[k + "forward_level"], rtol=0, atol=5e-6)

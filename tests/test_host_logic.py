@@ -1,0 +1,80 @@
+"""CPU: host-side mirrors of the reference's glue (scheduler, camera embedding, sharding)."""
+import numpy as np
+import torch
+
+from drawingspinup_amd.mv.pipeline import DDIMScheduler, DEFAULT_CAMERA_EMBEDDING
+from drawingspinup_amd.nsr import system as S
+
+
+def test_ddim_timesteps_and_step():
+    s = DDIMScheduler()
+    s.set_timesteps(75)
+    ts = s.timesteps.tolist()
+    # 'leading' spacing with steps_offset=1: step ratio 1000//75 = 13 -> 962+1, ..., 0+1
+    assert len(ts) == 75 and ts[0] == 74 * 13 + 1 and ts[-1] == 1 and ts[0] - ts[1] == 13
+    # alphas_cumprod of the scaled-linear schedule (SD-1.x): known end points
+    assert abs(float(s.alphas_cumprod[0]) - (1 - 0.00085)) < 1e-7
+    assert abs(float(s.alphas_cumprod[-1]) - 0.0047) < 2e-4
+    # eta = 0, exact epsilon: DDIM inverts q(x_t | x_0) deterministically
+    g = torch.Generator().manual_seed(0)
+    x0, eps = torch.randn(2, 4, 8, 8, generator=g), torch.randn(2, 4, 8, 8, generator=g)
+    t = ts[10]
+    a = s.alphas_cumprod[t]
+    xt = a ** 0.5 * x0 + (1 - a) ** 0.5 * eps
+    prev = s.step(eps, t, xt, eta=0.0)
+    ap = s.alphas_cumprod[t - 13]
+    torch.testing.assert_close(prev, ap ** 0.5 * x0 + (1 - ap) ** 0.5 * eps, rtol=1e-4, atol=1e-4)
+    # eta = 1 uses the injected variance noise with sigma_t
+    noise = torch.randn(2, 4, 8, 8, generator=g)
+    p1 = s.step(eps, t, xt, eta=1.0, variance_noise=noise)
+    var = ((1 - ap) / (1 - a)) * (1 - a / ap)
+    exp = ap ** 0.5 * x0 + (1 - ap - var) ** 0.5 * eps + var ** 0.5 * noise
+    torch.testing.assert_close(p1, exp, rtol=1e-4, atol=1e-4)
+
+
+def test_camera_embedding_table():
+    # rows equal SingleImageDataset.get_T of the nine_views poses (f16 rounded)
+    ce = DEFAULT_CAMERA_EMBEDDING
+    assert ce.shape == (12, 5)
+    np.testing.assert_allclose(ce[1, 1:3].float().numpy(), [-0.23624, 0.81238], atol=6e-4)
+    np.testing.assert_allclose(ce[3, 1:3].float().numpy(), [0.52204, 3.14159], atol=2e-3)
+    assert ce[:6, 3].tolist() == [1.0] * 6 and ce[6:, 4].tolist() == [1.0] * 6   # task one-hots
+
+
+def test_pose_generator_matches_fixed_pose_structure():
+    # instant_nsr/datasets/fixed_poses/000_front_RT.txt: rows (1,0,0|0), (0,0,1|0), (0,-1,0|-1.3)
+    f = S.ideal_w2c("front")
+    np.testing.assert_allclose(f, [[1, 0, 0, 0], [0, 0, 1, 0], [0, -1, 0, -1.3]], atol=1e-12)
+    r = S.ideal_w2c("right")
+    np.testing.assert_allclose(r, [[0, 1, 0, 0], [0, 0, 1, 0], [1, 0, 0, -1.3]], atol=1e-12)
+    fl = S.ideal_w2c("front_left")
+    np.testing.assert_allclose(fl[2], [-0.70710678, -0.70710678, 0, -1.83847763], atol=1e-6)
+    # ortho rays (ray_utils.py:20-33): pixel centres, origin plane z=0, direction +z
+    o, d = S.ortho_rays_hw(4, 2)
+    assert o.shape == (2, 4, 3) and torch.equal(d[..., 2], torch.ones(2, 4))
+    np.testing.assert_allclose(o[0, :, 0].numpy(), [-0.75, -0.25, 0.25, 0.75])
+    np.testing.assert_allclose(o[:, 0, 1].numpy(), [-0.5, 0.5])
+
+
+def test_lr_schedule_and_param_groups():
+    """configs/neuralangelo-ortho-wmask.yaml:101-127: AdamW groups geometry 1e-3 / texture 1e-2 /
+    variance 1e-3, constant for 500 steps then exponential decay to 0.1x at step 3000."""
+    sysm = S.OrthoNeuSSystem(device="cpu")
+    names = [g["name"] for g in sysm.optimizer.param_groups]
+    assert names == ["geometry", "texture", "variance"]
+    n_geo = sum(p.numel() for p in sysm.optimizer.param_groups[0]["params"])
+    assert n_geo == 3838848 * 2 + 64 * 23 + 64 + 64 + 13 * 64 + 13 + 13      # table + weight-normed MLP
+    for step, factor in ((0, 1.0), (499, 1.0), (500, 1.0), (1750, 0.1 ** 0.5), (3000, 0.1)):
+        sysm.global_step = step
+        sysm._set_lr()
+        lrs = [g["lr"] for g in sysm.optimizer.param_groups]
+        np.testing.assert_allclose(lrs, [1e-3 * factor, 1e-2 * factor, 1e-3 * factor], rtol=1e-9)
+    assert sysm.train_num_rays == 256 and sysm.train_num_samples == 256 * 1024
+
+
+def test_sharding():
+    from drawingspinup_amd import dist
+    uids = list(range(24))
+    parts = [dist.shard(uids, r, 8) for r in range(8)]
+    assert sorted(sum(parts, [])) == uids and all(len(p) == 3 for p in parts)
+    assert dist.shard(uids, 0, 1) == uids
