@@ -17,7 +17,25 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from .. import ops
 from .unet import (Downsample2D, Upsample2D, conv_nhwc, group_norm)
+
+
+def _conv_small_cin(conv, x_nhwc):
+    """3x3 conv whose input has fewer than 8 channels (VAE conv_in: 3 or 4): zero-pad channels
+    and weights to 8 so the HIP kernel's 16-byte channel groups apply (cached per weight)."""
+    w = conv.weight
+    c = getattr(conv, "_dsu_okc8", None)
+    if c is None or c[0] != w._version or c[1].device != w.device:
+        wp = F.pad(w.detach(), (0, 0, 0, 0, 0, 8 - w.shape[1]))
+        conv._dsu_okc8 = (w._version, ops.conv_weight_okc(wp))
+        c = conv._dsu_okc8
+    xp = F.pad(x_nhwc, (0, 8 - x_nhwc.shape[-1])).contiguous()
+    return ops.conv2d_nhwc_f16(xp, c[1], conv.bias, 3, 1, 1)
+
+
+def _conv1x1_nhwc(conv, x_nhwc):
+    return F.linear(x_nhwc, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
 
 
 # ----------------------------------------------------------------------------------- scheduler
@@ -143,17 +161,14 @@ class VaeEncoder(nn.Module):
         self.conv_out = nn.Conv2d(c, 2 * latent, 3, padding=1)
 
     def forward(self, x_nchw):
-        # 3 input channels: one tiny library convolution (the HIP conv reads 8-channel groups)
-        x = F.conv2d(x_nchw, self.conv_in.weight, self.conv_in.bias, padding=1)
-        x = x.permute(0, 2, 3, 1).contiguous()
+        x = _conv_small_cin(self.conv_in, x_nchw.permute(0, 2, 3, 1))
         for b in self.down_blocks:
             for r in b.resnets:
                 x = r(x)
             if hasattr(b, "downsamplers"):
                 # diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)) then stride-2 conv
-                conv = b.downsamplers[0].conv
-                xp = F.pad(x.permute(0, 3, 1, 2), (0, 1, 0, 1))
-                x = F.conv2d(xp, conv.weight, conv.bias, stride=2).permute(0, 2, 3, 1).contiguous()
+                xp = F.pad(x, (0, 0, 0, 1, 0, 1)).contiguous()           # NHWC: pad W and H by (0,1)
+                x = conv_nhwc(b.downsamplers[0].conv, xp)                  # stride 2, padding 0
         x = self.mid_block(x)
         x = group_norm(self.conv_norm_out, x, silu=True)
         return conv_nhwc(self.conv_out, x)
@@ -178,8 +193,7 @@ class VaeDecoder(nn.Module):
         self.conv_out = nn.Conv2d(c, cout, 3, padding=1)
 
     def forward(self, z_nchw):
-        x = F.conv2d(z_nchw, self.conv_in.weight, self.conv_in.bias, padding=1)   # 4 channels in
-        x = x.permute(0, 2, 3, 1).contiguous()
+        x = _conv_small_cin(self.conv_in, z_nchw)            # z arrives NHWC, 4 channels
         x = self.mid_block(x)
         for b in self.up_blocks:
             for r in b.resnets:
@@ -202,12 +216,12 @@ class AutoencoderKL(nn.Module):
     @torch.no_grad()
     def encode_mode(self, x):
         """vae.encode(x).latent_dist.mode(): the mean half of the moments."""
-        h = self.encoder(x).permute(0, 3, 1, 2)
-        return F.conv2d(h, self.quant_conv.weight, self.quant_conv.bias)[:, :4]
+        h = _conv1x1_nhwc(self.quant_conv, self.encoder(x))
+        return h[..., :4].permute(0, 3, 1, 2).contiguous()
 
     @torch.no_grad()
     def decode(self, z):
-        return self.decoder(F.conv2d(z, self.post_quant_conv.weight, self.post_quant_conv.bias))
+        return self.decoder(_conv1x1_nhwc(self.post_quant_conv, z.permute(0, 2, 3, 1).contiguous()))
 
 
 # ----------------------------------------------------------------------------------- pipeline
