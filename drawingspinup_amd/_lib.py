@@ -51,6 +51,11 @@ _PROTOS = {
     "dsu_weights_from_alpha_fwd": [P, P, P, c_i64, P, P],
     "dsu_weights_from_alpha_bwd": [P, P, P, P, P, c_i64, P, P],
     "dsu_accumulate_fwd": [P, P, c_i32, P, P, c_i64, P, P],
+    "dsu_neus_composite_fwd": [P, P, P, P, P, P, P, P, c_i64, P, c_f32, P, P, P, P],
+    "dsu_neus_composite_bwd": [P, P, P, P, P, P, P, P, c_i64, P, c_f32, P, P, P, P, P, P, P,
+                               P, P],
+    "dsu_shade_prep_fwd": [P, P, c_i64, P, P, P],
+    "dsu_shade_prep_bwd": [P, P, P, c_i64, P, P, P],
     "dsu_occgrid_ema": [P, P, P, c_i64, c_f32, P],
     "dsu_occgrid_binarize": [P, c_i64, c_f32, P, P],
     "dsu_ric_offsets": [c_i32, c_i32, P, P],

@@ -213,6 +213,244 @@ bool is_pow2f(float x) {
   return x > 0.0f && frexpf(x, &e) == 0.5f;
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Fused NeuS shading + compositing (neus.py:90-112 get_alpha, :143-153 weights/accumulate).
+// One wave per ray; lanes walk the ray's samples 64 at a time; transmittance by a wave-level
+// product scan carried across chunks.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_incl_scan_mul(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_up(v, o);
+    if (lane >= o) v *= t;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_incl_scan_add(float v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    float t = __shfl_up(v, o);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+struct AlphaOut {
+  float alpha, pc, nc, iter_cos, true_cos;
+  bool clipped;
+};
+
+__device__ __forceinline__ AlphaOut neus_alpha(float sdf, const float n[3], const float d[3],
+                                               float dist, float inv_s, float car) {
+  AlphaOut a;
+  a.true_cos = d[0] * n[0] + d[1] * n[1] + d[2] * n[2];
+  a.iter_cos = -(fmaxf(-a.true_cos * 0.5f + 0.5f, 0.0f) * (1.0f - car) +
+                 fmaxf(-a.true_cos, 0.0f) * car);
+  const float nx = sdf + a.iter_cos * dist * 0.5f, pv = sdf - a.iter_cos * dist * 0.5f;
+  a.pc = sigmoidf_(pv * inv_s);
+  a.nc = sigmoidf_(nx * inv_s);
+  const float raw = ((a.pc - a.nc) + 1e-5f) / (a.pc + 1e-5f);
+  a.clipped = raw < 0.0f || raw > 1.0f;
+  a.alpha = fminf(fmaxf(raw, 0.0f), 1.0f);
+  return a;
+}
+
+// outputs per ray: opacity(1) depth(1) rgb(3) normal(3) -> comp (R,8); per sample: alpha, weights
+__global__ __launch_bounds__(256) void composite_fwd_kernel(
+    const float* __restrict__ sdf, const float* __restrict__ normal,
+    const float* __restrict__ rgb, const float* __restrict__ rays_d,
+    const float* __restrict__ t_starts, const float* __restrict__ t_ends,
+    const int32_t* __restrict__ off, const int32_t* __restrict__ cnt, int64_t n_rays,
+    const float* __restrict__ inv_s_p, float car, float* __restrict__ alpha_o,
+    float* __restrict__ w_o, float* __restrict__ comp) {
+  const float inv_s = fminf(fmaxf(*inv_s_p, 1e-6f), 1e6f);   // .clip(1e-6, 1e6)  (neus.py:91)
+  const int lane = threadIdx.x & 63;
+  const int64_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rays) return;
+  const int64_t b = off[r];
+  const int c = cnt[r];
+  const float d[3] = {rays_d[r * 3], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
+  float T = 1.0f;
+  float acc[8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = 0.0f;
+  for (int j0 = 0; j0 < c; j0 += 64) {
+    const int j = j0 + lane;
+    const bool v = j < c;
+    float al = 0.0f, mid = 0.0f, n[3] = {0.f, 0.f, 0.f}, col[3] = {0.f, 0.f, 0.f};
+    if (v) {
+      const int64_t i = b + j;
+      n[0] = normal[i * 3]; n[1] = normal[i * 3 + 1]; n[2] = normal[i * 3 + 2];
+      const float ts = t_starts[i], te = t_ends[i];
+      mid = (ts + te) / 2.0f;
+      al = neus_alpha(sdf[i], n, d, te - ts, inv_s, car).alpha;
+      col[0] = rgb[i * 3]; col[1] = rgb[i * 3 + 1]; col[2] = rgb[i * 3 + 2];
+    }
+    const float incl = wave_incl_scan_mul(1.0f - al, lane);
+    float excl = __shfl_up(incl, 1);
+    if (lane == 0) excl = 1.0f;
+    const float w = al * (T * excl);
+    T *= __shfl(incl, 63);
+    if (v) {
+      alpha_o[b + j] = al;
+      w_o[b + j] = w;
+      acc[0] += w;
+      acc[1] += w * mid;
+      acc[2] += w * col[0]; acc[3] += w * col[1]; acc[4] += w * col[2];
+      acc[5] += w * n[0]; acc[6] += w * n[1]; acc[7] += w * n[2];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) acc[k] = wave_sum(acc[k]);
+  if (lane < 8) {
+    float v = acc[0];
+#pragma unroll
+    for (int k = 1; k < 8; ++k) v = lane == k ? acc[k] : v;
+    comp[r * 8 + lane] = v;
+  }
+}
+
+// d_comp (R,8) -> d_sdf (N), d_normal (N,3), d_rgb (N,3); d_inv_s accumulated (1 float)
+__global__ __launch_bounds__(256) void composite_bwd_kernel(
+    const float* __restrict__ sdf, const float* __restrict__ normal,
+    const float* __restrict__ rgb, const float* __restrict__ rays_d,
+    const float* __restrict__ t_starts, const float* __restrict__ t_ends,
+    const int32_t* __restrict__ off, const int32_t* __restrict__ cnt, int64_t n_rays,
+    const float* __restrict__ inv_s_p, float car, const float* __restrict__ alpha_s,
+    const float* __restrict__ w_s,
+    const float* __restrict__ d_comp, const float* __restrict__ d_w_extra,
+    float* __restrict__ d_sdf, float* __restrict__ d_normal, float* __restrict__ d_rgb,
+    float* __restrict__ d_inv_s) {
+  const float inv_raw = *inv_s_p;
+  const float inv_s = fminf(fmaxf(inv_raw, 1e-6f), 1e6f);
+  const bool inv_pass = inv_raw >= 1e-6f && inv_raw <= 1e6f;   // clip passes the gradient inside
+  const int lane = threadIdx.x & 63;
+  const int64_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  float dinv = 0.0f;
+  if (r < n_rays) {
+    const int64_t b = off[r];
+    const int c = cnt[r];
+    const float d[3] = {rays_d[r * 3], rays_d[r * 3 + 1], rays_d[r * 3 + 2]};
+    float dc[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) dc[k] = d_comp[r * 8 + k];
+    // pass 1: total = sum_j gw_j * w_j
+    float total = 0.0f;
+    for (int j = lane; j < c; j += 64) {
+      const int64_t i = b + j;
+      const float mid = (t_starts[i] + t_ends[i]) / 2.0f;
+      float gw = dc[0] + dc[1] * mid + dc[2] * rgb[i * 3] + dc[3] * rgb[i * 3 + 1] +
+                 dc[4] * rgb[i * 3 + 2] + dc[5] * normal[i * 3] + dc[6] * normal[i * 3 + 1] +
+                 dc[7] * normal[i * 3 + 2];
+      if (d_w_extra) gw += d_w_extra[i];
+      total += gw * w_s[i];
+    }
+    total = wave_sum(total);
+    // pass 2: nerfacc's weight backward, prefix form
+    float T = 1.0f, done = 0.0f;
+    for (int j0 = 0; j0 < c; j0 += 64) {
+      const int j = j0 + lane;
+      const bool v = j < c;
+      float al = 0.0f, w = 0.0f, gw = 0.0f, n[3] = {0.f, 0.f, 0.f};
+      int64_t i = b + (v ? j : 0);
+      float mid = 0.0f, dist = 0.0f, s = 0.0f;
+      if (v) {
+        al = alpha_s[i]; w = w_s[i];
+        n[0] = normal[i * 3]; n[1] = normal[i * 3 + 1]; n[2] = normal[i * 3 + 2];
+        const float ts = t_starts[i], te = t_ends[i];
+        mid = (ts + te) / 2.0f; dist = te - ts; s = sdf[i];
+        gw = dc[0] + dc[1] * mid + dc[2] * rgb[i * 3] + dc[3] * rgb[i * 3 + 1] +
+             dc[4] * rgb[i * 3 + 2] + dc[5] * n[0] + dc[6] * n[1] + dc[7] * n[2];
+        if (d_w_extra) gw += d_w_extra[i];
+      }
+      const float incl = wave_incl_scan_mul(1.0f - al, lane);
+      float excl = __shfl_up(incl, 1);
+      if (lane == 0) excl = 1.0f;
+      const float Tj = T * excl;
+      const float gww = gw * w;
+      const float pin = wave_incl_scan_add(gww, lane);      // inclusive prefix of gw*w
+      const float before = done + (pin - gww);              // sum_{k<j}
+      T *= __shfl(incl, 63);
+      done += __shfl(pin, 63);
+      if (v) {
+        const float accum = total - before;                 // sum_{k>=j} gw_k w_k
+        const float galpha = (gw * Tj - accum) / fmaxf(1.0f - al, 1e-10f);
+        // alpha = clip(((pc - nc) + 1e-5) / (pc + 1e-5))
+        const AlphaOut a = neus_alpha(s, n, d, dist, inv_s, car);
+        float dsdf = 0.0f, dn[3] = {0.f, 0.f, 0.f};
+        if (!a.clipped) {
+          const float den = a.pc + 1e-5f;
+          const float d_pc = galpha * (1.0f / den - ((a.pc - a.nc) + 1e-5f) / (den * den));
+          const float d_nc = -galpha / den;
+          const float d_pv = d_pc * a.pc * (1.0f - a.pc);   // wrt (prev * inv_s)
+          const float d_nx = d_nc * a.nc * (1.0f - a.nc);
+          const float pv = s - a.iter_cos * dist * 0.5f, nx = s + a.iter_cos * dist * 0.5f;
+          dinv += d_pv * pv + d_nx * nx;
+          dsdf = (d_pv + d_nx) * inv_s;
+          const float d_ic = (d_nx - d_pv) * inv_s * dist * 0.5f;
+          // iter_cos = -(relu(-tc*0.5+0.5)*(1-car) + relu(-tc)*car)
+          float d_tc = 0.0f;
+          if (-a.true_cos * 0.5f + 0.5f > 0.0f) d_tc += 0.5f * (1.0f - car);
+          if (-a.true_cos > 0.0f) d_tc += car;
+          d_tc *= d_ic;
+          dn[0] = d_tc * d[0]; dn[1] = d_tc * d[1]; dn[2] = d_tc * d[2];
+        }
+        d_sdf[i] = dsdf;
+        d_normal[i * 3] = dn[0] + w * dc[5];
+        d_normal[i * 3 + 1] = dn[1] + w * dc[6];
+        d_normal[i * 3 + 2] = dn[2] + w * dc[7];
+        d_rgb[i * 3] = w * dc[2]; d_rgb[i * 3 + 1] = w * dc[3]; d_rgb[i * 3 + 2] = w * dc[4];
+      }
+    }
+  }
+  dinv = wave_sum(dinv);
+  if (lane == 0 && dinv != 0.0f && inv_pass) unsafeAtomicAdd(d_inv_s, dinv);
+}
+
+// normal = grad / max(|grad|, 1e-12) ; tex_in = [feature(13), normal(3)]   (neus.py:143,145)
+__global__ void shade_prep_fwd_kernel(const float* __restrict__ grad,
+                                      const float* __restrict__ feat, int64_t n,
+                                      float* __restrict__ normal, float* __restrict__ tex_in) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g0 = grad[i * 3], g1 = grad[i * 3 + 1], g2 = grad[i * 3 + 2];
+  const float inv = 1.0f / fmaxf(sqrtf(g0 * g0 + g1 * g1 + g2 * g2), 1e-12f);
+  const float n0 = g0 * inv, n1 = g1 * inv, n2 = g2 * inv;
+  normal[i * 3] = n0; normal[i * 3 + 1] = n1; normal[i * 3 + 2] = n2;
+#pragma unroll
+  for (int k = 0; k < 13; ++k) tex_in[i * 16 + k] = feat[i * 13 + k];
+  tex_in[i * 16 + 13] = n0; tex_in[i * 16 + 14] = n1; tex_in[i * 16 + 15] = n2;
+}
+
+// d_grad = (dn - n (n.dn)) / |grad| with dn = d_normal + d_tex_in[13:16]; d_feat = d_tex_in[:13]
+__global__ void shade_prep_bwd_kernel(const float* __restrict__ grad,
+                                      const float* __restrict__ d_normal,
+                                      const float* __restrict__ d_tex_in, int64_t n,
+                                      float* __restrict__ d_grad, float* __restrict__ d_feat) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float g0 = grad[i * 3], g1 = grad[i * 3 + 1], g2 = grad[i * 3 + 2];
+  const float len = sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+  const float inv = 1.0f / fmaxf(len, 1e-12f);
+  const float n0 = g0 * inv, n1 = g1 * inv, n2 = g2 * inv;
+  float d0 = d_tex_in[i * 16 + 13], d1 = d_tex_in[i * 16 + 14], d2 = d_tex_in[i * 16 + 15];
+  if (d_normal) { d0 += d_normal[i * 3]; d1 += d_normal[i * 3 + 1]; d2 += d_normal[i * 3 + 2]; }
+  const float dot = n0 * d0 + n1 * d1 + n2 * d2;
+  const bool ok = len > 1e-12f;
+  d_grad[i * 3] = ok ? (d0 - n0 * dot) * inv : d0 * inv;
+  d_grad[i * 3 + 1] = ok ? (d1 - n1 * dot) * inv : d1 * inv;
+  d_grad[i * 3 + 2] = ok ? (d2 - n2 * dot) * inv : d2 * inv;
+#pragma unroll
+  for (int k = 0; k < 13; ++k) d_feat[i * 13 + k] = d_tex_in[i * 16 + k];
+}
+
 Aabb make_aabb(const float* a6, int res = 1) {
   Aabb a;
   a.pow2 = (res > 0 && (res & (res - 1)) == 0) ? 1 : 0;
@@ -319,6 +557,58 @@ int dsu_occgrid_binarize(const float* occs, int64_t n_cells, float thre, uint8_t
   if (n_cells == 0) return DSU_OK;
   occ_bin_kernel<<<dsu_capped_blocks(n_cells, 256), 256, 0, (hipStream_t)stream>>>(
       occs, n_cells, thre, binary);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_neus_composite_fwd(const float* sdf, const float* normal, const float* rgb,
+                           const float* rays_d, const float* t_starts, const float* t_ends,
+                           const int32_t* offsets, const int32_t* counts, int64_t n_rays,
+                           const float* inv_s, float cos_anneal_ratio, float* alpha,
+                           float* weights, float* comp, void* stream) {
+  if (n_rays < 0 || !inv_s || (n_rays && (!rays_d || !offsets || !counts || !comp)))
+    return DSU_EINVAL;
+  if (n_rays == 0) return DSU_OK;
+  composite_fwd_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      sdf, normal, rgb, rays_d, t_starts, t_ends, offsets, counts, n_rays, inv_s,
+      cos_anneal_ratio, alpha, weights, comp);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_neus_composite_bwd(const float* sdf, const float* normal, const float* rgb,
+                           const float* rays_d, const float* t_starts, const float* t_ends,
+                           const int32_t* offsets, const int32_t* counts, int64_t n_rays,
+                           const float* inv_s, float cos_anneal_ratio, const float* alpha,
+                           const float* weights, const float* d_comp, const float* d_weights,
+                           float* d_sdf, float* d_normal, float* d_rgb, float* d_inv_s,
+                           void* stream) {
+  if (n_rays < 0 || !inv_s || (n_rays && (!rays_d || !offsets || !counts || !d_comp || !d_inv_s)))
+    return DSU_EINVAL;
+  if (n_rays == 0) return DSU_OK;
+  composite_bwd_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      sdf, normal, rgb, rays_d, t_starts, t_ends, offsets, counts, n_rays, inv_s,
+      cos_anneal_ratio, alpha, weights, d_comp, d_weights, d_sdf, d_normal, d_rgb, d_inv_s);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_shade_prep_fwd(const float* grad, const float* feature, int64_t n, float* normal,
+                       float* tex_in, void* stream) {
+  if (n < 0 || (n && (!grad || !feature || !normal || !tex_in))) return DSU_EINVAL;
+  if (n == 0) return DSU_OK;
+  shade_prep_fwd_kernel<<<dsu_blocks_for(n, 256), 256, 0, (hipStream_t)stream>>>(grad, feature, n,
+                                                                               normal, tex_in);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_shade_prep_bwd(const float* grad, const float* d_normal, const float* d_tex_in, int64_t n,
+                       float* d_grad, float* d_feature, void* stream) {
+  if (n < 0 || (n && (!grad || !d_tex_in || !d_grad || !d_feature))) return DSU_EINVAL;
+  if (n == 0) return DSU_OK;
+  shade_prep_bwd_kernel<<<dsu_blocks_for(n, 256), 256, 0, (hipStream_t)stream>>>(
+      grad, d_normal, d_tex_in, n, d_grad, d_feature);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }

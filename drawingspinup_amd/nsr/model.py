@@ -158,6 +158,42 @@ class _SdfFdFn(torch.autograd.Function):
         return None, gt, g[0], g[1], g[2], g[3], None, None, None, None, None
 
 
+class _ShadePrepFn(torch.autograd.Function):
+    """normal = F.normalize(sdf_grad); tex_in = cat(feature, normal)  (neus.py:143, texture.py:22)."""
+
+    @staticmethod
+    def forward(ctx, grad, feature):
+        ctx.save_for_backward(grad)
+        return ops.shade_prep_fwd(grad, feature)
+
+    @staticmethod
+    def backward(ctx, d_normal, d_tex_in):
+        (grad,) = ctx.saved_tensors
+        return ops.shade_prep_bwd(grad, d_normal.contiguous(), d_tex_in.contiguous())
+
+
+class _CompositeFn(torch.autograd.Function):
+    """get_alpha + render_weight_from_alpha + 4x accumulate_along_rays fused (neus.py:90-112,
+    144, 147-153).  Returns comp (R,8) = [opacity, depth, rgb(3), sum w*normal(3)], weights, alpha."""
+
+    @staticmethod
+    def forward(ctx, sdf, normal, rgb, inv_s, rays_d, t_starts, t_ends, off, cnt, car):
+        comp, alpha, w = ops.neus_composite_fwd(sdf, normal, rgb, rays_d, t_starts, t_ends, off,
+                                                cnt, inv_s, car)
+        ctx.save_for_backward(sdf, normal, rgb, inv_s, rays_d, t_starts, t_ends, off, cnt, alpha, w)
+        ctx.car = car
+        ctx.mark_non_differentiable(alpha)
+        return comp, w, alpha
+
+    @staticmethod
+    def backward(ctx, d_comp, d_w, _d_alpha):
+        sdf, normal, rgb, inv_s, rays_d, ts, te, off, cnt, alpha, w = ctx.saved_tensors
+        d_sdf, d_normal, d_rgb, d_inv = ops.neus_composite_bwd(
+            sdf, normal, rgb, rays_d, ts, te, off, cnt, inv_s, ctx.car, alpha, w,
+            d_comp.contiguous(), None if d_w is None else d_w.contiguous())
+        return d_sdf, d_normal, d_rgb, d_inv.view_as(inv_s), None, None, None, None, None, None
+
+
 class VolumeSDF(nn.Module):
     def __init__(self, config):
         super().__init__()
@@ -312,6 +348,9 @@ class NeuSModel(nn.Module):
         self.randomized = config.randomized
         self.render_step_size = 1.732 * 2 * config.radius / config.num_samples_per_ray
         self.cos_anneal_ratio = 1.0
+        # True: shading + compositing in the fused kernels; False: the op-by-op path through the
+        # nerfacc-compatible operators (same results; kept for the drop-in seam and as a cross-check)
+        self.fused_shading = True
 
     def occ_eval_fn(self, x):
         sdf = self.geometry(x, with_grad=False, with_feature=False)
@@ -378,15 +417,28 @@ class NeuSModel(nn.Module):
             sdf, sdf_grad, feature, sdf_laplace = self.geometry(positions, with_grad=True,
                                                                 with_feature=True,
                                                                 with_laplace=True)
-        normal = F.normalize(sdf_grad, p=2, dim=-1)
-        alpha = self.get_alpha(sdf, normal, t_dirs, dists)[..., None]
-        rgb = self.texture(feature, t_dirs, normal)
-        weights = render_weight_from_alpha(alpha, ray_indices=ray_indices, n_rays=n_rays)
-        opacity = accumulate_along_rays(weights, ray_indices, values=None, n_rays=n_rays)
-        depth = accumulate_along_rays(weights, ray_indices, values=midpoints, n_rays=n_rays)
-        comp_rgb = accumulate_along_rays(weights, ray_indices, values=rgb, n_rays=n_rays)
-        comp_normal = accumulate_along_rays(weights, ray_indices, values=normal, n_rays=n_rays)
-        comp_normal = F.normalize(comp_normal, p=2, dim=-1)
+        if self.fused_shading:
+            from .render import RayPacking
+            _, off, cnt = RayPacking.last
+            normal, tex_in = _ShadePrepFn.apply(sdf_grad.contiguous(), feature.contiguous())
+            rgb = torch.sigmoid(self.texture.network(tex_in))
+            comp, weights, alpha = _CompositeFn.apply(
+                sdf.contiguous(), normal, rgb.contiguous(), self.variance.inv_s.reshape(1),
+                rays_d, t_starts.reshape(-1), t_ends.reshape(-1), off, cnt,
+                float(self.cos_anneal_ratio))
+            opacity, depth, comp_rgb = comp[:, 0:1], comp[:, 1:2], comp[:, 2:5]
+            comp_normal = F.normalize(comp[:, 5:8], p=2, dim=-1)
+            weights = weights[:, None]
+        else:
+            normal = F.normalize(sdf_grad, p=2, dim=-1)
+            alpha = self.get_alpha(sdf, normal, t_dirs, dists)[..., None]
+            rgb = self.texture(feature, t_dirs, normal)
+            weights = render_weight_from_alpha(alpha, ray_indices=ray_indices, n_rays=n_rays)
+            opacity = accumulate_along_rays(weights, ray_indices, values=None, n_rays=n_rays)
+            depth = accumulate_along_rays(weights, ray_indices, values=midpoints, n_rays=n_rays)
+            comp_rgb = accumulate_along_rays(weights, ray_indices, values=rgb, n_rays=n_rays)
+            comp_normal = accumulate_along_rays(weights, ray_indices, values=normal, n_rays=n_rays)
+            comp_normal = F.normalize(comp_normal, p=2, dim=-1)
         out = {"comp_rgb": comp_rgb, "comp_normal": comp_normal, "opacity": opacity,
                "depth": depth, "rays_valid": opacity > 0,
                "num_samples": torch.as_tensor([len(t_starts)], dtype=torch.int32,

@@ -331,3 +331,58 @@ def geglu_f16(h):
     out = torch.empty(h.shape[:-1] + (D,), dtype=torch.float16, device=h.device)
     check(lib().dsu_geglu_f16(ptr(h, torch.float16), rows, D, ptr(out), stream()), "dsu_geglu_f16")
     return out
+
+
+# ------------------------------------------------------------------ fused NeuS shading / compositing
+def shade_prep_fwd(grad, feature):
+    grad, feature = _f32c(grad), _f32c(feature)
+    n = grad.shape[0]
+    normal = torch.empty((n, 3), dtype=torch.float32, device=grad.device)
+    tex_in = torch.empty((n, 16), dtype=torch.float32, device=grad.device)
+    check(lib().dsu_shade_prep_fwd(ptr(grad), ptr(feature), n, ptr(normal), ptr(tex_in), stream()),
+          "dsu_shade_prep_fwd")
+    return normal, tex_in
+
+
+def shade_prep_bwd(grad, d_normal, d_tex_in):
+    grad = _f32c(grad)
+    n = grad.shape[0]
+    d_grad = torch.empty((n, 3), dtype=torch.float32, device=grad.device)
+    d_feat = torch.empty((n, 13), dtype=torch.float32, device=grad.device)
+    dn = None if d_normal is None else _f32c(d_normal)
+    check(lib().dsu_shade_prep_bwd(ptr(grad), ptr(dn), ptr(_f32c(d_tex_in)), n, ptr(d_grad),
+                                   ptr(d_feat), stream()), "dsu_shade_prep_bwd")
+    return d_grad, d_feat
+
+
+def neus_composite_fwd(sdf, normal, rgb, rays_d, t_starts, t_ends, offsets, counts, inv_s, car):
+    n, n_rays = sdf.shape[0], rays_d.shape[0]
+    dev = sdf.device
+    alpha = torch.empty(n, dtype=torch.float32, device=dev)
+    w = torch.empty(n, dtype=torch.float32, device=dev)
+    comp = torch.empty((n_rays, 8), dtype=torch.float32, device=dev)
+    check(lib().dsu_neus_composite_fwd(ptr(_f32c(sdf)), ptr(_f32c(normal)), ptr(_f32c(rgb)),
+                                       ptr(_f32c(rays_d)), ptr(_f32c(t_starts)), ptr(_f32c(t_ends)),
+                                       ptr(offsets, torch.int32), ptr(counts, torch.int32), n_rays,
+                                       ptr(inv_s, torch.float32), float(car), ptr(alpha), ptr(w),
+                                       ptr(comp), stream()), "dsu_neus_composite_fwd")
+    return comp, alpha, w
+
+
+def neus_composite_bwd(sdf, normal, rgb, rays_d, t_starts, t_ends, offsets, counts, inv_s, car,
+                       alpha, weights, d_comp, d_weights=None):
+    n, n_rays = sdf.shape[0], rays_d.shape[0]
+    dev = sdf.device
+    d_sdf = torch.empty(n, dtype=torch.float32, device=dev)
+    d_normal = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    d_rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    d_inv = torch.zeros(1, dtype=torch.float32, device=dev)
+    dw = None if d_weights is None else _f32c(d_weights)
+    check(lib().dsu_neus_composite_bwd(ptr(_f32c(sdf)), ptr(_f32c(normal)), ptr(_f32c(rgb)),
+                                       ptr(_f32c(rays_d)), ptr(_f32c(t_starts)), ptr(_f32c(t_ends)),
+                                       ptr(offsets, torch.int32), ptr(counts, torch.int32), n_rays,
+                                       ptr(inv_s, torch.float32), float(car), ptr(alpha),
+                                       ptr(weights), ptr(_f32c(d_comp)), ptr(dw), ptr(d_sdf),
+                                       ptr(d_normal), ptr(d_rgb), ptr(d_inv), stream()),
+          "dsu_neus_composite_bwd")
+    return d_sdf, d_normal, d_rgb, d_inv

@@ -165,6 +165,35 @@ int dsu_occgrid_ema(float* occs, const int64_t* idx, const float* occ, int64_t n
 int dsu_occgrid_binarize(const float* occs, int64_t n_cells, float thre, uint8_t* binary,
                          void* stream);
 
+/* Fused NeuS shading + compositing of one ray batch (neus.py:90-112 get_alpha, :143-153
+ * render_weight_from_alpha + the four accumulate_along_rays): per sample
+ *   alpha = clip((sigmoid(prev*inv_s) - sigmoid(next*inv_s) + 1e-5) / (sigmoid(prev*inv_s) + 1e-5))
+ * with the cos-anneal of neus.py:97-104, w = alpha * prod_{j<i}(1-alpha_j); per ray
+ * comp[r] = {opacity, depth, rgb(3), sum w*normal (3)}.  sdf (n), normal (n,3), rgb (n,3),
+ * rays_d (n_rays,3) unit directions, t_starts/t_ends (n); alpha/weights (n) are written for
+ * the backward pass.  inv_s: DEVICE pointer to the scalar exp(10*variance) (clipped to
+ * [1e-6,1e6] inside, neus.py:91), so no host synchronisation is needed. */
+int dsu_neus_composite_fwd(const float* sdf, const float* normal, const float* rgb,
+                           const float* rays_d, const float* t_starts, const float* t_ends,
+                           const int32_t* offsets, const int32_t* counts, int64_t n_rays,
+                           const float* inv_s, float cos_anneal_ratio, float* alpha,
+                           float* weights, float* comp, void* stream);
+/* Backward: d_comp (n_rays,8), optional d_weights (n) -> d_sdf (n), d_normal (n,3), d_rgb (n,3);
+ * d_inv_s (1 float, caller zeroes) accumulates the gradient of the variance scalar. */
+int dsu_neus_composite_bwd(const float* sdf, const float* normal, const float* rgb,
+                           const float* rays_d, const float* t_starts, const float* t_ends,
+                           const int32_t* offsets, const int32_t* counts, int64_t n_rays,
+                           const float* inv_s, float cos_anneal_ratio, const float* alpha,
+                           const float* weights, const float* d_comp, const float* d_weights,
+                           float* d_sdf, float* d_normal, float* d_rgb, float* d_inv_s,
+                           void* stream);
+/* normal = F.normalize(sdf_grad) and the texture-MLP input cat(feature, normal) (neus.py:143,
+ * texture.py:22) in one pass; and its backward. */
+int dsu_shade_prep_fwd(const float* grad, const float* feature, int64_t n, float* normal,
+                       float* tex_in, void* stream);
+int dsu_shade_prep_bwd(const float* grad, const float* d_normal, const float* d_tex_in, int64_t n,
+                       float* d_grad, float* d_feature, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Style translator (3_style_translator/training/models.py).
  * ---------------------------------------------------------------------------------- */
