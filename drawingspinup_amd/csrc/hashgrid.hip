@@ -16,86 +16,11 @@
 //             (x*1) ^ (y*2654435761) ^ (z*805459861)   (uint32), both taken mod size_l
 //   feature:  acc = fma((f16)weight, table[index], acc) in binary16 for c = 0..7 (f16 FMA,
 //             one rounding per step), exactly tcnn's half-precision accumulation.
-#include "common.h"
-#include <math.h>
+#include "hashgrid_dev.h"
+
+using namespace dsu_hg;
 
 namespace {
-
-struct GridMeta {
-  uint32_t off[DSU_MAX_LEVELS + 1];
-  uint32_t res[DSU_MAX_LEVELS];
-  float scale[DSU_MAX_LEVELS];
-  uint32_t hashed[DSU_MAX_LEVELS];
-};
-
-constexpr int HID = 64;   // n_neurons (neuralangelo-ortho-wmask.yaml:66)
-constexpr int NOUT = 13;  // feature_dim (yaml:39)
-
-__device__ __forceinline__ uint32_t grid_index(uint32_t hashed, uint32_t hsize, uint32_t res,
-                                               uint32_t x, uint32_t y, uint32_t z) {
-  uint32_t idx;
-  if (hashed) {
-    idx = x ^ (y * 2654435761u) ^ (z * 805459861u);
-    return idx & (hsize - 1);  // hashed levels always have a power-of-two size
-  }
-  idx = x + y * res + z * res * res;
-  if (idx >= hsize) idx %= hsize;
-  return idx;
-}
-
-struct CellPos {
-  uint32_t c[3];
-  float f[3];
-};
-
-__device__ __forceinline__ CellPos cell_of(float scale, float x, float y, float z) {
-  CellPos p;
-  float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
-  float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
-  p.c[0] = (uint32_t)(int)fx;
-  p.c[1] = (uint32_t)(int)fy;
-  p.c[2] = (uint32_t)(int)fz;
-  p.f[0] = px - fx;
-  p.f[1] = py - fy;
-  p.f[2] = pz - fz;
-  return p;
-}
-
-__device__ __forceinline__ float corner_weight(const CellPos& p, int c) {
-  float w = 1.0f;
-  w *= (c & 1) ? p.f[0] : 1.0f - p.f[0];
-  w *= (c & 2) ? p.f[1] : 1.0f - p.f[1];
-  w *= (c & 4) ? p.f[2] : 1.0f - p.f[2];
-  return w;
-}
-
-// One level's trilinear lookup with tcnn's half-precision FMA chain.
-__device__ __forceinline__ __half2 lookup_level(const __half2* __restrict__ table,
-                                                const GridMeta& m, int l, float x, float y,
-                                                float z) {
-  const uint32_t hsize = m.off[l + 1] - m.off[l];
-  const __half2* lvl = table + m.off[l];
-  CellPos p = cell_of(m.scale[l], x, y, z);
-  uint32_t idx[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c)
-    idx[c] = grid_index(m.hashed[l], hsize, m.res[l], p.c[0] + (c & 1), p.c[1] + ((c >> 1) & 1),
-                        p.c[2] + ((c >> 2) & 1));
-  __half2 v[8];
-#pragma unroll
-  for (int c = 0; c < 8; ++c) v[c] = lvl[idx[c]];  // 8 independent 4-byte gathers in flight
-  __half2 acc = __float2half2_rn(0.0f);
-#pragma unroll
-  for (int c = 0; c < 8; ++c) {
-    float wf = corner_weight(p, c);
-    // keep the f32 product rounded to f32 BEFORE the f16 conversion (tcnn: (T)weight); without
-    // this the compiler folds mul+cvt into one v_fma_mixlo_f16 with a single rounding.
-    asm volatile("" : "+v"(wf));
-    __half w = __float2half_rn(wf);
-    acc = __hfma2(__half2(w, w), v[c], acc);
-  }
-  return acc;
-}
 
 // ---------------------------------------------------------------- plain encode (tcnn shim)
 template <int NL>
@@ -174,16 +99,6 @@ __device__ __forceinline__ void load_mlp_to_lds(float* lds, const float* __restr
   __syncthreads();
 }
 
-__device__ __forceinline__ float softplus100(float x) {
-  // nn.Softplus(beta=100, threshold=20)  (network_utils.py:134-136)
-  float bx = x * 100.0f;
-  return bx > 20.0f ? x : log1pf(expf(bx)) / 100.0f;
-}
-__device__ __forceinline__ float softplus100_grad(float x) {
-  float bx = x * 100.0f;
-  return bx > 20.0f ? 1.0f : 1.0f / (1.0f + expf(-bx));
-}
-
 // Encode one contracted point into the MLP input vector (xyz*2-1, masked features).
 template <int NL>
 __device__ __forceinline__ void encode_input(const __half2* __restrict__ table,
@@ -245,12 +160,6 @@ __device__ __forceinline__ float layer1_row(const float* lds, const float* h, in
     acc = fmaf(w.w, h[4 * j4 + 3], acc);
   }
   return acc;
-}
-
-__device__ __forceinline__ float contract(float p, float radius) {
-  // scale_anything(x, (-r, r), (0, 1))  (instant_nsr/models/utils.py:101-106)
-  float d = (p - (-radius)) / (radius - (-radius));
-  return d * (1.0f - 0.0f) + 0.0f;
 }
 
 template <int NL, int NO>
@@ -336,28 +245,6 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
       laplace[i] = ((t0 + t1) + t2) / eps2;
     }
   }
-}
-
-constexpr int GC_LOG2 = 12;
-constexpr int GC_SLOTS = 1 << GC_LOG2;
-constexpr uint32_t GC_EMPTY = 0xFFFFFFFFu;
-
-__device__ __forceinline__ void grad_cache_add(uint32_t* keys, float* vals,
-                                               float* __restrict__ gtable, uint32_t entry,
-                                               float v0, float v1) {
-  uint32_t slot = (entry * 2654435761u) >> (32 - GC_LOG2);
-#pragma unroll
-  for (int probe = 0; probe < 3; ++probe) {
-    const uint32_t old = atomicCAS(&keys[slot], GC_EMPTY, entry);
-    if (old == GC_EMPTY || old == entry) {
-      atomicAdd(&vals[2 * slot], v0);       // ds_add_f32
-      atomicAdd(&vals[2 * slot + 1], v1);
-      return;
-    }
-    slot = (slot + 1) & (GC_SLOTS - 1);
-  }
-  unsafeAtomicAdd(gtable + (size_t)entry * 2, v0);
-  unsafeAtomicAdd(gtable + (size_t)entry * 2 + 1, v1);
 }
 
 // LDS carve-up of the backward kernel (floats): MLP image | 4 per-wave staging areas | cache
@@ -666,6 +553,14 @@ __global__ void reduce_partials_kernel(const float* __restrict__ partials, int n
   else g_b1[i - P::B1] += s;
 }
 
+template <int NL>
+size_t bwd_lds_bytes() {
+  return (size_t)BwdLds<NL>::TOTAL * sizeof(float);
+}
+
+}  // namespace
+
+namespace dsu_hg {
 int make_meta(const dsu_hashgrid_cfg* cfg, GridMeta* m) {
   dsu_hashgrid_levels lv;
   int rc = dsu_hashgrid_make_levels(cfg, &lv);
@@ -678,13 +573,7 @@ int make_meta(const dsu_hashgrid_cfg* cfg, GridMeta* m) {
   }
   return DSU_OK;
 }
-
-template <int NL>
-size_t bwd_lds_bytes() {
-  return (size_t)BwdLds<NL>::TOTAL * sizeof(float);
-}
-
-}  // namespace
+}  // namespace dsu_hg
 
 #define DSU_DISPATCH_NL(nl, ...)          \
   switch (nl) {                            \
@@ -756,7 +645,7 @@ int dsu_hashgrid_encode_bwd(const dsu_hashgrid_cfg* cfg, const float* x, const f
   return DSU_OK;
 }
 
-int dsu_sdf_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+int dsu_sdf_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
                 const float* pts, int64_t n, float radius, uint32_t active_levels,
                 uint32_t n_out, float* out, void* stream) {
   if (!cfg || !table_f16 || !mlp || (!pts && n) || (!out && n) || n < 0) return DSU_EINVAL;
@@ -782,7 +671,7 @@ int dsu_sdf_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sd
   return DSU_OK;
 }
 
-int dsu_sdf_fd_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
                    const float* pts, int64_t n, float radius, float eps,
                    uint32_t active_levels, float* sdf, float* grad, float* feature,
                    float* laplace, void* stream) {
@@ -808,7 +697,7 @@ int dsu_sdf_fd_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu
 
 constexpr int BWD_MAX_BLOCKS = 768;
 
-int64_t dsu_sdf_fd_bwd_workspace_bytes(const dsu_hashgrid_cfg* cfg, int64_t n) {
+int64_t dsu_sdf_fd_bwd_workspace_bytes_valu(const dsu_hashgrid_cfg* cfg, int64_t n) {
   if (!cfg || n < 0) return DSU_EINVAL;
   const int blocks = dsu_capped_blocks(n, 256, BWD_MAX_BLOCKS);
   switch (cfg->n_levels) {
@@ -818,7 +707,7 @@ int64_t dsu_sdf_fd_bwd_workspace_bytes(const dsu_hashgrid_cfg* cfg, int64_t n) {
   }
 }
 
-int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+int dsu_sdf_fd_bwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
                    const float* pts, int64_t n, float radius, float eps,
                    uint32_t active_levels, const float* d_sdf, const float* d_grad,
                    const float* d_feature, const float* d_laplace, float* grad_table,
@@ -832,7 +721,7 @@ int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu
   int rc = make_meta(cfg, &m);
   if (rc) return rc;
   if (n == 0) return DSU_OK;
-  const int64_t need = dsu_sdf_fd_bwd_workspace_bytes(cfg, n);
+  const int64_t need = dsu_sdf_fd_bwd_workspace_bytes_valu(cfg, n);
   if (need < 0) return (int)need;
   if (!workspace || workspace_bytes < need) return DSU_EINVAL;
   hipStream_t s = (hipStream_t)stream;

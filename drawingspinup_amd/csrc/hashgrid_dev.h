@@ -1,0 +1,128 @@
+// Device helpers shared by the hash-grid kernels (hashgrid.hip, hashgrid_mfma.hip).
+// See hashgrid.hip for the arithmetic contract.
+#pragma once
+#include "common.h"
+#include <math.h>
+
+namespace dsu_hg {
+
+struct GridMeta {
+  uint32_t off[DSU_MAX_LEVELS + 1];
+  uint32_t res[DSU_MAX_LEVELS];
+  float scale[DSU_MAX_LEVELS];
+  uint32_t hashed[DSU_MAX_LEVELS];
+};
+
+constexpr int HID = 64;   // n_neurons (neuralangelo-ortho-wmask.yaml:66)
+constexpr int NOUT = 13;  // feature_dim (yaml:39)
+
+__device__ __forceinline__ uint32_t grid_index(uint32_t hashed, uint32_t hsize, uint32_t res,
+                                               uint32_t x, uint32_t y, uint32_t z) {
+  uint32_t idx;
+  if (hashed) {
+    idx = x ^ (y * 2654435761u) ^ (z * 805459861u);
+    return idx & (hsize - 1);  // hashed levels always have a power-of-two size
+  }
+  idx = x + y * res + z * res * res;
+  if (idx >= hsize) idx %= hsize;
+  return idx;
+}
+
+struct CellPos {
+  uint32_t c[3];
+  float f[3];
+};
+
+__device__ __forceinline__ CellPos cell_of(float scale, float x, float y, float z) {
+  CellPos p;
+  float px = fmaf(scale, x, 0.5f), py = fmaf(scale, y, 0.5f), pz = fmaf(scale, z, 0.5f);
+  float fx = floorf(px), fy = floorf(py), fz = floorf(pz);
+  p.c[0] = (uint32_t)(int)fx;
+  p.c[1] = (uint32_t)(int)fy;
+  p.c[2] = (uint32_t)(int)fz;
+  p.f[0] = px - fx;
+  p.f[1] = py - fy;
+  p.f[2] = pz - fz;
+  return p;
+}
+
+__device__ __forceinline__ float corner_weight(const CellPos& p, int c) {
+  float w = 1.0f;
+  w *= (c & 1) ? p.f[0] : 1.0f - p.f[0];
+  w *= (c & 2) ? p.f[1] : 1.0f - p.f[1];
+  w *= (c & 4) ? p.f[2] : 1.0f - p.f[2];
+  return w;
+}
+
+// One level's trilinear lookup with tcnn's half-precision FMA chain.
+__device__ __forceinline__ __half2 lookup_level(const __half2* __restrict__ table,
+                                                const GridMeta& m, int l, float x, float y,
+                                                float z) {
+  const uint32_t hsize = m.off[l + 1] - m.off[l];
+  const __half2* lvl = table + m.off[l];
+  CellPos p = cell_of(m.scale[l], x, y, z);
+  uint32_t idx[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    idx[c] = grid_index(m.hashed[l], hsize, m.res[l], p.c[0] + (c & 1), p.c[1] + ((c >> 1) & 1),
+                        p.c[2] + ((c >> 2) & 1));
+  __half2 v[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) v[c] = lvl[idx[c]];  // 8 independent 4-byte gathers in flight
+  __half2 acc = __float2half2_rn(0.0f);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float wf = corner_weight(p, c);
+    // keep the f32 product rounded to f32 BEFORE the f16 conversion (tcnn: (T)weight); without
+    // this the compiler folds mul+cvt into one v_fma_mixlo_f16 with a single rounding.
+    asm volatile("" : "+v"(wf));
+    __half w = __float2half_rn(wf);
+    acc = __hfma2(__half2(w, w), v[c], acc);
+  }
+  return acc;
+}
+
+__device__ __forceinline__ float softplus100(float x) {
+  // nn.Softplus(beta=100, threshold=20)  (network_utils.py:134-136)
+  // evaluated as max(x,0) + log(1 + exp(-|100x|))/100 on the hardware exp/log units
+  // (v_exp_f32 / v_log_f32): |error| <= ~1e-9 absolute, versus ~100 VALU instructions for
+  // libm log1pf(expf()) — 64 of these per network evaluation dominated the kernel otherwise
+  float bx = x * 100.0f;
+  return bx > 20.0f ? x : fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(bx))) * 0.01f;
+}
+__device__ __forceinline__ float softplus100_grad(float x) {
+  float bx = x * 100.0f;
+  return bx > 20.0f ? 1.0f : __frcp_rn(1.0f + __expf(-bx));
+}
+
+__device__ __forceinline__ float contract(float p, float radius) {
+  // scale_anything(x, (-r, r), (0, 1))  (instant_nsr/models/utils.py:101-106)
+  float d = (p - (-radius)) / (radius - (-radius));
+  return d * (1.0f - 0.0f) + 0.0f;
+}
+
+constexpr int GC_LOG2 = 12;
+constexpr int GC_SLOTS = 1 << GC_LOG2;
+constexpr uint32_t GC_EMPTY = 0xFFFFFFFFu;
+
+__device__ __forceinline__ void grad_cache_add(uint32_t* keys, float* vals,
+                                               float* __restrict__ gtable, uint32_t entry,
+                                               float v0, float v1) {
+  uint32_t slot = (entry * 2654435761u) >> (32 - GC_LOG2);
+#pragma unroll
+  for (int probe = 0; probe < 3; ++probe) {
+    const uint32_t old = atomicCAS(&keys[slot], GC_EMPTY, entry);
+    if (old == GC_EMPTY || old == entry) {
+      atomicAdd(&vals[2 * slot], v0);       // ds_add_f32
+      atomicAdd(&vals[2 * slot + 1], v1);
+      return;
+    }
+    slot = (slot + 1) & (GC_SLOTS - 1);
+  }
+  unsafeAtomicAdd(gtable + (size_t)entry * 2, v0);
+  unsafeAtomicAdd(gtable + (size_t)entry * 2 + 1, v1);
+}
+
+int make_meta(const dsu_hashgrid_cfg* cfg, GridMeta* m);
+
+}  // namespace dsu_hg

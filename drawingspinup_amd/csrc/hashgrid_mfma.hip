@@ -1,0 +1,721 @@
+// Fused hash-grid + SDF-MLP kernels, MFMA formulation (gfx950, v_mfma_f32_32x32x2_f32).
+//
+// Same arithmetic contract and C entry points as the VALU kernels in hashgrid.hip (which stay
+// selectable with DSU_SDF_IMPL=valu for A/B runs); what changes is WHERE the 23->64->13 MLP
+// and its backward run: on the matrix pipe, in exact f32 (the f32 MFMA is bit-for-bit an fmaf
+// chain), with the activations never leaving registers between layers.
+//
+// One wave = 64 points, one point per lane for the hash-grid gathers.  Layer 0 is
+//     Pre^T[64 hidden x 64 points] = W0'[64 x K] . In'^T[K x 64 points]
+// as 2 (hidden tiles) x 2 (point halves) 32x32 MFMA tiles; In' is the MLP input re-ordered
+// {features | xyz | 1} so that the bias is a weight column and the two features of a level sit
+// in one accumulator quad.  The B operand of the 32x32x2 MFMA wants In'[point][2t] from lanes
+// 0-31 and In'[point][2t+1] from lanes 32-63: ONE v_permlane32_swap per k-pair turns the
+// point-per-lane registers into the operands of both point halves.  The accumulator layout
+// (lane = point, register quad = 4 consecutive hidden units, lane>>5 selects the quad's half)
+// is fed straight back as the B operand of the backward GEMM dIn^T = W0'^T . dPre^T by
+// permuting the weight rows instead of the data.  Only the parameter-gradient GEMMs
+// (contraction over points = lanes) go through LDS, 32 points at a time.
+#include "hashgrid_dev.h"
+
+#include <stdlib.h>
+#include <string.h>
+
+using namespace dsu_hg;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int NL>
+struct MC {
+  static constexpr int DIN = 3 + 2 * NL;   // reference input width (xyz first)
+  static constexpr int KIN = 2 * NL + 4;   // permuted input: features | xyz | bias-one
+  static constexpr int KP = KIN / 2;       // k-pairs of the 32x32x2 MFMA
+};
+
+// column of the reference W0 (row-major (64, DIN)) that permuted input k multiplies; -1 = bias
+template <int NL>
+__device__ __host__ constexpr int ref_col(int k) {
+  return k < 2 * NL ? 3 + k : (k < 2 * NL + 3 ? k - 2 * NL : -1);
+}
+
+// hidden unit held by accumulator register r of hidden tile T in a lane of half h = lane>>5
+__device__ __forceinline__ int feat_of(int T, int r, int h) {
+  return 32 * T + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+
+// a' = {lanes 0-31: a ; lanes 32-63: b of lane-32}   b' = {lanes 0-31: a of lane+32 ; 32-63: b}
+__device__ __forceinline__ void swap_halves(float a, float b, float& o0, float& o1) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  o0 = __uint_as_float(r[0]);
+  o1 = __uint_as_float(r[1]);
+}
+
+template <int NL>
+struct Frags {
+  float w0[2][MC<NL>::KP];   // A operand of layer 0: W0'[32T + (lane&31)][2t + (lane>>5)]
+  float w1o0[2][16];         // W1[0][feat_of(T, r, h)]
+  float b1o0;
+};
+
+template <int NL>
+__device__ __forceinline__ float w0p(const dsu_sdf_mlp& m, int feat, int k) {
+  const int c = ref_col<NL>(k);
+  return c >= 0 ? m.w0[feat * MC<NL>::DIN + c] : m.b0[feat];
+}
+
+template <int NL>
+__device__ __forceinline__ void load_frags(const dsu_sdf_mlp& m, Frags<NL>& f, int lane) {
+  const int l31 = lane & 31, h = lane >> 5;
+#pragma unroll
+  for (int T = 0; T < 2; ++T) {
+#pragma unroll
+    for (int t = 0; t < MC<NL>::KP; ++t) f.w0[T][t] = w0p<NL>(m, 32 * T + l31, 2 * t + h);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) f.w1o0[T][r] = m.w1[feat_of(T, r, h)];
+  }
+  f.b1o0 = m.b1[0];
+}
+
+// MLP input of one contracted point in the permuted order
+template <int NL>
+__device__ __forceinline__ void encode_input_p(const __half2* __restrict__ table,
+                                               const GridMeta& m, uint32_t active, float x,
+                                               float y, float z, float* in /*KIN*/) {
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    float2 f = make_float2(0.0f, 0.0f);
+    if ((uint32_t)l < active) f = __half22float2(lookup_level(table, m, l, x, y, z));
+    in[2 * l] = f.x;
+    in[2 * l + 1] = f.y;
+  }
+  in[2 * NL + 0] = x * 2.0f + -1.0f;
+  in[2 * NL + 1] = y * 2.0f + -1.0f;
+  in[2 * NL + 2] = z * 2.0f + -1.0f;
+  in[2 * NL + 3] = 1.0f;
+}
+
+// acc[half][T]: hidden pre-activations; then softplus in place.
+template <int NL>
+__device__ __forceinline__ void layer0_mfma(const Frags<NL>& f, const float* in, uint32_t active,
+                                            f32x16 (&acc)[2][2]) {
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][T][r] = 0.0f;
+#pragma unroll
+  for (int t = 0; t < MC<NL>::KP; ++t) {
+    if (t < NL && (uint32_t)t >= active) continue;   // masked level: both inputs are zero
+    float b0, b1;
+    swap_halves(in[2 * t], in[2 * t + 1], b0, b1);
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+      acc[0][T] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w0[T][t], b0, acc[0][T], 0, 0, 0);
+      acc[1][T] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w0[T][t], b1, acc[1][T], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][T][r] = softplus100(acc[a][T][r]);
+}
+
+// out[0] of the lane's OWN point from the hidden activations spread over lane and lane^32
+template <int NL>
+__device__ __forceinline__ float layer1_o0(const Frags<NL>& f, const f32x16 (&H)[2][2], int h) {
+  float p0 = 0.0f, p1 = 0.0f;
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      p0 = fmaf(f.w1o0[T][r], H[0][T][r], p0);
+      p1 = fmaf(f.w1o0[T][r], H[1][T][r], p1);
+    }
+  const float send = h == 0 ? p1 : p0;
+  const float recv = __shfl_xor(send, 32);
+  return (h == 0 ? p0 : p1) + recv + f.b1o0;
+}
+
+// outputs 1..12 (the centre evaluation's feature vector); W1 rows permuted in LDS:
+// w1perm[h][o][T*16 + r] = W1[o][feat_of(T, r, h)]
+__device__ __forceinline__ void layer1_rest(const float* w1perm, const float* b1s,
+                                            const f32x16 (&H)[2][2], int h, float* out /*13*/) {
+  const float* wp = w1perm + h * NOUT * 32;
+#pragma unroll 1
+  for (int o = 1; o < NOUT; ++o) {
+    float p0 = 0.0f, p1 = 0.0f;
+    const float4* w4 = reinterpret_cast<const float4*>(wp + o * 32);
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 w = w4[T * 4 + q];
+        p0 = fmaf(w.x, H[0][T][4 * q + 0], p0); p1 = fmaf(w.x, H[1][T][4 * q + 0], p1);
+        p0 = fmaf(w.y, H[0][T][4 * q + 1], p0); p1 = fmaf(w.y, H[1][T][4 * q + 1], p1);
+        p0 = fmaf(w.z, H[0][T][4 * q + 2], p0); p1 = fmaf(w.z, H[1][T][4 * q + 2], p1);
+        p0 = fmaf(w.w, H[0][T][4 * q + 3], p0); p1 = fmaf(w.w, H[1][T][4 * q + 3], p1);
+      }
+    const float send = h == 0 ? p1 : p0;
+    const float recv = __shfl_xor(send, 32);
+    out[o] = (h == 0 ? p0 : p1) + recv + b1s[o];
+  }
+}
+
+__device__ __forceinline__ void load_w1perm(float* w1perm, float* b1s, const dsu_sdf_mlp& m) {
+  for (int i = threadIdx.x; i < 2 * NOUT * 32; i += blockDim.x) {
+    const int h = i / (NOUT * 32), o = (i / 32) % NOUT, tr = i % 32;
+    w1perm[i] = m.w1[o * HID + feat_of(tr >> 4, tr & 15, h)];
+  }
+  for (int i = threadIdx.x; i < 16; i += blockDim.x) b1s[i] = i < NOUT ? m.b1[i] : 0.0f;
+}
+
+__device__ __forceinline__ void fd_point(const float p[3], int e, float eps, float radius,
+                                         float q[3]) {
+  q[0] = p[0]; q[1] = p[1]; q[2] = p[2];
+  if (e > 0) {
+    const int ax = (e - 1) >> 1;
+    const float d = ((e - 1) & 1) ? -eps : eps;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const float v = q[a] + (a == ax ? d : 0.0f);
+      q[a] = fminf(fmaxf(v, -radius), radius);      // (points_ + offsets).clamp  (geometry.py:170)
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- forward
+template <int NL, int NO>
+__global__ __launch_bounds__(256) void sdf_fwd_mfma_kernel(const __half2* __restrict__ table,
+                                                           GridMeta m, dsu_sdf_mlp mlp,
+                                                           const float* __restrict__ pts,
+                                                           int64_t n, float radius,
+                                                           uint32_t active,
+                                                           float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float w1perm[2 * NOUT * 32];
+  __shared__ float b1s[16];
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  Frags<NL> fr;
+  load_frags<NL>(mlp, fr, lane);
+  if (NO > 1) {
+    load_w1perm(w1perm, b1s, mlp);
+    __syncthreads();
+  }
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t base = blockIdx.x * (int64_t)blockDim.x; base < n; base += stride) {
+    const int64_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    const int64_t ii = valid ? i : n - 1;
+    float in[MC<NL>::KIN];
+    encode_input_p<NL>(table, m, active, contract(pts[ii * 3], radius),
+                       contract(pts[ii * 3 + 1], radius), contract(pts[ii * 3 + 2], radius), in);
+    f32x16 H[2][2];
+    layer0_mfma<NL>(fr, in, active, H);
+    float o[NOUT];
+    o[0] = layer1_o0<NL>(fr, H, h);
+    if (NO > 1) layer1_rest(w1perm, b1s, H, h, o);
+    if (valid) {
+#pragma unroll
+      for (int k = 0; k < NO; ++k) out[i * NO + k] = o[k];
+    }
+  }
+}
+
+template <int NL>
+__global__ __launch_bounds__(256) void sdf_fd_fwd_mfma_kernel(
+    const __half2* __restrict__ table, GridMeta m, dsu_sdf_mlp mlp,
+    const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
+    uint32_t active, float* __restrict__ sdf, float* __restrict__ grad,
+    float* __restrict__ feature, float* __restrict__ laplace) {
+  __shared__ __attribute__((aligned(16))) float w1perm[2 * NOUT * 32];
+  __shared__ float b1s[16];
+  const int lane = threadIdx.x & 63, h = lane >> 5;
+  Frags<NL> fr;
+  load_frags<NL>(mlp, fr, lane);
+  load_w1perm(w1perm, b1s, mlp);
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t base = blockIdx.x * (int64_t)blockDim.x; base < n; base += stride) {
+    const int64_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    const int64_t ii = valid ? i : n - 1;
+    const float p[3] = {pts[ii * 3], pts[ii * 3 + 1], pts[ii * 3 + 2]};
+    float s[7];
+#pragma unroll 1
+    for (int e = 0; e < 7; ++e) {
+      float q[3];
+      fd_point(p, e, eps, radius, q);
+      float in[MC<NL>::KIN];
+      encode_input_p<NL>(table, m, active, contract(q[0], radius), contract(q[1], radius),
+                         contract(q[2], radius), in);
+      f32x16 H[2][2];
+      layer0_mfma<NL>(fr, in, active, H);
+      s[e] = layer1_o0<NL>(fr, H, h);
+      if (e == 0 && feature != nullptr) {
+        float o[NOUT];
+        o[0] = s[0];
+        layer1_rest(w1perm, b1s, H, h, o);
+        if (valid) {
+#pragma unroll
+          for (int k = 0; k < NOUT; ++k) feature[i * NOUT + k] = o[k];
+        }
+      }
+    }
+    if (valid) {
+      sdf[i] = s[0];
+      if (grad != nullptr) {
+        grad[i * 3 + 0] = 0.5f * (s[1] - s[2]) / eps;
+        grad[i * 3 + 1] = 0.5f * (s[3] - s[4]) / eps;
+        grad[i * 3 + 2] = 0.5f * (s[5] - s[6]) / eps;
+      }
+      if (laplace != nullptr) {
+        const float t0 = s[1] + s[2] - 2.0f * s[0];
+        const float t1 = s[3] + s[4] - 2.0f * s[0];
+        const float t2 = s[5] + s[6] - 2.0f * s[0];
+        laplace[i] = ((t0 + t1) + t2) / eps2;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------- backward
+// LDS (floats): w1perm | b1s | 4 x per-wave staging {sd[32][68], sin[32][36], sdo[32][36]} | cache
+constexpr int SD_ROW = 68, SIN_ROW = 36;
+constexpr int STAGE_F = 32 * SD_ROW + 2 * 32 * SIN_ROW;   // 4480 floats per wave
+constexpr int W1P_F = 2 * NOUT * 32 + 16;
+constexpr int BWD_CACHE_OFF = W1P_F + 4 * STAGE_F;
+constexpr int BWD_LDS_F = BWD_CACHE_OFF + 3 * GC_SLOTS;
+// per-workgroup partial vector: gw0p[64 feat][32 k'] | gw1p[64 feat][32 o'] | gb1[16]
+constexpr int PART_GW0 = 0, PART_GW1 = 64 * 32, PART_GB1 = 2 * 64 * 32;
+constexpr int PART_STRIDE = 2 * 64 * 32 + 64;
+
+template <int NL>
+__global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
+    const __half2* __restrict__ table, GridMeta m, dsu_sdf_mlp mlp,
+    const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
+    uint32_t active, const float* __restrict__ d_sdf, const float* __restrict__ d_grad,
+    const float* __restrict__ d_feature, const float* __restrict__ d_laplace,
+    float* __restrict__ gtable, float* __restrict__ partials) {
+  constexpr int KIN = MC<NL>::KIN;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* w1perm = lds;
+  float* b1s = lds + 2 * NOUT * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  float* sd = lds + W1P_F + wave * STAGE_F;
+  float* sin_ = sd + 32 * SD_ROW;
+  float* sdo = sin_ + 32 * SIN_ROW;
+  uint32_t* c_keys = reinterpret_cast<uint32_t*>(lds + BWD_CACHE_OFF);
+  float* c_vals = lds + BWD_CACHE_OFF + GC_SLOTS;
+
+  Frags<NL> fr;
+  load_frags<NL>(mlp, fr, lane);
+  // A operand of dIn^T = W0'^T . dPre^T : W0'[feat_of(T, r, h)][k = lane & 31]
+  float w0t[2][16];
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      w0t[T][r] = l31 < KIN ? w0p<NL>(mlp, feat_of(T, r, h), l31) : 0.0f;
+  load_w1perm(w1perm, b1s, mlp);
+  for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
+    c_keys[t] = GC_EMPTY;
+    c_vals[2 * t] = 0.0f;
+    c_vals[2 * t + 1] = 0.0f;
+  }
+  __syncthreads();
+
+  f32x16 gw0[2], gw1[2];   // [feat tile]: D[i = feat][j = k' or o']
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gw0[T][r] = gw1[T][r] = 0.0f;
+  float gb1[NOUT];
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) gb1[o] = 0.0f;
+
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t bbase = blockIdx.x * (int64_t)blockDim.x; bbase < n; bbase += stride) {
+    const int64_t i = bbase + threadIdx.x;
+    const bool valid = i < n;
+    const int64_t ii = valid ? i : n - 1;
+    const float p[3] = {pts[ii * 3], pts[ii * 3 + 1], pts[ii * 3 + 2]};
+    float ds = 0.f, dl = 0.f, dg[3] = {0.f, 0.f, 0.f};
+    if (valid) {
+      if (d_sdf) ds = d_sdf[i];
+      if (d_laplace) dl = d_laplace[i];
+      if (d_grad) { dg[0] = d_grad[i * 3]; dg[1] = d_grad[i * 3 + 1]; dg[2] = d_grad[i * 3 + 2]; }
+    }
+#pragma unroll 1
+    for (int e = 0; e < 7; ++e) {
+      float q[3];
+      fd_point(p, e, eps, radius, q);
+      const float cx = contract(q[0], radius), cy = contract(q[1], radius),
+                  cz = contract(q[2], radius);
+      float in[KIN];
+      encode_input_p<NL>(table, m, active, cx, cy, cz, in);
+      f32x16 H[2][2];
+      layer0_mfma<NL>(fr, in, active, H);
+      // upstream gradient on this evaluation's outputs (own point)
+      float dout[NOUT];
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) dout[o] = 0.0f;
+      if (valid) {
+        if (e == 0) {
+          if (d_feature) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) dout[o] = d_feature[i * NOUT + o];
+          }
+          dout[0] += ds - 6.0f * dl / eps2;
+        } else {
+          const int ax = (e - 1) >> 1;
+          const float sgn = ((e - 1) & 1) ? -1.0f : 1.0f;
+          dout[0] = sgn * 0.5f * dg[ax] / eps + dl / eps2;
+        }
+      }
+      const int no = e == 0 ? NOUT : 1;
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o)
+        if (o < no) gb1[o] += dout[o];
+      // partner's position (for the scatter of the other point half)
+      const float pcx = __shfl_xor(cx, 32), pcy = __shfl_xor(cy, 32), pcz = __shfl_xor(cz, 32);
+
+#pragma unroll 1
+      for (int half = 0; half < 2; ++half) {
+        // gradient on the outputs of the points of this half: own if this lane owns the half
+        float d[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+          float other = 0.0f;
+          if (o < no) other = __shfl_xor(dout[o], 32);
+          d[o] = (h == half) ? dout[o] : other;
+        }
+        const f32x16(&Hh)[2] = H[half];
+        f32x16 din;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) din[r] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+          float dpre[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dpre[r] = fr.w1o0[T][r] * d[0];
+          if (e == 0) {
+            const float* wp = w1perm + h * NOUT * 32 + T * 16;
+#pragma unroll 1
+            for (int o = 1; o < NOUT; ++o) {
+              const float4* w4 = reinterpret_cast<const float4*>(wp + o * 32);
+              const float dv = d[o];
+#pragma unroll
+              for (int qd = 0; qd < 4; ++qd) {
+                const float4 w = w4[qd];
+                dpre[4 * qd + 0] = fmaf(w.x, dv, dpre[4 * qd + 0]);
+                dpre[4 * qd + 1] = fmaf(w.y, dv, dpre[4 * qd + 1]);
+                dpre[4 * qd + 2] = fmaf(w.z, dv, dpre[4 * qd + 2]);
+                dpre[4 * qd + 3] = fmaf(w.w, dv, dpre[4 * qd + 3]);
+              }
+            }
+          }
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            // softplus'(pre) = sigmoid(100 pre) = 1 - exp(-100 softplus(pre))
+            dpre[r] *= 1.0f - __expf(-100.0f * Hh[T][r]);
+            din = __builtin_amdgcn_mfma_f32_32x32x2f32(w0t[T][r], dpre[r], din, 0, 0, 0);
+          }
+          // dPre of this half's points -> LDS rows [point][hidden] for the W0 gradient GEMM
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd)
+            *reinterpret_cast<float4*>(&sd[l31 * SD_ROW + 32 * T + 8 * qd + 4 * h]) =
+                make_float4(dpre[4 * qd], dpre[4 * qd + 1], dpre[4 * qd + 2], dpre[4 * qd + 3]);
+        }
+        if (h == half) {
+#pragma unroll
+          for (int k4 = 0; k4 < 8; ++k4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * k4 + 0 < KIN) v.x = in[(4 * k4 + 0) < KIN ? 4 * k4 + 0 : 0];
+            if (4 * k4 + 1 < KIN) v.y = in[(4 * k4 + 1) < KIN ? 4 * k4 + 1 : 0];
+            if (4 * k4 + 2 < KIN) v.z = in[(4 * k4 + 2) < KIN ? 4 * k4 + 2 : 0];
+            if (4 * k4 + 3 < KIN) v.w = in[(4 * k4 + 3) < KIN ? 4 * k4 + 3 : 0];
+            *reinterpret_cast<float4*>(&sin_[l31 * SIN_ROW + 4 * k4]) = v;
+          }
+#pragma unroll
+          for (int o4 = 0; o4 < 8; ++o4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * o4 + 0 < NOUT) v.x = dout[(4 * o4 + 0) < NOUT ? 4 * o4 + 0 : 0];
+            if (4 * o4 + 1 < NOUT) v.y = dout[(4 * o4 + 1) < NOUT ? 4 * o4 + 1 : 0];
+            if (4 * o4 + 2 < NOUT) v.z = dout[(4 * o4 + 2) < NOUT ? 4 * o4 + 2 : 0];
+            if (4 * o4 + 3 < NOUT) v.w = dout[(4 * o4 + 3) < NOUT ? 4 * o4 + 3 : 0];
+            *reinterpret_cast<float4*>(&sdo[l31 * SIN_ROW + 4 * o4]) = v;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // gW0[feat][k'] += sum_points dPre[point][feat] * In'[point][k']
+#pragma unroll 4
+        for (int t = 0; t < 16; ++t) {
+          const int pr = 2 * t + h;
+          const float b = sin_[pr * SIN_ROW + l31];
+          gw0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + l31], b, gw0[0], 0, 0, 0);
+          gw0[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + 32 + l31], b, gw0[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // hidden activations of this half's points -> LDS, then gW1[feat][o'] += H^T . dOut
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+          for (int qd = 0; qd < 4; ++qd)
+            *reinterpret_cast<float4*>(&sd[l31 * SD_ROW + 32 * T + 8 * qd + 4 * h]) =
+                make_float4(Hh[T][4 * qd], Hh[T][4 * qd + 1], Hh[T][4 * qd + 2], Hh[T][4 * qd + 3]);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+        for (int t = 0; t < 16; ++t) {
+          const int pr = 2 * t + h;
+          const float b = sdo[pr * SIN_ROW + l31];
+          gw1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + l31], b, gw1[0], 0, 0, 0);
+          gw1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + 32 + l31], b, gw1[1], 0, 0, 0);
+        }
+        // scatter dIn rows held by this lane: input row i = (r&3) + 8(r>>2) + 4h, levels (i>>1)
+        {
+          const bool own = h == half;
+          const float sx = own ? cx : pcx, sy = own ? cy : pcy, sz = own ? cz : pcz;
+          const bool pv = __shfl(valid ? 1 : 0, half * 32 + l31) != 0;
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const int lev = ((r & 3) + 8 * (r >> 2)) / 2 + 2 * h;   // compile-time part + lane half
+            if (lev < NL && (uint32_t)lev < active) {
+              const float d0 = din[r], d1 = din[r + 1];
+              if (pv && (d0 != 0.0f || d1 != 0.0f)) {
+                const uint32_t hsize = m.off[lev + 1] - m.off[lev];
+                const CellPos cp = cell_of(m.scale[lev], sx, sy, sz);
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                  const uint32_t idx =
+                      grid_index(m.hashed[lev], hsize, m.res[lev], cp.c[0] + (c & 1),
+                                 cp.c[1] + ((c >> 1) & 1), cp.c[2] + ((c >> 2) & 1));
+                  const float w = corner_weight(cp, c);
+                  grad_cache_add(c_keys, c_vals, gtable, m.off[lev] + idx, w * d0, w * d1);
+                }
+              }
+            }
+          }
+        }
+      }
+    }
+    // flush the gradient cache: one global atomic pair per touched entry, then reset
+    __syncthreads();
+    for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
+      const uint32_t key = c_keys[t];
+      if (key != GC_EMPTY) {
+        unsafeAtomicAdd(gtable + (size_t)key * 2, c_vals[2 * t]);
+        unsafeAtomicAdd(gtable + (size_t)key * 2 + 1, c_vals[2 * t + 1]);
+        c_keys[t] = GC_EMPTY;
+        c_vals[2 * t] = 0.0f;
+        c_vals[2 * t + 1] = 0.0f;
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- workgroup reduction of the parameter-gradient tiles -> one partial vector per workgroup
+  __syncthreads();
+  float* red = lds + W1P_F;                     // [4 waves][PART_STRIDE] (fits: 4*4160 floats)
+  {
+    float* r0 = red + wave * PART_STRIDE;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int feat = feat_of(T, r, h);
+        r0[PART_GW0 + feat * 32 + l31] = gw0[T][r];
+        r0[PART_GW1 + feat * 32 + l31] = gw1[T][r];
+      }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) gb1[o] += __shfl_xor(gb1[o], 32);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1)
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) gb1[o] += __shfl_xor(gb1[o], off);
+    if (lane == 0) {
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) r0[PART_GB1 + o] = gb1[o];
+    }
+  }
+  __syncthreads();
+  float* part = partials + (size_t)blockIdx.x * PART_STRIDE;
+  for (int v = threadIdx.x; v < PART_GB1 + NOUT; v += blockDim.x)
+    part[v] = (red[v] + red[PART_STRIDE + v]) + (red[2 * PART_STRIDE + v] + red[3 * PART_STRIDE + v]);
+}
+
+template <int NL>
+__global__ void reduce_partials_mfma_kernel(const float* __restrict__ partials, int nblocks,
+                                            float* __restrict__ g_w0, float* __restrict__ g_b0,
+                                            float* __restrict__ g_w1, float* __restrict__ g_b1) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v >= PART_GB1 + NOUT) return;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int b = 0;
+  for (; b + 3 < nblocks; b += 4) {
+    s0 += partials[(size_t)b * PART_STRIDE + v];
+    s1 += partials[(size_t)(b + 1) * PART_STRIDE + v];
+    s2 += partials[(size_t)(b + 2) * PART_STRIDE + v];
+    s3 += partials[(size_t)(b + 3) * PART_STRIDE + v];
+  }
+  for (; b < nblocks; ++b) s0 += partials[(size_t)b * PART_STRIDE + v];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (v < PART_GW1) {
+    const int feat = v >> 5, k = v & 31;
+    if (k < MC<NL>::KIN) {
+      const int c = ref_col<NL>(k);
+      if (c >= 0) g_w0[feat * MC<NL>::DIN + c] += s;
+      else g_b0[feat] += s;
+    }
+  } else if (v < PART_GB1) {
+    const int feat = (v - PART_GW1) >> 5, o = (v - PART_GW1) & 31;
+    if (o < NOUT) g_w1[o * HID + feat] += s;
+  } else {
+    g_b1[v - PART_GB1] += s;
+  }
+}
+
+constexpr int BWD_MFMA_MAX_BLOCKS = 512;
+
+}  // namespace
+
+#define DSU_DISPATCH_NL(nl, ...)                       \
+  switch (nl) {                                        \
+    case 10: { constexpr int NL = 10; __VA_ARGS__ } break; \
+    case 12: { constexpr int NL = 12; __VA_ARGS__ } break; \
+    default: return DSU_EUNSUP;                        \
+  }
+
+// VALU implementations (hashgrid.hip), kept for A/B runs: DSU_SDF_IMPL=valu
+extern "C" int dsu_sdf_fwd_valu(const dsu_hashgrid_cfg*, const void*, const dsu_sdf_mlp*,
+                                const float*, int64_t, float, uint32_t, uint32_t, float*, void*);
+extern "C" int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg*, const void*, const dsu_sdf_mlp*,
+                                   const float*, int64_t, float, float, uint32_t, float*, float*,
+                                   float*, float*, void*);
+extern "C" int dsu_sdf_fd_bwd_valu(const dsu_hashgrid_cfg*, const void*, const dsu_sdf_mlp*,
+                                   const float*, int64_t, float, float, uint32_t, const float*,
+                                   const float*, const float*, const float*, float*, float*,
+                                   float*, float*, float*, void*, int64_t, void*);
+extern "C" int64_t dsu_sdf_fd_bwd_workspace_bytes_valu(const dsu_hashgrid_cfg*, int64_t);
+
+// Default mix (measured on MI355X, N = 262 144 ray-ordered samples, 4 active levels):
+//   forward:  VALU 0.22 ms vs MFMA 0.30 ms  -> VALU (gather-latency bound; 2 waves/SIMD help)
+//   backward: VALU 2.31 ms vs MFMA 1.60 ms  -> MFMA
+// DSU_SDF_IMPL=valu|mfma forces one implementation for everything (A/B runs, tests).
+static bool use_valu(bool forward) {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DSU_SDF_IMPL");
+    v = !e ? 0 : (strcmp(e, "valu") == 0 ? 1 : (strcmp(e, "mfma") == 0 ? 2 : 0));
+  }
+  return v == 1 || (v == 0 && forward);
+}
+
+extern "C" {
+
+int dsu_sdf_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                const float* pts, int64_t n, float radius, uint32_t active_levels,
+                uint32_t n_out, float* out, void* stream) {
+  if (use_valu(true))
+    return dsu_sdf_fwd_valu(cfg, table_f16, mlp, pts, n, radius, active_levels, n_out, out, stream);
+  if (!cfg || !table_f16 || !mlp || (!pts && n) || (!out && n) || n < 0) return DSU_EINVAL;
+  if (!mlp->w0 || !mlp->b0 || !mlp->w1 || !mlp->b1) return DSU_EINVAL;
+  if (active_levels > cfg->n_levels) return DSU_EINVAL;
+  if (n_out != 1 && n_out != NOUT) return DSU_EUNSUP;
+  GridMeta m;
+  int rc = make_meta(cfg, &m);
+  if (rc) return rc;
+  if (n == 0) return DSU_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = dsu_capped_blocks(n, 256, 4096);
+  DSU_DISPATCH_NL(cfg->n_levels, {
+    if (n_out == 1)
+      sdf_fwd_mfma_kernel<NL, 1><<<dim3(blocks), dim3(256), 0, s>>>(
+          (const __half2*)table_f16, m, *mlp, pts, n, radius, active_levels, out);
+    else
+      sdf_fwd_mfma_kernel<NL, NOUT><<<dim3(blocks), dim3(256), 0, s>>>(
+          (const __half2*)table_f16, m, *mlp, pts, n, radius, active_levels, out);
+  });
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_sdf_fd_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                   const float* pts, int64_t n, float radius, float eps,
+                   uint32_t active_levels, float* sdf, float* grad, float* feature,
+                   float* laplace, void* stream) {
+  if (use_valu(true))
+    return dsu_sdf_fd_fwd_valu(cfg, table_f16, mlp, pts, n, radius, eps, active_levels, sdf, grad,
+                               feature, laplace, stream);
+  if (!cfg || !table_f16 || !mlp || (!pts && n) || (!sdf && n) || n < 0) return DSU_EINVAL;
+  if (!mlp->w0 || !mlp->b0 || !mlp->w1 || !mlp->b1) return DSU_EINVAL;
+  if (active_levels > cfg->n_levels || !(eps > 0.0f)) return DSU_EINVAL;
+  GridMeta m;
+  int rc = make_meta(cfg, &m);
+  if (rc) return rc;
+  if (n == 0) return DSU_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const float eps2 = (float)((double)eps * (double)eps);
+  const int blocks = dsu_capped_blocks(n, 256, 4096);
+  DSU_DISPATCH_NL(cfg->n_levels, {
+    sdf_fd_fwd_mfma_kernel<NL><<<dim3(blocks), dim3(256), 0, s>>>(
+        (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, sdf, grad,
+        feature, laplace);
+  });
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int64_t dsu_sdf_fd_bwd_workspace_bytes(const dsu_hashgrid_cfg* cfg, int64_t n) {
+  if (use_valu(false)) return dsu_sdf_fd_bwd_workspace_bytes_valu(cfg, n);
+  if (!cfg || n < 0) return DSU_EINVAL;
+  if (cfg->n_levels != 10 && cfg->n_levels != 12) return DSU_EUNSUP;
+  const int blocks = dsu_capped_blocks(n, 256, BWD_MFMA_MAX_BLOCKS);
+  return (int64_t)blocks * PART_STRIDE * sizeof(float);
+}
+
+int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                   const float* pts, int64_t n, float radius, float eps,
+                   uint32_t active_levels, const float* d_sdf, const float* d_grad,
+                   const float* d_feature, const float* d_laplace, float* grad_table,
+                   float* g_w0, float* g_b0, float* g_w1, float* g_b1, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
+  if (use_valu(false))
+    return dsu_sdf_fd_bwd_valu(cfg, table_f16, mlp, pts, n, radius, eps, active_levels, d_sdf,
+                               d_grad, d_feature, d_laplace, grad_table, g_w0, g_b0, g_w1, g_b1,
+                               workspace, workspace_bytes, stream);
+  if (!cfg || !table_f16 || !mlp || (!pts && n) || n < 0) return DSU_EINVAL;
+  if (!mlp->w0 || !mlp->b0 || !mlp->w1 || !mlp->b1) return DSU_EINVAL;
+  if (!grad_table || !g_w0 || !g_b0 || !g_w1 || !g_b1) return DSU_EINVAL;
+  if (active_levels > cfg->n_levels || !(eps > 0.0f)) return DSU_EINVAL;
+  GridMeta m;
+  int rc = make_meta(cfg, &m);
+  if (rc) return rc;
+  if (n == 0) return DSU_OK;
+  const int64_t need = dsu_sdf_fd_bwd_workspace_bytes(cfg, n);
+  if (need < 0) return (int)need;
+  if (!workspace || workspace_bytes < need) return DSU_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const float eps2 = (float)((double)eps * (double)eps);
+  const int blocks = dsu_capped_blocks(n, 256, BWD_MFMA_MAX_BLOCKS);
+  const size_t shm = (size_t)BWD_LDS_F * sizeof(float);
+  DSU_DISPATCH_NL(cfg->n_levels, {
+    if (hipFuncSetAttribute((const void*)sdf_fd_bwd_mfma_kernel<NL>,
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+      return DSU_ELAUNCH;
+    sdf_fd_bwd_mfma_kernel<NL><<<dim3(blocks), dim3(256), shm, s>>>(
+        (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
+        d_grad, d_feature, d_laplace, grad_table, (float*)workspace);
+    reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 255) / 256), dim3(256), 0, s>>>(
+        (const float*)workspace, blocks, g_w0, g_b0, g_w1, g_b1);
+  });
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+}  // extern "C"
