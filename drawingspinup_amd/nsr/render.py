@@ -98,6 +98,7 @@ class OccupancyGrid(nn.Module):
 class RayPacking:
     """Side channel between ray_marching and the compositing ops."""
     last = None
+    total = 0      # number of samples of the last ray_marching call (host int)
 
 
 @torch.no_grad()
@@ -123,6 +124,7 @@ def ray_marching(rays_o, rays_d, t_min=None, t_max=None, scene_aabb=None, grid=N
     ri, ts, te, off, cnt = ops.ray_march(rays_o, rays_d, tmin, tmax, gaabb, occ, res,
                                          render_step_size)
     RayPacking.last = (ri, off, cnt)
+    RayPacking.total = int(ri.shape[0])
     return ri, ts[:, None], te[:, None]
 
 

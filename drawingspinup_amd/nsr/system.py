@@ -126,6 +126,31 @@ def ranking_loss(error, penalize_ratio=0.7, extra_weights=None, type="mean"):
     return torch.mean(s_error) if type == "mean" else torch.sum(s_error)
 
 
+def ranking_loss_masked(error, valid, penalize_ratio=0.7, extra_weights=None, type="mean"):
+    """ranking_loss(error[valid], ratio, extra_weights[valid], type) without the boolean-mask
+    gather: `x[mask]` makes the host wait for the device (nonzero), several times per step.
+
+    NB the reference indexes the SORTED errors with the ORIGINAL positions of the k smallest
+    (criterions.py:17-18: `error, indices = torch.sort(error)` then
+    `index_select(error, 0, indices[:k])`), i.e. it sums sorted[p] over the subset positions p of
+    the k smallest entries.  That exact selection is reproduced: masked-out entries sort to the
+    end as +inf, subset positions come from a running count of `valid`, and
+    k = int(ratio * valid.sum()) stays on the device (float64 product = Python's value)."""
+    n = error.shape[0]
+    e = torch.where(valid, error, torch.full_like(error, float("inf")))
+    se, idx = torch.sort(e)                                   # sorted valid errors, then +inf
+    k = torch.floor(penalize_ratio * valid.sum().double())
+    sel = torch.arange(n, device=error.device) < k
+    pos = torch.cumsum(valid.to(torch.int64), 0) - 1          # position inside error[valid]
+    pj = torch.index_select(pos, 0, idx).clamp_(min=0)        # subset position of the j-th smallest
+    vals = torch.index_select(se, 0, pj)
+    vals = torch.where(sel, vals, torch.zeros_like(vals))
+    if extra_weights is not None:
+        vals = vals * torch.index_select(extra_weights, 0, idx)
+    total = vals.sum()
+    return total / k.to(total.dtype) if type == "mean" else total
+
+
 class OrthoNeuSSystem:
     def __init__(self, model_config=None, system_config=None, device="cuda", seed=123456):
         torch.manual_seed(seed)
@@ -170,23 +195,25 @@ class OrthoNeuSSystem:
     # ----------------------------------------------------------------- losses
     def losses(self, out, batch):
         L = self.config.loss
-        cosines = batch["cosines"].clone()
         view_weights = batch["view_weights"]
-        cosines[cosines > -0.1] = 0
+        cosines = torch.where(batch["cosines"] > -0.1, torch.zeros_like(batch["cosines"]),
+                              batch["cosines"])                         # cosines[cosines > -0.1] = 0
         mask = (batch["mask"] > 0) & (cosines < -0.1)
         terms = {}
-        err = F.mse_loss(out["comp_rgb"][mask], batch["rgb"][mask], reduction="none")
-        terms["rgb_mse"] = ranking_loss(err.sum(1), L.rgb_p_ratio, type="mean") * L.lambda_rgb_mse
+        # x[mask] of the reference (neus_ortho.py:94-116) evaluated without host round trips
+        err = F.mse_loss(out["comp_rgb"], batch["rgb"], reduction="none")
+        terms["rgb_mse"] = ranking_loss_masked(err.sum(1), mask, L.rgb_p_ratio, type="mean") \
+            * L.lambda_rgb_mse
         if L.lambda_rgb_l1:
-            l1 = F.l1_loss(out["comp_rgb"][mask], batch["rgb"][mask], reduction="none")
-            terms["rgb_l1"] = ranking_loss(l1.sum(1), L.rgb_p_ratio) * L.lambda_rgb_l1
+            l1 = F.l1_loss(out["comp_rgb"], batch["rgb"], reduction="none")
+            terms["rgb_l1"] = ranking_loss_masked(l1.sum(1), mask, L.rgb_p_ratio) * L.lambda_rgb_l1
         normal_errors = 1 - F.cosine_similarity(out["comp_normal"], batch["normal"], dim=1)
         if L.geo_aware:
             e = torch.exp(cosines.abs())
             normal_errors = normal_errors * e / e.sum()
-            ln = ranking_loss(normal_errors[mask], L.normal_p_ratio, view_weights[mask], "sum")
+            ln = ranking_loss_masked(normal_errors, mask, L.normal_p_ratio, view_weights, "sum")
         else:
-            ln = ranking_loss(normal_errors[mask], L.normal_p_ratio, view_weights[mask], "mean")
+            ln = ranking_loss_masked(normal_errors, mask, L.normal_p_ratio, view_weights, "mean")
         terms["normal"] = ln * L.lambda_normal
         terms["eikonal"] = ((torch.linalg.norm(out["sdf_grad_samples"], ord=2, dim=-1) - 1.0) ** 2
                             ).mean() * L.lambda_eikonal
@@ -217,7 +244,10 @@ class OrthoNeuSSystem:
         self.model.update_step(0, self.global_step)
         out = self.model(batch["rays"], jitter=inject.get("jitter"),
                          pts_random=inject.get("pts_random"), perturb=inject.get("perturb"))
-        n_samples = int(out["num_samples"].sum().item())        # neus_ortho.py:91 host sync
+        # neus_ortho.py:91 reads num_samples back with .item(); the marcher already had to
+        # bring the total to the host to size its outputs, so reuse that value (no second sync)
+        from .render import RayPacking
+        n_samples = RayPacking.total
         if self.model.config.dynamic_ray_sampling and n_samples > 0:
             tr = int(self.train_num_rays * (self.train_num_samples / n_samples))
             self.train_num_rays = min(int(self.train_num_rays * 0.9 + tr * 0.1),

@@ -168,3 +168,29 @@ def test_nerfacc_kats():
                                      np.array([0.0, 0.0, 0.004, 0.0], np.float32), 0.95, 0.001)
     np.testing.assert_allclose(occs, [0.0, 0.019, 0.004, 0.0], rtol=1e-6)
     assert binary.tolist() == [False, True, True, False]
+
+
+def test_sync_free_ranking_loss_equals_reference_form():
+    """ranking_loss_masked(e, m, ...) == ranking_loss(e[m], ..., w[m]) (criterions.py:16-27)."""
+    from drawingspinup_amd.nsr.system import ranking_loss, ranking_loss_masked
+    g = torch.Generator().manual_seed(3)
+    for n in (1, 7, 10, 100, 1000):
+        for ratio in (0.8, 0.9, 0.7):
+            e = torch.rand(n, generator=g, dtype=torch.float32)
+            w = torch.rand(n, generator=g)
+            m = torch.rand(n, generator=g) > 0.3
+            if int(m.sum()) == 0 or int(ratio * int(m.sum())) == 0:
+                continue
+            for typ in ("mean", "sum"):
+                a = ranking_loss_masked(e, m, ratio, w, typ)
+                b = ranking_loss(e[m], ratio, w[m], typ)
+                torch.testing.assert_close(a, b, rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(ranking_loss_masked(e, torch.ones_like(m), ratio),
+                                       ranking_loss(e, ratio), rtol=1e-6, atol=1e-7)
+    # gradients agree with the reference form too (it selects sorted[indices[:k]], see docstring)
+    e1 = torch.tensor([0.5, 0.1, 0.9, 0.3, 0.7], requires_grad=True)
+    e2 = e1.detach().clone().requires_grad_(True)
+    m = torch.tensor([True, True, False, True, True])
+    ranking_loss_masked(e1, m, 0.7, None, "mean").backward()
+    ranking_loss(e2[m], 0.7, None, "mean").backward()
+    assert torch.equal(e1.grad, e2.grad)
