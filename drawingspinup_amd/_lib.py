@@ -48,6 +48,8 @@ _PROTOS = {
     "dsu_ray_aabb": [P, P, c_i64, P, P, c_f32, P, P, P],
     "dsu_ray_march_count": [P, P, P, P, c_i64, P, P, c_i32, c_f32, P, P],
     "dsu_ray_march_fill": [P, P, P, P, c_i64, P, P, c_i32, c_f32, P, P, P, P, P],
+    "dsu_ray_march_scratch": [P, P, P, P, c_i64, P, P, c_i32, c_f32, c_i32, P, P, P, P],
+    "dsu_ray_compact": [P, P, c_i32, P, P, c_i64, P, P, P, P],
     "dsu_weights_from_alpha_fwd": [P, P, P, c_i64, P, P],
     "dsu_weights_from_alpha_bwd": [P, P, P, P, P, c_i64, P, P],
     "dsu_accumulate_fwd": [P, P, c_i32, P, P, c_i64, P, P],

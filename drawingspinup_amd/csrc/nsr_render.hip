@@ -92,11 +92,13 @@ __global__ void ray_aabb_kernel(const float* __restrict__ ro, const float* __res
   tmax_o[i] = far;
 }
 
-template <bool FILL>
+// MODE 0: count only; 1: fill at offsets[i]; 2: single pass — fill a fixed-capacity scratch row
+// (i * cap) AND write the count, so the serial march runs once (compacted by ray_compact_kernel)
+template <int MODE>
 __global__ void ray_march_kernel(const float* __restrict__ ro, const float* __restrict__ rd,
                                  const float* __restrict__ tmin, const float* __restrict__ tmax,
                                  int64_t n, Aabb a, const uint8_t* __restrict__ occ, int res,
-                                 float step, const int32_t* __restrict__ offsets,
+                                 float step, const int32_t* __restrict__ offsets, int cap,
                                  int32_t* __restrict__ num_steps,
                                  int64_t* __restrict__ ray_indices, float* __restrict__ t_starts,
                                  float* __restrict__ t_ends) {
@@ -106,18 +108,20 @@ __global__ void ray_march_kernel(const float* __restrict__ ro, const float* __re
   const float d[3] = {rd[i * 3], rd[i * 3 + 1], rd[i * 3 + 2]};
   const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
   const float near = tmin[i], far = tmax[i];
+  constexpr bool FILL = MODE != 0;
   int64_t base = 0;
-  if (FILL) base = offsets[i];
+  if (MODE == 1) base = offsets[i];
+  if (MODE == 2) base = i * (int64_t)cap;
   const float dt = step;  // cone_angle == 0: calc_dt clamps to dt_min
   int j = 0;
   float t0 = near, t1 = t0 + dt, tm = (t0 + t1) * 0.5f;
   while (tm < far) {
     const float p[3] = {o[0] + tm * d[0], o[1] + tm * d[1], o[2] + tm * d[2]};
     if (occ == nullptr || occupied_at(p, a, occ, res)) {
-      if (FILL) {
+      if (MODE == 1 || (MODE == 2 && j < cap)) {
         t_starts[base + j] = t0;
         t_ends[base + j] = t1;
-        ray_indices[base + j] = i;
+        if (MODE == 1) ray_indices[base + j] = i;
       }
       ++j;
       t0 = t1;
@@ -133,7 +137,28 @@ __global__ void ray_march_kernel(const float* __restrict__ ro, const float* __re
       t1 = tm + dt * 0.5f;
     }
   }
-  if (!FILL) num_steps[i] = j;
+  if (MODE != 1) num_steps[i] = j;
+}
+
+// one wave per ray: scratch rows -> packed samples
+__global__ __launch_bounds__(256) void ray_compact_kernel(const float* __restrict__ t0s,
+                                                          const float* __restrict__ t1s, int cap,
+                                                          const int32_t* __restrict__ off,
+                                                          const int32_t* __restrict__ cnt,
+                                                          int64_t n_rays,
+                                                          int64_t* __restrict__ ray_indices,
+                                                          float* __restrict__ t_starts,
+                                                          float* __restrict__ t_ends) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rays) return;
+  const int64_t b = off[r];
+  const int c = cnt[r];
+  for (int j = lane; j < c; j += 64) {
+    t_starts[b + j] = t0s[r * cap + j];
+    t_ends[b + j] = t1s[r * cap + j];
+    ray_indices[b + j] = r;
+  }
 }
 
 __global__ void weights_fwd_kernel(const float* __restrict__ alpha,
@@ -486,8 +511,8 @@ int dsu_ray_march_count(const float* rays_o, const float* rays_d, const float* t
   if (n_rays < 0 || !aabb6 || !(step > 0.0f) || (occ_binary && res <= 0)) return DSU_EINVAL;
   if (n_rays && (!rays_o || !rays_d || !t_min || !t_max || !num_steps)) return DSU_EINVAL;
   if (n_rays == 0) return DSU_OK;
-  ray_march_kernel<false><<<dsu_blocks_for(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
-      rays_o, rays_d, t_min, t_max, n_rays, make_aabb(aabb6, occ_binary ? res : 1), occ_binary, res, step, nullptr,
+  ray_march_kernel<0><<<dsu_blocks_for(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
+      rays_o, rays_d, t_min, t_max, n_rays, make_aabb(aabb6, occ_binary ? res : 1), occ_binary, res, step, nullptr, 0,
       num_steps, nullptr, nullptr, nullptr);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
@@ -501,9 +526,40 @@ int dsu_ray_march_fill(const float* rays_o, const float* rays_d, const float* t_
   if (n_rays < 0 || !aabb6 || !(step > 0.0f) || (occ_binary && res <= 0)) return DSU_EINVAL;
   if (n_rays && (!rays_o || !rays_d || !t_min || !t_max || !offsets)) return DSU_EINVAL;
   if (n_rays == 0) return DSU_OK;
-  ray_march_kernel<true><<<dsu_blocks_for(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
-      rays_o, rays_d, t_min, t_max, n_rays, make_aabb(aabb6, occ_binary ? res : 1), occ_binary, res, step, offsets,
+  ray_march_kernel<1><<<dsu_blocks_for(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
+      rays_o, rays_d, t_min, t_max, n_rays, make_aabb(aabb6, occ_binary ? res : 1), occ_binary, res, step, offsets, 0,
       nullptr, ray_indices, t_starts, t_ends);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_ray_march_scratch(const float* rays_o, const float* rays_d, const float* t_min,
+                          const float* t_max, int64_t n_rays, const float* aabb6,
+                          const uint8_t* occ_binary, int32_t res, float step, int32_t capacity,
+                          int32_t* num_steps, float* scratch_t_starts, float* scratch_t_ends,
+                          void* stream) {
+  if (n_rays < 0 || !aabb6 || !(step > 0.0f) || (occ_binary && res <= 0) || capacity <= 0)
+    return DSU_EINVAL;
+  if (n_rays && (!rays_o || !rays_d || !t_min || !t_max || !num_steps || !scratch_t_starts ||
+                 !scratch_t_ends))
+    return DSU_EINVAL;
+  if (n_rays == 0) return DSU_OK;
+  ray_march_kernel<2><<<dsu_blocks_for(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
+      rays_o, rays_d, t_min, t_max, n_rays, make_aabb(aabb6, occ_binary ? res : 1), occ_binary,
+      res, step, nullptr, capacity, num_steps, nullptr, scratch_t_starts, scratch_t_ends);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_ray_compact(const float* scratch_t_starts, const float* scratch_t_ends, int32_t capacity,
+                    const int32_t* offsets, const int32_t* counts, int64_t n_rays,
+                    int64_t* ray_indices, float* t_starts, float* t_ends, void* stream) {
+  if (n_rays < 0 || capacity <= 0) return DSU_EINVAL;
+  if (n_rays && (!scratch_t_starts || !scratch_t_ends || !offsets || !counts)) return DSU_EINVAL;
+  if (n_rays == 0) return DSU_OK;
+  ray_compact_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      scratch_t_starts, scratch_t_ends, capacity, offsets, counts, n_rays, ray_indices, t_starts,
+      t_ends);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }

@@ -121,8 +121,8 @@ def ray_marching(rays_o, rays_d, t_min=None, t_max=None, scene_aabb=None, grid=N
     occ, res, gaabb = None, 0, aabb
     if grid is not None:
         occ, res, gaabb = grid.binary_u8(), grid.res, grid._aabb_host
-    ri, ts, te, off, cnt = ops.ray_march(rays_o, rays_d, tmin, tmax, gaabb, occ, res,
-                                         render_step_size)
+    ri, ts, te, off, cnt = ops.ray_march_single_pass(rays_o, rays_d, tmin, tmax, gaabb, occ, res,
+                                                     render_step_size)
     RayPacking.last = (ri, off, cnt)
     RayPacking.total = int(ri.shape[0])
     return ri, ts[:, None], te[:, None]

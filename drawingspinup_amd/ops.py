@@ -166,6 +166,48 @@ def ray_march(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step):
     return ray_indices, t_starts, t_ends, offsets, counts
 
 
+_MARCH_SCRATCH = {}
+
+
+def ray_march_single_pass(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step):
+    """Same outputs as ray_march with ONE serial march (fixed-capacity scratch rows + compaction).
+    The capacity covers the longest possible chord of the box; rays are re-marched with the
+    two-pass path in the (never observed) case that a count exceeds it."""
+    import math
+    rays_o, rays_d = _f32c(rays_o), _f32c(rays_d)
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    a = (C.c_float * 6)(*[float(v) for v in aabb6])
+    diag = math.sqrt(sum((aabb6[3 + d] - aabb6[d]) ** 2 for d in range(3)))
+    cap = int(diag / step) + 8
+    key = (str(dev), cap)
+    sc = _MARCH_SCRATCH.get(key)
+    if sc is None or sc[0].shape[0] < n * cap:
+        rows = max(n, 8192)
+        sc = (torch.empty(rows * cap, dtype=torch.float32, device=dev),
+              torch.empty(rows * cap, dtype=torch.float32, device=dev))
+        _MARCH_SCRATCH[key] = sc
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    occp = ptr(occ_binary, torch.uint8) if occ_binary is not None else None
+    check(lib().dsu_ray_march_scratch(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), n, a, occp,
+                                      int(res), float(step), cap, ptr(counts), ptr(sc[0]),
+                                      ptr(sc[1]), stream()), "dsu_ray_march_scratch")
+    csum = torch.cumsum(counts, 0, dtype=torch.int32)
+    offsets = (csum - counts).contiguous()
+    stats = torch.stack([csum[-1], counts.max()]).tolist() if n > 0 else [0, 0]   # one host sync
+    total, cmax = int(stats[0]), int(stats[1])
+    if cmax > cap:
+        return ray_march(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step)
+    ray_indices = torch.empty(total, dtype=torch.int64, device=dev)
+    t_starts = torch.empty(total, dtype=torch.float32, device=dev)
+    t_ends = torch.empty(total, dtype=torch.float32, device=dev)
+    if total > 0:
+        check(lib().dsu_ray_compact(ptr(sc[0]), ptr(sc[1]), cap, ptr(offsets), ptr(counts), n,
+                                    ptr(ray_indices), ptr(t_starts), ptr(t_ends), stream()),
+              "dsu_ray_compact")
+    return ray_indices, t_starts, t_ends, offsets, counts
+
+
 def weights_from_alpha_fwd(alpha, offsets, counts):
     alpha = _f32c(alpha)
     w = torch.empty_like(alpha)

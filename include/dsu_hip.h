@@ -144,6 +144,20 @@ int dsu_ray_march_fill(const float* rays_o, const float* rays_d, const float* t_
                        const int32_t* offsets, int64_t* ray_indices, float* t_starts,
                        float* t_ends, void* stream);
 
+/* Single-pass variant of the two calls above: the serial march runs ONCE, writing each ray's
+ * samples into a fixed-capacity scratch row (ray r at scratch[r*capacity ...]) together with
+ * its count; dsu_ray_compact then packs the rows at the exclusive prefix sum of the counts.
+ * Identical results (same stepping loop); a ray with more than `capacity` samples is
+ * reported through num_steps (caller checks max(num_steps) <= capacity). */
+int dsu_ray_march_scratch(const float* rays_o, const float* rays_d, const float* t_min,
+                          const float* t_max, int64_t n_rays, const float* aabb6,
+                          const uint8_t* occ_binary, int32_t res, float step, int32_t capacity,
+                          int32_t* num_steps, float* scratch_t_starts, float* scratch_t_ends,
+                          void* stream);
+int dsu_ray_compact(const float* scratch_t_starts, const float* scratch_t_ends, int32_t capacity,
+                    const int32_t* offsets, const int32_t* counts, int64_t n_rays,
+                    int64_t* ray_indices, float* t_starts, float* t_ends, void* stream);
+
 /* render_weight_from_alpha (neus.py:147): per ray segment [offsets[r], offsets[r]+cnt[r])
  * w_i = alpha_i * prod_{j<i}(1-alpha_j).  One ray per thread. */
 int dsu_weights_from_alpha_fwd(const float* alpha, const int32_t* offsets, const int32_t* counts,

@@ -132,3 +132,23 @@ def test_occgrid(dev):
     exp = before.clone()
     exp[idx] = torch.maximum(before[idx] * 0.95, occ2)
     assert torch.equal(t, exp)
+
+
+def test_single_pass_march_equals_two_pass(dev):
+    occ = torch.from_numpy(_sphere_grid()).to(dev)
+    g = np.random.default_rng(11)
+    o = np.tile(np.array([[0.05, -0.1, -1.6]], np.float32), (777, 1))
+    d = g.normal(size=(777, 3)).astype(np.float32) * 0.25 + np.array([0, 0, 1], np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    to, td = torch.from_numpy(o).to(dev), torch.from_numpy(d).to(dev)
+    tmin, tmax = ops.ray_aabb(to, td, AABB)
+    a = ops.ray_march(to, td, tmin, tmax, AABB, occ, 128, STEP)
+    b = ops.ray_march_single_pass(to, td, tmin, tmax, AABB, occ, 128, STEP)
+    assert a[0].numel() > 1000
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # dense (no grid): longest chords, still within the scratch capacity
+    a = ops.ray_march(to, td, tmin, tmax, AABB, None, 0, STEP)
+    b = ops.ray_march_single_pass(to, td, tmin, tmax, AABB, None, 0, STEP)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
