@@ -429,6 +429,7 @@ class NeuSModel(nn.Module):
             opacity, depth, comp_rgb = comp[:, 0:1], comp[:, 1:2], comp[:, 2:5]
             comp_normal = F.normalize(comp[:, 5:8], p=2, dim=-1)
             weights = weights[:, None]
+            comp_raw = comp
         else:
             normal = F.normalize(sdf_grad, p=2, dim=-1)
             alpha = self.get_alpha(sdf, normal, t_dirs, dists)[..., None]
@@ -439,10 +440,11 @@ class NeuSModel(nn.Module):
             comp_rgb = accumulate_along_rays(weights, ray_indices, values=rgb, n_rays=n_rays)
             comp_normal = accumulate_along_rays(weights, ray_indices, values=normal, n_rays=n_rays)
             comp_normal = F.normalize(comp_normal, p=2, dim=-1)
-        out = {"comp_rgb": comp_rgb, "comp_normal": comp_normal, "opacity": opacity,
+        out = {} if not (self.fused_shading and self.training) else {"comp_raw": comp_raw}
+        out.update({"comp_rgb": comp_rgb, "comp_normal": comp_normal, "opacity": opacity,
                "depth": depth, "rays_valid": opacity > 0,
                "num_samples": torch.as_tensor([len(t_starts)], dtype=torch.int32,
-                                              device=rays.device)}
+                                              device=rays.device)})
         if self.training:
             out.update({"sdf_samples": sdf, "sdf_grad_samples": sdf_grad,
                         "random_sdf": random_sdf, "random_sdf_grad": random_sdf_grad,

@@ -151,6 +151,63 @@ def ranking_loss_masked(error, valid, penalize_ratio=0.7, extra_weights=None, ty
     return total / k.to(total.dtype) if type == "mean" else total
 
 
+class RayLossGraph:
+    """HIP-graph capture of OrthoNeuSSystem.ray_losses + d(loss)/d(comp) on fixed-capacity
+    buffers.  The ray count changes every step (dynamic ray sampling), so the tensors are padded
+    to `capacity` rows and the real rows are marked from a device-side count; replaying the graph
+    is ONE host call instead of ~200 small launches."""
+
+    KEYS = ("rgb", "normal", "mask", "cosines", "view_weights")
+
+    def __init__(self, system, capacity):
+        self.system, self.capacity = system, capacity
+        dev = system.device
+        z = lambda *shape: torch.zeros(*shape, device=dev)
+        self.comp = z(capacity, 8).requires_grad_(True)
+        self.bufs = {"rgb": z(capacity, 3), "normal": z(capacity, 3), "mask": z(capacity),
+                     "cosines": z(capacity), "view_weights": z(capacity)}
+        self.n_rays = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.graph = None
+        self.names = None
+
+    def _compute(self):
+        pad = torch.arange(self.capacity, device=self.comp.device) < self.n_rays
+        terms = self.system.ray_losses(self.comp, self.bufs, pad)
+        self.names = list(terms.keys())
+        total = sum(terms.values())
+        (g,) = torch.autograd.grad(total, self.comp)
+        return torch.stack([terms[k].detach() for k in self.names]), g
+
+    def _capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                self._compute()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.out_terms, self.out_grad = self._compute()
+
+    @torch.no_grad()
+    def _load(self, comp, batch):
+        r = comp.shape[0]
+        assert r <= self.capacity
+        self.comp.data[:r].copy_(comp.detach())
+        for k in self.KEYS:
+            self.bufs[k][:r].copy_(batch[k])
+        self.n_rays.fill_(r)
+        return r
+
+    def run(self, comp, batch):
+        r = self._load(comp, batch)
+        if self.graph is None:
+            self._capture()
+        self.graph.replay()
+        terms = {k: self.out_terms[i] for i, k in enumerate(self.names)}
+        return terms, self.out_grad[:r]
+
+
 class OrthoNeuSSystem:
     def __init__(self, model_config=None, system_config=None, device="cuda", seed=123456):
         torch.manual_seed(seed)
@@ -171,6 +228,8 @@ class OrthoNeuSSystem:
         self._gamma = 0.1 ** (1.0 / (self.config.max_steps - self.config.constant_steps))
         self.dataset = None
         self.last = {}
+        self.use_loss_graph = os.environ.get("DSU_NO_GRAPH", "0") != "1" and self.device.type == "cuda"
+        self._loss_graph = None
 
     # ----------------------------------------------------------------- data
     def preprocess_data(self, index=None, x=None, y=None):
@@ -193,40 +252,59 @@ class OrthoNeuSSystem:
                 "view_weights": view_weights}
 
     # ----------------------------------------------------------------- losses
-    def losses(self, out, batch):
+    def ray_losses(self, comp, batch, pad=None):
+        """The three ray-level terms (neus_ortho.py:94-133) from the raw composite
+        comp (R,8) = [opacity, depth, rgb(3), sum w*normal(3)].  `pad` (R,) bool marks the real
+        rays when the tensors are padded to a fixed capacity (graph replay); None = all real."""
         L = self.config.loss
+        comp_rgb, opacity = comp[:, 2:5], comp[:, 0]
+        comp_normal = F.normalize(comp[:, 5:8], p=2, dim=-1)
         view_weights = batch["view_weights"]
         cosines = torch.where(batch["cosines"] > -0.1, torch.zeros_like(batch["cosines"]),
                               batch["cosines"])                         # cosines[cosines > -0.1] = 0
         mask = (batch["mask"] > 0) & (cosines < -0.1)
+        real = torch.ones_like(mask) if pad is None else pad
+        mask = mask & real
         terms = {}
-        # x[mask] of the reference (neus_ortho.py:94-116) evaluated without host round trips
-        err = F.mse_loss(out["comp_rgb"], batch["rgb"], reduction="none")
+        # x[mask] of the reference evaluated without host round trips (ranking_loss_masked)
+        err = F.mse_loss(comp_rgb, batch["rgb"], reduction="none")
         terms["rgb_mse"] = ranking_loss_masked(err.sum(1), mask, L.rgb_p_ratio, type="mean") \
             * L.lambda_rgb_mse
         if L.lambda_rgb_l1:
-            l1 = F.l1_loss(out["comp_rgb"], batch["rgb"], reduction="none")
+            l1 = F.l1_loss(comp_rgb, batch["rgb"], reduction="none")
             terms["rgb_l1"] = ranking_loss_masked(l1.sum(1), mask, L.rgb_p_ratio) * L.lambda_rgb_l1
-        normal_errors = 1 - F.cosine_similarity(out["comp_normal"], batch["normal"], dim=1)
+        normal_errors = 1 - F.cosine_similarity(comp_normal, batch["normal"], dim=1)
         if L.geo_aware:
             e = torch.exp(cosines.abs())
-            normal_errors = normal_errors * e / e.sum()
+            normal_errors = normal_errors * e / (e * real).sum()
             ln = ranking_loss_masked(normal_errors, mask, L.normal_p_ratio, view_weights, "sum")
         else:
             ln = ranking_loss_masked(normal_errors, mask, L.normal_p_ratio, view_weights, "mean")
         terms["normal"] = ln * L.lambda_normal
+        opac = torch.clamp(opacity, 1e-3, 1 - 1e-3)
+        lm = ranking_loss_masked(binary_cross_entropy(opac, batch["mask"].float()), real,
+                                 L.mask_p_ratio, view_weights)
+        terms["mask"] = lm * (L.lambda_mask if self.dataset.has_mask else 0.0)
+        return terms
+
+    def sample_losses(self, out):
+        """Sample-level terms: eikonal, sparsity, 3-D normal smoothness (neus_ortho.py:118-151)."""
+        L = self.config.loss
+        terms = {}
         terms["eikonal"] = ((torch.linalg.norm(out["sdf_grad_samples"], ord=2, dim=-1) - 1.0) ** 2
                             ).mean() * L.lambda_eikonal
-        opacity = torch.clamp(out["opacity"].squeeze(-1), 1e-3, 1 - 1e-3)
-        lm = ranking_loss(binary_cross_entropy(opacity, batch["mask"].float()), L.mask_p_ratio,
-                          view_weights)
-        terms["mask"] = lm * (L.lambda_mask if self.dataset.has_mask else 0.0)
         terms["sparsity"] = torch.exp(-L.sparsity_scale * out["random_sdf"].abs()).mean() \
             * L.lambda_sparsity
         if L.lambda_3d_normal_smooth > 0:
             terms["normal_smooth"] = (out["random_sdf_grad"] - out["normal_perturb"]).abs().mean() \
                 * L.lambda_3d_normal_smooth
         return terms
+
+    def losses(self, out, batch):
+        comp = out.get("comp_raw")
+        if comp is None:      # op-by-op path: rebuild the raw composite layout
+            comp = torch.cat([out["opacity"], out["depth"], out["comp_rgb"], out["comp_normal"]], 1)
+        return {**self.ray_losses(comp, batch), **self.sample_losses(out)}
 
     # ----------------------------------------------------------------- one optimisation step
     def _set_lr(self):
@@ -252,11 +330,22 @@ class OrthoNeuSSystem:
             tr = int(self.train_num_rays * (self.train_num_samples / n_samples))
             self.train_num_rays = min(int(self.train_num_rays * 0.9 + tr * 0.1),
                                       self.model.config.max_train_num_rays)
-        terms = self.losses(out, batch)
-        loss = sum(terms.values())
         self._set_lr()
         self.optimizer.zero_grad(set_to_none=True)
-        loss.backward()
+        if self.use_loss_graph and "comp_raw" in out:
+            # ray-level losses + their gradient w.r.t. the composite: one captured HIP graph
+            # (fixed max_train_num_rays capacity, real rays marked by a device-side count)
+            if self._loss_graph is None:
+                self._loss_graph = RayLossGraph(self, self.model.config.max_train_num_rays)
+            rterms, d_comp = self._loss_graph.run(out["comp_raw"], batch)
+            sterms = self.sample_losses(out)
+            torch.autograd.backward([sum(sterms.values()), out["comp_raw"]], [None, d_comp])
+            terms = {**rterms, **sterms}
+            loss = sum(terms.values())
+        else:
+            terms = self.losses(out, batch)
+            loss = sum(terms.values())
+            loss.backward()
         self.optimizer.step()
         self.global_step += 1
         self.last = {"loss": loss.detach(), "n_samples": n_samples,
