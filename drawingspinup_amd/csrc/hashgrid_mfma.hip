@@ -52,6 +52,17 @@ __device__ __forceinline__ void swap_halves(float a, float b, float& o0, float& 
   o1 = __uint_as_float(r[1]);
 }
 
+// DPP row shifts inside 16-lane rows (0x101.. = row_shl:n -> lane i reads lane i+n,
+// 0x111.. = row_shr:n -> lane i reads lane i-n); lanes shifted in from outside the row read 0.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) {
+  return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
 template <int NL>
 struct Frags {
   float w0[2][MC<NL>::KP];   // A operand of layer 0: W0'[32T + (lane&31)][2t + (lane>>5)]
@@ -299,7 +310,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
     uint32_t active, const float* __restrict__ d_sdf, const float* __restrict__ d_grad,
     const float* __restrict__ d_feature, const float* __restrict__ d_laplace,
-    float* __restrict__ gtable, float* __restrict__ partials) {
+    float* __restrict__ gtable, float* __restrict__ partials, int ablate) {
   constexpr int KIN = MC<NL>::KIN;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* w1perm = lds;
@@ -454,6 +465,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
         }
         __builtin_amdgcn_wave_barrier();
         // gW0[feat][k'] += sum_points dPre[point][feat] * In'[point][k']
+        if (!(ablate & 2))
 #pragma unroll 4
         for (int t = 0; t < 16; ++t) {
           const int pr = 2 * t + h;
@@ -470,6 +482,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
             *reinterpret_cast<float4*>(&sd[l31 * SD_ROW + 32 * T + 8 * qd + 4 * h]) =
                 make_float4(Hh[T][4 * qd], Hh[T][4 * qd + 1], Hh[T][4 * qd + 2], Hh[T][4 * qd + 3]);
         __builtin_amdgcn_wave_barrier();
+        if (!(ablate & 2))
 #pragma unroll 4
         for (int t = 0; t < 16; ++t) {
           const int pr = 2 * t + h;
@@ -478,7 +491,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
           gw1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + 32 + l31], b, gw1[1], 0, 0, 0);
         }
         // scatter dIn rows held by this lane: input row i = (r&3) + 8(r>>2) + 4h, levels (i>>1)
-        {
+        if (!(ablate & 1)) {
           const bool own = h == half;
           const float sx = own ? cx : pcx, sy = own ? cy : pcy, sz = own ? cz : pcz;
           const bool pv = __shfl(valid ? 1 : 0, half * 32 + l31) != 0;
@@ -486,17 +499,45 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
           for (int r = 0; r < 16; r += 2) {
             const int lev = ((r & 3) + 8 * (r >> 2)) / 2 + 2 * h;   // compile-time part + lane half
             if (lev < NL && (uint32_t)lev < active) {
-              const float d0 = din[r], d1 = din[r + 1];
-              if (pv && (d0 != 0.0f || d1 != 0.0f)) {
-                const uint32_t hsize = m.off[lev + 1] - m.off[lev];
-                const CellPos cp = cell_of(m.scale[lev], sx, sy, sz);
+              const bool on = pv;
+              const float d0 = on ? din[r] : 0.0f, d1 = on ? din[r + 1] : 0.0f;
+              const uint32_t hsize = m.off[lev + 1] - m.off[lev];
+              const CellPos cp = cell_of(m.scale[lev], sx, sy, sz);
+              // Neighbouring lanes are neighbouring samples of a ray and mostly sit in the SAME
+              // cell: sum the 8x2 corner contributions over runs of equal cells inside each
+              // 16-lane row with DPP row shifts (segmented suffix scan), so that only the first
+              // lane of a run touches the LDS cache — no same-address LDS-atomic serialisation.
+              float v[16];
+#pragma unroll
+              for (int c = 0; c < 8; ++c) {
+                const float w = corner_weight(cp, c);
+                v[2 * c] = w * d0;
+                v[2 * c + 1] = w * d1;
+              }
+              const int key = (int)(cp.c[0] | (cp.c[1] << 10) | (cp.c[2] << 20));
+              const int l15 = lane & 15;
+              int e = (l15 == 15 || dpp_i<0x101>(key) != key) ? 1 : 0;   // run ends at this lane
+#define DSU_SEG_STEP(CTRL)                                              \
+              {                                                         \
+                const int eo = dpp_i<CTRL>(e);                          \
+                _Pragma("unroll") for (int k = 0; k < 16; ++k) {        \
+                  const float vo = dpp_f<CTRL>(v[k]);                   \
+                  v[k] += e ? 0.0f : vo;                                \
+                }                                                       \
+                e |= eo;                                                \
+              }
+              DSU_SEG_STEP(0x101) DSU_SEG_STEP(0x102) DSU_SEG_STEP(0x104) DSU_SEG_STEP(0x108)
+#undef DSU_SEG_STEP
+              const bool leader = l15 == 0 || dpp_i<0x111>(key) != key;  // first lane of its run
+              if (leader) {
 #pragma unroll
                 for (int c = 0; c < 8; ++c) {
-                  const uint32_t idx =
-                      grid_index(m.hashed[lev], hsize, m.res[lev], cp.c[0] + (c & 1),
-                                 cp.c[1] + ((c >> 1) & 1), cp.c[2] + ((c >> 2) & 1));
-                  const float w = corner_weight(cp, c);
-                  grad_cache_add(c_keys, c_vals, gtable, m.off[lev] + idx, w * d0, w * d1);
+                  if (v[2 * c] != 0.0f || v[2 * c + 1] != 0.0f) {
+                    const uint32_t idx =
+                        grid_index(m.hashed[lev], hsize, m.res[lev], cp.c[0] + (c & 1),
+                                   cp.c[1] + ((c >> 1) & 1), cp.c[2] + ((c >> 2) & 1));
+                    grad_cache_add(c_keys, c_vals, gtable, m.off[lev] + idx, v[2 * c], v[2 * c + 1]);
+                  }
                 }
               }
             }
@@ -710,7 +751,8 @@ int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu
       return DSU_ELAUNCH;
     sdf_fd_bwd_mfma_kernel<NL><<<dim3(blocks), dim3(256), shm, s>>>(
         (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
-        d_grad, d_feature, d_laplace, grad_table, (float*)workspace);
+        d_grad, d_feature, d_laplace, grad_table, (float*)workspace,
+        getenv("DSU_BWD_ABLATE") ? atoi(getenv("DSU_BWD_ABLATE")) : 0);
     reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 255) / 256), dim3(256), 0, s>>>(
         (const float*)workspace, blocks, g_w0, g_b0, g_w1, g_b1);
   });
