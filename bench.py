@@ -175,8 +175,11 @@ def main():
         ks = timer.summary()
         roof = None
         if ks:
-            roof = {"bound": "hbm", "kernel": "sdf_fd_bwd_kernel", "achieved": ks["gbps"],
+            roof = {"bound": "hbm", "kernel": "sdf_fd_bwd_mfma_kernel", "achieved": ks["gbps"],
                     "peak": 8000.0, "unit": "GB/s", "frac": ks["gbps"] / 8000.0, "traffic": None,
+                    "traffic_pmc_reference": "profiles/round1_pmc_sdf_kernels.txt: 614 MB HBM-side "
+                                             "(FETCH 27 MB + WRITE 587 MB) per launch at N=262144, "
+                                             "4 levels vs 726 MB algorithmic",
                     "launches": ks["launches"], "avg_launch_ms": ks["avg_ms"],
                     "alg_bytes_per_launch": ks["avg_bytes"]}
         out = {
