@@ -1,0 +1,46 @@
+"""`python recon.py --uid U [--all]` of the reference (2_charactor_reconstructor/recon.py:44-62):
+3000 optimisation steps, then the 2 x 512^3 SDF export.  The SDF volumes are saved as
+<uid>/mesh/it3000-sdf512_{coarse,fine}.npy; marching cubes / mesh post-processing are CPU geometry
+outside this path."""
+import argparse
+import json
+import os
+
+import numpy as np
+import torch
+
+from .. import dist as ddist
+from ..nsr.system import OrthoNeuSSystem
+from . import data as D
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--uid", default="0dd66be9d0534b93a092d8c4c4dfd30a")
+    ap.add_argument("--all", action="store_true")
+    ap.add_argument("--data_root", default="../dataset/AnimatedDrawings/preprocessed")
+    ap.add_argument("--uid_list_file", default="../dataset/AnimatedDrawings/drawings_uids.json")
+    ap.add_argument("--pose_dir", default=None, help=".../instant_nsr/datasets/fixed_poses")
+    ap.add_argument("--max_steps", type=int, default=3000)
+    ap.add_argument("--seed", type=int, default=123456)          # recon.py:30
+    args = ap.parse_args(argv)
+    rank, world, local = ddist.init()
+    dev = torch.device("cuda", local)
+    uids = json.load(open(args.uid_list_file)) if args.all else [args.uid]
+    for uid in ddist.shard(uids, rank, world):
+        ds = D.load_mv_prediction(os.path.join(args.data_root, uid, "mv"), dev, args.pose_dir)
+        system = OrthoNeuSSystem(device=dev, seed=args.seed)
+        system.fit(ds, max_steps=args.max_steps, log_every=500)
+        coarse, fine, vmin, vmax = system.export_levels()
+        out = os.path.join(args.data_root, uid, "mesh")
+        os.makedirs(out, exist_ok=True)
+        np.save(os.path.join(out, f"it{system.global_step}-sdf512_coarse.npy"), coarse.cpu().numpy())
+        np.save(os.path.join(out, f"it{system.global_step}-sdf512_fine.npy"), fine.cpu().numpy())
+        np.save(os.path.join(out, f"it{system.global_step}-sdf512_fine_bbox.npy"),
+                torch.stack([vmin, vmax]).cpu().numpy())
+        torch.save(system.model.state_dict(), os.path.join(out, f"it{system.global_step}.ckpt"))
+        print(uid, flush=True)
+
+
+if __name__ == "__main__":
+    main()

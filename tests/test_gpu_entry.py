@@ -1,0 +1,51 @@
+"""The reference's entry points (mv.py -> recon.py -> test_stage1.py -> test_stage2.py) on a
+synthetic uid directory: same CLI flags, same on-disk layout, files handed over through PNGs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+
+def _drawing(size=512):
+    g = np.random.default_rng(0)
+    a = np.zeros((size, size, 4), np.uint8)
+    a[..., :3] = np.kron(g.integers(0, 256, (size // 8, size // 8, 3)), np.ones((8, 8, 1))).astype(np.uint8)
+    yy, xx = np.mgrid[:size, :size]
+    a[..., 3] = ((((xx - size / 2) / (0.3 * size)) ** 2 + ((yy - size / 2) / (0.42 * size)) ** 2) <= 1) * 255
+    return Image.fromarray(a, "RGBA")
+
+
+def test_entry_points_chain(dev, tmp_path):
+    from drawingspinup_amd.entry import mv, recon, _test_stage
+    root, uid = str(tmp_path), "uid0"
+    os.makedirs(os.path.join(root, uid, "char"))
+    _drawing().save(os.path.join(root, uid, "char", "ffc_resnet_inpainted.png"))
+    mv.main(["--uid", uid, "--data_root", root, "--num_inference_steps", "2"])
+    for sub in ("color", "normal", "mask"):
+        files = sorted(os.listdir(os.path.join(root, uid, "mv", sub)))
+        assert files == sorted(f"{v}.png" for v in ("front", "front_right", "right", "back", "left", "front_left"))
+    assert Image.open(os.path.join(root, uid, "mv", "color", "front.png")).size == (1024, 1024)
+    recon.main(["--uid", uid, "--data_root", root, "--max_steps", "20"])
+    fine = np.load(os.path.join(root, uid, "mesh", "it20-sdf512_fine.npy"))
+    assert fine.shape == (512, 512, 512) and np.isfinite(fine).all()
+    sd = torch.load(os.path.join(root, uid, "mesh", "it20.ckpt"), map_location="cpu")
+    assert "geometry.encoding.encoding.encoding.params" in sd and "variance.variance" in sd
+    # stage 3 inputs: 2 synthetic frames (colour / pos / edge) in the blender_render layout
+    act = os.path.join(root, uid, "mesh", "blender_render", "dance")
+    for sub in ("color", "pos", "edge"):
+        os.makedirs(os.path.join(act, sub))
+    for f in range(2):
+        _drawing().save(os.path.join(act, "color", f"{f:04d}.png"))
+        _drawing().save(os.path.join(act, "pos", f"{f:04d}.png"))
+        Image.fromarray(np.full((512, 512), 255, np.uint8)).save(os.path.join(act, "edge", f"{f:04d}.png"))
+    _test_stage.run(1, ["--uid", uid, "--root_dir", root, "--random_init"])
+    s1 = Image.open(os.path.join(act, "res_stage1_mask_pos", "0000.png"))
+    assert s1.mode == "RGBA" and s1.size == (512, 512)
+    _test_stage.run(2, ["--uid", uid, "--root_dir", root, "--random_init"])
+    s2 = Image.open(os.path.join(act, "res_stage2_mask_pos_edge", "0001.png"))
+    assert s2.mode == "RGBA" and s2.size == (512, 512)
+    assert np.array_equal(np.array(s2)[..., 3], np.array(_drawing())[..., 3])      # alpha = input mask
