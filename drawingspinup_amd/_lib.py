@@ -30,6 +30,13 @@ class SdfMlp(C.Structure):
     _fields_ = [("w0", c_vp), ("b0", c_vp), ("w1", c_vp), ("b1", c_vp)]
 
 
+class RayLossCfg(C.Structure):
+    _fields_ = [("rgb_p_ratio", C.c_double), ("normal_p_ratio", C.c_double),
+                ("mask_p_ratio", C.c_double), ("lambda_rgb_mse", c_f32),
+                ("lambda_rgb_l1", c_f32), ("lambda_normal", c_f32), ("lambda_mask", c_f32),
+                ("geo_aware", c_i32), ("reserved", c_i32)]
+
+
 # name -> argtypes; every function returns int.  Kept in one table so that the CPU test
 # "the library exports every symbol the header declares" can walk it.
 P = c_vp
@@ -50,6 +57,10 @@ _PROTOS = {
     "dsu_ray_march_fill": [P, P, P, P, c_i64, P, P, c_i32, c_f32, P, P, P, P, P],
     "dsu_ray_march_scratch": [P, P, P, P, c_i64, P, P, c_i32, c_f32, c_i32, P, P, P, P],
     "dsu_ray_compact": [P, P, c_i32, P, P, c_i64, P, P, P, P],
+    "dsu_ray_compact_points": [P, P, c_i32, P, P, c_i64, P, P, P, P, P, P],
+    "dsu_ray_offsets": [P, c_i64, P, P, P],
+    "dsu_ray_losses": [P, P, P, P, P, P, c_i32, C.POINTER(RayLossCfg), P, P, P],
+    "dsu_sample_losses": [P, P, c_i64, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, P, P, P, P],
     "dsu_weights_from_alpha_fwd": [P, P, P, c_i64, P, P],
     "dsu_weights_from_alpha_bwd": [P, P, P, P, P, c_i64, P, P],
     "dsu_accumulate_fwd": [P, P, c_i32, P, P, c_i64, P, P],

@@ -8,6 +8,7 @@
 // (nerfacc/cuda/csrc/ray_marching.cu @ v0.3.3) and is mirrored by oracle/nerfacc_ref.py.
 #include "common.h"
 #include <math.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -19,30 +20,37 @@ struct Aabb {
                      // bit for bit, so the serial marching chain can avoid IEEE divisions
 };
 
+template <bool P2>
 __device__ __forceinline__ float div_ext(float x, const Aabb& a, int d) {
-  return a.pow2 ? x * a.inv_ext[d] : x / (a.mx[d] - a.mn[d]);
+  return P2 ? x * a.inv_ext[d] : x / (a.mx[d] - a.mn[d]);
 }
+template <bool P2>
 __device__ __forceinline__ float div_res(float x, const Aabb& a, int res, float inv_res) {
-  return a.pow2 ? x * inv_res : x / (float)res;
+  return P2 ? x * inv_res : x / (float)res;
 }
 
 __device__ __forceinline__ float signf1(float x) { return copysignf(1.0f, x); }
 
-__device__ __forceinline__ bool occupied_at(const float p[3], const Aabb& a,
-                                            const uint8_t* __restrict__ occ, int res) {
-  if (p[0] < a.mn[0] || p[0] > a.mx[0] || p[1] < a.mn[1] || p[1] > a.mx[1] || p[2] < a.mn[2] ||
-      p[2] > a.mx[2])
-    return false;
+// grid_occupied_at (nerfacc): false outside the roi, else the binary cell of the point.
+// Split in two so that the marcher can issue many lookups back to back: occ_cell() is pure
+// arithmetic (cell index clamped into range, so the load that follows is unconditional) and the
+// caller combines the loaded byte with `inside`.
+template <bool P2>
+__device__ __forceinline__ int occ_cell(const float p[3], const Aabb& a, int res, bool& inside) {
+  inside = !(p[0] < a.mn[0] || p[0] > a.mx[0] || p[1] < a.mn[1] || p[1] > a.mx[1] ||
+             p[2] < a.mn[2] || p[2] > a.mx[2]);
   int ix[3];
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    float u = div_ext(p[d] - a.mn[d], a, d);
+    float u = div_ext<P2>(p[d] - a.mn[d], a, d);
+    u = inside ? u : 0.0f;                       // keep the int conversion defined outside the roi
     int i = (int)(u * (float)res);
     ix[d] = min(max(i, 0), res - 1);
   }
-  return occ[(ix[0] * res + ix[1]) * res + ix[2]] != 0;
+  return (ix[0] * res + ix[1]) * res + ix[2];
 }
 
+template <bool P2>
 __device__ __forceinline__ float dist_to_next_voxel(const float p[3], const float dir[3],
                                                     const float inv_dir[3], const Aabb& a,
                                                     int res) {
@@ -50,8 +58,8 @@ __device__ __forceinline__ float dist_to_next_voxel(const float p[3], const floa
   const float inv_res = 1.0f / (float)res;
 #pragma unroll
   for (int d = 0; d < 3; ++d) {
-    float g = div_ext(p[d] - a.mn[d], a, d) * (float)res;
-    float td = div_res((floorf(g + 0.5f + 0.5f * signf1(dir[d])) - g) * inv_dir[d], a, res,
+    float g = div_ext<P2>(p[d] - a.mn[d], a, d) * (float)res;
+    float td = div_res<P2>((floorf(g + 0.5f + 0.5f * signf1(dir[d])) - g) * inv_dir[d], a, res,
                        inv_res) * (a.mx[d] - a.mn[d]);
     t = fminf(t, td);
   }
@@ -92,9 +100,32 @@ __global__ void ray_aabb_kernel(const float* __restrict__ ro, const float* __res
   tmax_o[i] = far;
 }
 
+// advance_to_next_voxel (nerfacc): from the rejected lattice point tm, keep the sample lattice and
+// move to the first lattice point at or beyond the next voxel boundary (pure arithmetic).
+template <bool P2>
+__device__ __forceinline__ float skip_voxel(float tm, const float o[3], const float d[3],
+                                            const float inv[3], const Aabb& a, int res, float dt,
+                                            float far) {
+  const float p[3] = {o[0] + tm * d[0], o[1] + tm * d[1], o[2] + tm * d[2]};
+  float target = tm + dist_to_next_voxel<P2>(p, d, inv, a, res);
+  target = fminf(target, far);
+  float tt = tm;
+  do { tt += dt; } while (tt < target);
+  return tt;
+}
+
 // MODE 0: count only; 1: fill at offsets[i]; 2: single pass — fill a fixed-capacity scratch row
 // (i * cap) AND write the count, so the serial march runs once (compacted by ray_compact_kernel)
-template <int MODE>
+//
+// One ray per lane, ~600 lattice points per ray, and the serial loop is ONE dependent occupancy
+// byte load (~250 ns measured, L2 hit) per lattice point or per skipped voxel: pure latency with
+// 32 waves on 256 CUs.  Both continuations of the recurrence are therefore computed ahead with
+// the same f32 operations the serial loop would execute (so the bits are the same):
+//   chain A: the next SPEC lattice points assuming every one is accepted,
+//   chain B: the next SB voxel skips assuming every landing point is rejected,
+// all SPEC+SB-1 occupancy bytes are fetched as independent loads, and the points are consumed in
+// order along whichever chain the first byte selects until the prediction fails.
+template <int MODE, bool HAS_OCC, bool P2, int SB>
 __global__ void ray_march_kernel(const float* __restrict__ ro, const float* __restrict__ rd,
                                  const float* __restrict__ tmin, const float* __restrict__ tmax,
                                  int64_t n, Aabb a, const uint8_t* __restrict__ occ, int res,
@@ -108,34 +139,100 @@ __global__ void ray_march_kernel(const float* __restrict__ ro, const float* __re
   const float d[3] = {rd[i * 3], rd[i * 3 + 1], rd[i * 3 + 2]};
   const float inv[3] = {1.0f / d[0], 1.0f / d[1], 1.0f / d[2]};
   const float near = tmin[i], far = tmax[i];
-  constexpr bool FILL = MODE != 0;
   int64_t base = 0;
   if (MODE == 1) base = offsets[i];
   if (MODE == 2) base = i * (int64_t)cap;
   const float dt = step;  // cone_angle == 0: calc_dt clamps to dt_min
   int j = 0;
   float t0 = near, t1 = t0 + dt, tm = (t0 + t1) * 0.5f;
+  constexpr int SPEC = 8;
   while (tm < far) {
-    const float p[3] = {o[0] + tm * d[0], o[1] + tm * d[1], o[2] + tm * d[2]};
-    if (occ == nullptr || occupied_at(p, a, occ, res)) {
-      if (MODE == 1 || (MODE == 2 && j < cap)) {
-        t_starts[base + j] = t0;
-        t_ends[base + j] = t1;
-        if (MODE == 1) ray_indices[base + j] = i;
-      }
-      ++j;
-      t0 = t1;
-      t1 = t0 + dt;
-      tm = (t0 + t1) * 0.5f;
-    } else {
-      // advance_to_next_voxel: keep the sample lattice, skip to the first lattice point
-      // at or beyond the next voxel boundary
-      float target = tm + dist_to_next_voxel(p, d, inv, a, res);
-      target = fminf(target, far);
-      do { tm += dt; } while (tm < target);
-      t0 = tm - dt * 0.5f;
-      t1 = tm + dt * 0.5f;
+    // ---- chain A: lattice points under "accepted"
+    float At0[SPEC], At1[SPEC], Atm[SPEC];
+    float a0 = t0, a1 = t1, am = tm;
+#pragma unroll
+    for (int b = 0; b < SPEC; ++b) {
+      At0[b] = a0; At1[b] = a1; Atm[b] = am;
+      a0 = a1;
+      a1 = a0 + dt;
+      am = (a0 + a1) * 0.5f;
     }
+    bool Aocc[SPEC];
+    if (HAS_OCC) {
+      int Ai[SPEC];
+      bool Ain[SPEC];
+#pragma unroll
+      for (int b = 0; b < SPEC; ++b) {
+        const float p[3] = {o[0] + Atm[b] * d[0], o[1] + Atm[b] * d[1], o[2] + Atm[b] * d[2]};
+        Ai[b] = occ_cell<P2>(p, a, res, Ain[b]);
+      }
+      uint32_t Av[SPEC];
+#pragma unroll
+      for (int b = 0; b < SPEC; ++b) Av[b] = occ[Ai[b]];
+      // ---- chain B: landing points of successive voxel skips under "rejected"
+      float Btm[SB + 1];
+      uint32_t Bv[SB];
+      bool Bin[SB];
+      Btm[0] = tm;
+      Bv[0] = 0;
+      Bin[0] = false;
+#pragma unroll
+      for (int k = 0; k < SB; ++k) {
+        Btm[k + 1] = skip_voxel<P2>(Btm[k], o, d, inv, a, res, dt, far);
+        if (k + 1 < SB) {
+          const float t = Btm[k + 1];
+          const float p[3] = {o[0] + t * d[0], o[1] + t * d[1], o[2] + t * d[2]};
+          const int ci = occ_cell<P2>(p, a, res, Bin[k + 1]);
+          Bv[k + 1] = occ[ci];
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < SPEC; ++b) Aocc[b] = Ain[b] && Av[b] != 0;
+      if (!Aocc[0]) {
+        // the current point is rejected: walk the skip chain while the landing points stay
+        // empty; stop on the first one that is occupied or past the far plane (it becomes the
+        // current point of the next round)
+        float nt = Btm[SB];
+        bool alive = true;
+#pragma unroll
+        for (int k = 1; k < SB; ++k) {
+          if (alive && (!(Btm[k] < far) || (Bin[k] && Bv[k] != 0))) {
+            nt = Btm[k];
+            alive = false;
+          }
+        }
+        tm = nt;
+        t0 = tm - dt * 0.5f;
+        t1 = tm + dt * 0.5f;
+        continue;
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < SPEC; ++b) Aocc[b] = true;
+    }
+    bool alive = true;
+#pragma unroll
+    for (int b = 0; b < SPEC; ++b) {
+      if (alive) {
+        if (!(Atm[b] < far)) {          // the serial loop's exit test
+          t0 = At0[b]; t1 = At1[b]; tm = Atm[b];
+          alive = false;
+        } else if (Aocc[b]) {
+          if (MODE == 1 || (MODE == 2 && j < cap)) {
+            t_starts[base + j] = At0[b];
+            t_ends[base + j] = At1[b];
+            if (MODE == 1) ray_indices[base + j] = i;
+          }
+          ++j;
+        } else {
+          tm = skip_voxel<P2>(Atm[b], o, d, inv, a, res, dt, far);
+          t0 = tm - dt * 0.5f;
+          t1 = tm + dt * 0.5f;
+          alive = false;
+        }
+      }
+    }
+    if (alive) { t0 = a0; t1 = a1; tm = am; }   // all SPEC points accepted
   }
   if (MODE != 1) num_steps[i] = j;
 }
@@ -158,6 +255,31 @@ __global__ __launch_bounds__(256) void ray_compact_kernel(const float* __restric
     t_starts[b + j] = t0s[r * cap + j];
     t_ends[b + j] = t1s[r * cap + j];
     ray_indices[b + j] = r;
+  }
+}
+
+// compaction that also emits the sample positions the reference builds with
+// rays_o[ray_indices] + rays_d[ray_indices] * ((t_starts + t_ends) / 2)   (neus.py:131-134)
+__global__ __launch_bounds__(256) void ray_compact_points_kernel(
+    const float* __restrict__ t0s, const float* __restrict__ t1s, int cap,
+    const int32_t* __restrict__ off, const int32_t* __restrict__ cnt, int64_t n_rays,
+    const float* __restrict__ ro, const float* __restrict__ rd, float* __restrict__ t_starts,
+    float* __restrict__ t_ends, float* __restrict__ positions) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n_rays) return;
+  const int64_t b = off[r];
+  const int c = cnt[r];
+  const float o[3] = {ro[r * 3], ro[r * 3 + 1], ro[r * 3 + 2]};
+  const float d[3] = {rd[r * 3], rd[r * 3 + 1], rd[r * 3 + 2]};
+  for (int j = lane; j < c; j += 64) {
+    const float t0 = t0s[r * cap + j], t1 = t1s[r * cap + j];
+    t_starts[b + j] = t0;
+    t_ends[b + j] = t1;
+    const float mid = (t0 + t1) / 2.0f;
+    positions[(b + j) * 3 + 0] = o[0] + d[0] * mid;
+    positions[(b + j) * 3 + 1] = o[1] + d[1] * mid;
+    positions[(b + j) * 3 + 2] = o[2] + d[2] * mid;
   }
 }
 
@@ -491,6 +613,33 @@ Aabb make_aabb(const float* a6, int res = 1) {
 
 }  // namespace
 
+// march kernel variant: occupancy grid present or not, power-of-two box (exact reciprocal
+// multiplies instead of IEEE divisions), skip-chain length (DSU_MARCH_SB=4|8, default 4)
+static int march_sb() {
+  static int v = 0;
+  if (!v) {
+    const char* e = getenv("DSU_MARCH_SB");
+    v = (e && atoi(e) == 8) ? 8 : 4;
+  }
+  return v;
+}
+#define DSU_MARCH_ONE(M, O, P, S, nr, st, ...) \
+  ray_march_kernel<M, O, P, S><<<dsu_blocks_for(nr, 64), 64, 0, (hipStream_t)st>>>(__VA_ARGS__)
+#define DSU_LAUNCH_MARCH(M, nr, st, box, occp, ...)                                   \
+  do {                                                                                \
+    const bool p2_ = (box).pow2 != 0;                                                 \
+    if (!(occp)) {                                                                    \
+      if (p2_) DSU_MARCH_ONE(M, false, true, 4, nr, st, __VA_ARGS__);                 \
+      else DSU_MARCH_ONE(M, false, false, 4, nr, st, __VA_ARGS__);                    \
+    } else if (march_sb() == 8) {                                                     \
+      if (p2_) DSU_MARCH_ONE(M, true, true, 8, nr, st, __VA_ARGS__);                  \
+      else DSU_MARCH_ONE(M, true, false, 8, nr, st, __VA_ARGS__);                     \
+    } else {                                                                          \
+      if (p2_) DSU_MARCH_ONE(M, true, true, 4, nr, st, __VA_ARGS__);                  \
+      else DSU_MARCH_ONE(M, true, false, 4, nr, st, __VA_ARGS__);                     \
+    }                                                                                 \
+  } while (0)
+
 extern "C" {
 
 int dsu_ray_aabb(const float* rays_o, const float* rays_d, int64_t n_rays, const float* aabb6,
@@ -511,9 +660,10 @@ int dsu_ray_march_count(const float* rays_o, const float* rays_d, const float* t
   if (n_rays < 0 || !aabb6 || !(step > 0.0f) || (occ_binary && res <= 0)) return DSU_EINVAL;
   if (n_rays && (!rays_o || !rays_d || !t_min || !t_max || !num_steps)) return DSU_EINVAL;
   if (n_rays == 0) return DSU_OK;
-  ray_march_kernel<0><<<dsu_blocks_for(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
-      rays_o, rays_d, t_min, t_max, n_rays, make_aabb(aabb6, occ_binary ? res : 1), occ_binary, res, step, nullptr, 0,
-      num_steps, nullptr, nullptr, nullptr);
+  const Aabb box = make_aabb(aabb6, occ_binary ? res : 1);
+  DSU_LAUNCH_MARCH(0, n_rays, stream, box, occ_binary, rays_o, rays_d, t_min, t_max,
+                   n_rays, box,
+                   occ_binary, res, step, nullptr, 0, num_steps, nullptr, nullptr, nullptr);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }
@@ -526,9 +676,10 @@ int dsu_ray_march_fill(const float* rays_o, const float* rays_d, const float* t_
   if (n_rays < 0 || !aabb6 || !(step > 0.0f) || (occ_binary && res <= 0)) return DSU_EINVAL;
   if (n_rays && (!rays_o || !rays_d || !t_min || !t_max || !offsets)) return DSU_EINVAL;
   if (n_rays == 0) return DSU_OK;
-  ray_march_kernel<1><<<dsu_blocks_for(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
-      rays_o, rays_d, t_min, t_max, n_rays, make_aabb(aabb6, occ_binary ? res : 1), occ_binary, res, step, offsets, 0,
-      nullptr, ray_indices, t_starts, t_ends);
+  const Aabb box = make_aabb(aabb6, occ_binary ? res : 1);
+  DSU_LAUNCH_MARCH(1, n_rays, stream, box, occ_binary, rays_o, rays_d, t_min, t_max,
+                   n_rays, box,
+                   occ_binary, res, step, offsets, 0, nullptr, ray_indices, t_starts, t_ends);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }
@@ -544,9 +695,10 @@ int dsu_ray_march_scratch(const float* rays_o, const float* rays_d, const float*
                  !scratch_t_ends))
     return DSU_EINVAL;
   if (n_rays == 0) return DSU_OK;
-  ray_march_kernel<2><<<dsu_blocks_for(n_rays, 64), 64, 0, (hipStream_t)stream>>>(
-      rays_o, rays_d, t_min, t_max, n_rays, make_aabb(aabb6, occ_binary ? res : 1), occ_binary,
-      res, step, nullptr, capacity, num_steps, nullptr, scratch_t_starts, scratch_t_ends);
+  const Aabb box = make_aabb(aabb6, occ_binary ? res : 1);
+  DSU_LAUNCH_MARCH(2, n_rays, stream, box, occ_binary, rays_o, rays_d, t_min, t_max,
+                   n_rays, box,
+                   occ_binary, res, step, nullptr, capacity, num_steps, nullptr, scratch_t_starts, scratch_t_ends);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }
@@ -560,6 +712,22 @@ int dsu_ray_compact(const float* scratch_t_starts, const float* scratch_t_ends, 
   ray_compact_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, (hipStream_t)stream>>>(
       scratch_t_starts, scratch_t_ends, capacity, offsets, counts, n_rays, ray_indices, t_starts,
       t_ends);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_ray_compact_points(const float* scratch_t_starts, const float* scratch_t_ends,
+                           int32_t capacity, const int32_t* offsets, const int32_t* counts,
+                           int64_t n_rays, const float* rays_o, const float* rays_d,
+                           float* t_starts, float* t_ends, float* positions, void* stream) {
+  if (n_rays < 0 || capacity <= 0) return DSU_EINVAL;
+  if (n_rays && (!scratch_t_starts || !scratch_t_ends || !offsets || !counts || !rays_o ||
+                 !rays_d || !t_starts || !t_ends || !positions))
+    return DSU_EINVAL;
+  if (n_rays == 0) return DSU_OK;
+  ray_compact_points_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, (hipStream_t)stream>>>(
+      scratch_t_starts, scratch_t_ends, capacity, offsets, counts, n_rays, rays_o, rays_d,
+      t_starts, t_ends, positions);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }

@@ -13,6 +13,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .. import ops
 from .model import Cfg, NeuSModel
 
 DEFAULT_SYSTEM_CONFIG = Cfg({     # configs/neuralangelo-ortho-wmask.yaml:86-141
@@ -222,7 +223,11 @@ class OrthoNeuSSystem:
         oc = self.config.optimizer
         groups = [{"params": list(getattr(self.model, n).parameters()), "name": n, "lr": lr}
                   for n, lr in oc.params.items()]
-        self.optimizer = torch.optim.AdamW(groups, lr=oc.lr, betas=tuple(oc.betas), eps=oc.eps)
+        # same update rule as the reference's torch.optim.AdamW; the fused (single-launch per
+        # group) implementation on the GPU instead of ~10 foreach launches per group
+        fused = self.device.type == "cuda" and os.environ.get("DSU_ADAM", "fused") == "fused"
+        self.optimizer = torch.optim.AdamW(groups, lr=oc.lr, betas=tuple(oc.betas), eps=oc.eps,
+                                           **({"fused": True} if fused else {}))
         self._base_lrs = [g["lr"] for g in groups]
         # ExponentialLR gamma = 0.1 ** (1 / (max_steps - constant_steps))  (recon.py:13)
         self._gamma = 0.1 ** (1.0 / (self.config.max_steps - self.config.constant_steps))
@@ -230,6 +235,10 @@ class OrthoNeuSSystem:
         self.last = {}
         self.use_loss_graph = os.environ.get("DSU_NO_GRAPH", "0") != "1" and self.device.type == "cuda"
         self._loss_graph = None
+        # "fused": forward and backward of a step driven kernel by kernel (no autograd graph
+        # except for the texture MLP and the tiny weight-norm / variance chains);
+        # "autograd": the op-by-op step through torch.autograd (cross-check, same numbers)
+        self.step_mode = os.environ.get("DSU_STEP", "fused")
 
     # ----------------------------------------------------------------- data
     def preprocess_data(self, index=None, x=None, y=None):
@@ -314,6 +323,122 @@ class OrthoNeuSSystem:
             g["lr"] = base * f
 
     def training_step(self, inject=None):
+        if self.step_mode == "fused" and self.model.fused_shading \
+                and self.train_num_rays <= ops.RAY_LOSS_MAX_RAYS:
+            return self.training_step_fused(inject)
+        return self.training_step_autograd(inject)
+
+    def training_step_fused(self, inject=None):
+        """Same step as training_step_autograd (neus_ortho.py:84-160 + the model forward
+        neus.py:115-196), with the backward pass sequenced by hand over the fused kernels:
+        march(+positions) -> geometry (7-eval fused) -> shading prep -> texture MLP -> compositing
+        -> ray losses (+d/d comp) -> compositing bwd -> texture bwd -> shading bwd -> sample
+        losses (+gradients) -> geometry bwd -> weight-norm / variance chains -> AdamW."""
+        from .render import RayPacking
+        m, L = self.model, self.config.loss
+        geo, enc = m.geometry, m.geometry.hashgrid
+        m.train()
+        inject = inject or {}
+        batch = self.preprocess_data(inject.get("index"), inject.get("x"), inject.get("y"))
+        m.update_step(0, self.global_step)
+        rays = batch["rays"]
+        dev = rays.device
+        rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
+        n_rays = rays.shape[0]
+        jitter = inject.get("jitter")
+        if jitter is None and m.randomized:
+            jitter = torch.rand(n_rays, device=dev)
+        pts_random, perturb = inject.get("pts_random"), inject.get("perturb")
+        if pts_random is None:
+            pts_random = torch.rand([1024 * 2, 3], device=dev) * 2 - 1
+        if perturb is None:
+            perturb = torch.randn_like(pts_random)
+        n_r = pts_random.shape[0]
+        with torch.no_grad():
+            tmin, tmax = ops.ray_aabb(rays_o, rays_d, m._aabb_host,
+                                      jitter if m.randomized else None, m.render_step_size)
+            occ, res = None, 0
+            if m.config.grid_prune:
+                occ, res = m.occupancy_grid.binary_u8(), m.occupancy_grid.res
+            allp, ts, te, off, cnt, n_s = ops.ray_march_points(
+                rays_o, rays_d, tmin, tmax, m._aabb_host, occ, res, m.render_step_size,
+                tail_rows=2 * n_r)
+            RayPacking.total = n_s
+            allp[n_s:n_s + n_r] = pts_random
+            torch.add(pts_random, perturb, alpha=1e-2, out=allp[n_s + n_r:])
+        n_all = n_s + 2 * n_r
+        if m.config.dynamic_ray_sampling and n_s > 0:
+            tr = int(self.train_num_rays * (self.train_num_samples / n_s))
+            self.train_num_rays = min(int(self.train_num_rays * 0.9 + tr * 0.1),
+                                      m.config.max_train_num_rays)
+        self._set_lr()
+        self.optimizer.zero_grad(set_to_none=True)
+
+        # ---- forward
+        w0, b0, w1, b1 = geo._mlp()                      # weight-norm chain (autograd, tiny)
+        mlp = [t.detach().contiguous() for t in (w0, b0, w1, b1)]
+        table = enc.table_f16()
+        eps, active = geo._finite_difference_eps, geo.active_levels
+        inv_s = m.variance.inv_s
+        with torch.no_grad():
+            a_sdf, a_grad, a_feat, _ = ops.sdf_fd_fwd(enc.cfg, table, mlp, allp, geo.radius, eps,
+                                                      active, True, True, False)
+            normal, tex_in = ops.shade_prep_fwd(a_grad[:n_s], a_feat[:n_s])
+        tex_in.requires_grad_(True)
+        rgb = torch.sigmoid(m.texture.mlp_split_k(tex_in))
+        with torch.no_grad():
+            rgb_d = rgb.detach()
+            inv_d = inv_s.detach().reshape(1)
+            car = float(m.cos_anneal_ratio)
+            comp, alpha, w = ops.neus_composite_fwd(a_sdf[:n_s], normal, rgb_d, rays_d, ts, te, off,
+                                                    cnt, inv_d, car)
+            rterms, d_comp = ops.ray_losses(
+                comp, batch["rgb"], batch["normal"], batch["mask"], batch["cosines"],
+                batch["view_weights"],
+                {"rgb_p_ratio": L.rgb_p_ratio, "normal_p_ratio": L.normal_p_ratio,
+                 "mask_p_ratio": L.mask_p_ratio, "lambda_rgb_mse": L.lambda_rgb_mse,
+                 "lambda_rgb_l1": L.lambda_rgb_l1 or 0.0, "lambda_normal": L.lambda_normal,
+                 "lambda_mask": L.lambda_mask if self.dataset.has_mask else 0.0,
+                 "geo_aware": L.geo_aware})
+            # ---- backward
+            d_sdf_all = torch.empty(n_all, device=dev)
+            d_grad_all = torch.empty(n_all, 3, device=dev)
+            d_feat_all = torch.empty(n_all, 13, device=dev)
+            d_feat_all[n_s:].zero_()
+            _, d_normal, d_rgb, d_inv = ops.neus_composite_bwd(
+                a_sdf[:n_s], normal, rgb_d, rays_d, ts, te, off, cnt, inv_d, car, alpha, w, d_comp,
+                None, d_sdf_out=d_sdf_all[:n_s])
+        torch.autograd.backward([rgb, inv_s], [d_rgb, d_inv.view_as(inv_s)])
+        with torch.no_grad():
+            ops.shade_prep_bwd(a_grad[:n_s], d_normal, tex_in.grad,
+                               out=(d_grad_all[:n_s], d_feat_all[:n_s]))
+            smooth = L.lambda_3d_normal_smooth if L.lambda_3d_normal_smooth > 0 else 0.0
+            sterms, _, _ = ops.sample_losses(a_sdf, a_grad, n_s, n_r, L.lambda_eikonal,
+                                             L.lambda_sparsity, L.sparsity_scale, smooth,
+                                             d_sdf_all, d_grad_all)
+            g_table, g = ops.sdf_fd_bwd(enc.cfg, table, mlp, allp, geo.radius, eps, active,
+                                        d_sdf_all, d_grad_all, d_feat_all, None)
+        enc.params.grad = g_table
+        lin0, lin1 = [l for l in geo.network.layers if isinstance(l, torch.nn.Linear)]
+        if w0.requires_grad and w0.grad_fn is not None:
+            torch.autograd.backward([w0, w1], [g[0], g[2]])
+        else:                                            # no weight norm: w is the parameter
+            lin0.weight.grad, lin1.weight.grad = g[0], g[2]
+        lin0.bias.grad, lin1.bias.grad = g[1], g[3]
+        self.optimizer.step()
+        self.global_step += 1
+        terms = {"rgb_mse": rterms[0]}
+        if L.lambda_rgb_l1:
+            terms["rgb_l1"] = rterms[1]
+        terms.update({"normal": rterms[2], "mask": rterms[3], "eikonal": sterms[0],
+                      "sparsity": sterms[1]})
+        if L.lambda_3d_normal_smooth > 0:
+            terms["normal_smooth"] = sterms[2]
+        loss = rterms.sum() + sterms.sum()
+        self.last = {"loss": loss, "n_samples": n_s, "n_rays": n_rays, **terms}
+        return self.last
+
+    def training_step_autograd(self, inject=None):
         """One step.  `inject` (tests) = dict(index,x,y,jitter,pts_random,perturb) replaces the
         device RNG draws so that a step is reproducible against the oracle."""
         self.model.train()

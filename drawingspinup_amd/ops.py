@@ -10,7 +10,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import HashGridCfg, SdfMlp, check, lib, ptr, stream
+from ._lib import DsuError, HashGridCfg, SdfMlp, check, lib, ptr, stream
 
 
 @dataclass(frozen=True)
@@ -113,7 +113,9 @@ def sdf_fd_bwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, d_sdf, d_gr
     w0, b0, w1, b1 = mlp
     if grad_table is None:
         grad_table = torch.zeros(cfg.n_params, dtype=torch.float32, device=dev)
-    g = [torch.zeros_like(t) for t in (w0, b0, w1, b1)]
+    sizes = [t.numel() for t in (w0, b0, w1, b1)]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)      # one memset
+    g = [v.view_as(t) for v, t in zip(torch.split(flat, sizes), (w0, b0, w1, b1))]
     c, m = cfg.c(), _mlp_struct(*mlp)
     d = [None if t is None else _f32c(t) for t in (d_sdf, d_grad, d_feature, d_laplace)]
     wbytes = lib().dsu_sdf_fd_bwd_workspace_bytes(C.byref(c), n)
@@ -206,6 +208,92 @@ def ray_march_single_pass(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, 
                                     ptr(ray_indices), ptr(t_starts), ptr(t_ends), stream()),
               "dsu_ray_compact")
     return ray_indices, t_starts, t_ends, offsets, counts
+
+
+def ray_march_points(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step, tail_rows=0):
+    """Single-pass march for the fused optimisation step: returns
+    (points (total + tail_rows, 3), t_starts, t_ends, offsets, counts, total) where
+    points[:total] = rays_o[r] + rays_d[r] * (t_start + t_end) / 2 and the tail rows are left for
+    the caller (random / perturbed points evaluated in the same geometry launch).  One host copy
+    (total, max count); no ray_indices."""
+    import math
+    rays_o, rays_d = _f32c(rays_o), _f32c(rays_d)
+    n = rays_o.shape[0]
+    dev = rays_o.device
+    a = (C.c_float * 6)(*[float(v) for v in aabb6])
+    diag = math.sqrt(sum((aabb6[3 + d] - aabb6[d]) ** 2 for d in range(3)))
+    cap = int(diag / step) + 8
+    key = (str(dev), cap)
+    sc = _MARCH_SCRATCH.get(key)
+    if sc is None or sc[0].shape[0] < n * cap:
+        rows = max(n, 8192)
+        sc = (torch.empty(rows * cap, dtype=torch.float32, device=dev),
+              torch.empty(rows * cap, dtype=torch.float32, device=dev))
+        _MARCH_SCRATCH[key] = sc
+    counts = torch.empty(n, dtype=torch.int32, device=dev)
+    offsets = torch.empty(n, dtype=torch.int32, device=dev)
+    stats = torch.empty(2, dtype=torch.int32, device=dev)
+    occp = ptr(occ_binary, torch.uint8) if occ_binary is not None else None
+    check(lib().dsu_ray_march_scratch(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), n, a, occp,
+                                      int(res), float(step), cap, ptr(counts), ptr(sc[0]),
+                                      ptr(sc[1]), stream()), "dsu_ray_march_scratch")
+    check(lib().dsu_ray_offsets(ptr(counts), n, ptr(offsets), ptr(stats), stream()),
+          "dsu_ray_offsets")
+    total, cmax = stats.tolist()                                  # the step's one host sync
+    if cmax > cap:
+        raise DsuError(f"a ray produced {cmax} samples, above the scratch capacity {cap}")
+    points = torch.empty(total + tail_rows, 3, dtype=torch.float32, device=dev)
+    t_starts = torch.empty(total, dtype=torch.float32, device=dev)
+    t_ends = torch.empty(total, dtype=torch.float32, device=dev)
+    if total > 0:
+        check(lib().dsu_ray_compact_points(ptr(sc[0]), ptr(sc[1]), cap, ptr(offsets), ptr(counts),
+                                           n, ptr(rays_o), ptr(rays_d), ptr(t_starts),
+                                           ptr(t_ends), ptr(points), stream()),
+              "dsu_ray_compact_points")
+    return points, t_starts, t_ends, offsets, counts, total
+
+
+RAY_LOSS_MAX_RAYS = 8192      # DSU_RAY_LOSS_MAX_RAYS (include/dsu_hip.h)
+
+
+def ray_losses(comp, rgb, normal, mask, cosines, view_weights, cfg):
+    """Fused ray-level loss terms + d/d comp.  cfg: dict with rgb_p_ratio, normal_p_ratio,
+    mask_p_ratio, lambda_rgb_mse, lambda_rgb_l1, lambda_normal, lambda_mask, geo_aware.
+    Returns (terms (4,) = [rgb_mse, rgb_l1, normal, mask], d_comp (R,8))."""
+    from ._lib import RayLossCfg
+    comp = _f32c(comp)
+    r = comp.shape[0]
+    c = RayLossCfg(float(cfg["rgb_p_ratio"]), float(cfg["normal_p_ratio"]),
+                   float(cfg["mask_p_ratio"]), float(cfg["lambda_rgb_mse"]),
+                   float(cfg["lambda_rgb_l1"]), float(cfg["lambda_normal"]),
+                   float(cfg["lambda_mask"]), int(bool(cfg["geo_aware"])), 0)
+    terms = torch.empty(4, dtype=torch.float32, device=comp.device)
+    d_comp = torch.empty_like(comp)
+    check(lib().dsu_ray_losses(ptr(comp), ptr(_f32c(rgb)), ptr(_f32c(normal)), ptr(_f32c(mask)),
+                               ptr(_f32c(cosines)), ptr(_f32c(view_weights)), r, C.byref(c),
+                               ptr(terms), ptr(d_comp), stream()), "dsu_ray_losses")
+    return terms, d_comp
+
+
+def sample_losses(sdf_all, grad_all, n_samples, n_random, lambda_eikonal, lambda_sparsity,
+                  sparsity_scale, lambda_smooth, d_sdf_all=None, d_grad_all=None):
+    """Fused sample-level loss terms + gradients.  With d_sdf_all / d_grad_all given, their
+    first n_samples rows already hold the compositing / shading gradients and the eikonal part
+    is added; otherwise fresh tensors are returned.
+    Returns (terms (3,) = [eikonal, sparsity, normal_smooth], d_sdf_all, d_grad_all)."""
+    sdf_all, grad_all = _f32c(sdf_all), _f32c(grad_all)
+    acc = d_sdf_all is not None
+    if not acc:
+        d_sdf_all = torch.empty_like(sdf_all)
+        d_grad_all = torch.empty_like(grad_all)
+    assert sdf_all.shape[0] == n_samples + 2 * n_random
+    terms = torch.empty(3, dtype=torch.float32, device=sdf_all.device)
+    check(lib().dsu_sample_losses(ptr(sdf_all), ptr(grad_all), n_samples, n_random,
+                                  float(lambda_eikonal), float(lambda_sparsity),
+                                  float(sparsity_scale), float(lambda_smooth), int(acc),
+                                  ptr(d_sdf_all, torch.float32), ptr(d_grad_all, torch.float32),
+                                  ptr(terms), stream()), "dsu_sample_losses")
+    return terms, d_sdf_all, d_grad_all
 
 
 def weights_from_alpha_fwd(alpha, offsets, counts):
@@ -386,11 +474,17 @@ def shade_prep_fwd(grad, feature):
     return normal, tex_in
 
 
-def shade_prep_bwd(grad, d_normal, d_tex_in):
+def shade_prep_bwd(grad, d_normal, d_tex_in, out=None):
+    """out = (d_grad (n,3), d_feat (n,13)) preallocated contiguous f32 (e.g. row prefixes of the
+    buffers the geometry backward consumes)."""
     grad = _f32c(grad)
     n = grad.shape[0]
-    d_grad = torch.empty((n, 3), dtype=torch.float32, device=grad.device)
-    d_feat = torch.empty((n, 13), dtype=torch.float32, device=grad.device)
+    if out is None:
+        d_grad = torch.empty((n, 3), dtype=torch.float32, device=grad.device)
+        d_feat = torch.empty((n, 13), dtype=torch.float32, device=grad.device)
+    else:
+        d_grad, d_feat = out
+        assert d_grad.shape == (n, 3) and d_feat.shape == (n, 13)
     dn = None if d_normal is None else _f32c(d_normal)
     check(lib().dsu_shade_prep_bwd(ptr(grad), ptr(dn), ptr(_f32c(d_tex_in)), n, ptr(d_grad),
                                    ptr(d_feat), stream()), "dsu_shade_prep_bwd")
@@ -412,10 +506,11 @@ def neus_composite_fwd(sdf, normal, rgb, rays_d, t_starts, t_ends, offsets, coun
 
 
 def neus_composite_bwd(sdf, normal, rgb, rays_d, t_starts, t_ends, offsets, counts, inv_s, car,
-                       alpha, weights, d_comp, d_weights=None):
+                       alpha, weights, d_comp, d_weights=None, d_sdf_out=None):
     n, n_rays = sdf.shape[0], rays_d.shape[0]
     dev = sdf.device
-    d_sdf = torch.empty(n, dtype=torch.float32, device=dev)
+    d_sdf = torch.empty(n, dtype=torch.float32, device=dev) if d_sdf_out is None else d_sdf_out
+    assert d_sdf.shape == (n,)
     d_normal = torch.empty((n, 3), dtype=torch.float32, device=dev)
     d_rgb = torch.empty((n, 3), dtype=torch.float32, device=dev)
     d_inv = torch.zeros(1, dtype=torch.float32, device=dev)

@@ -158,6 +158,19 @@ int dsu_ray_compact(const float* scratch_t_starts, const float* scratch_t_ends, 
                     const int32_t* offsets, const int32_t* counts, int64_t n_rays,
                     int64_t* ray_indices, float* t_starts, float* t_ends, void* stream);
 
+/* dsu_ray_compact that also writes the sample positions
+ * rays_o[r] + rays_d[r] * ((t_start + t_end) / 2)  (neus.py:131-134: t_origins, t_dirs,
+ * midpoints, positions) and no ray_indices — the fused step addresses samples by (offsets,
+ * counts) only. */
+int dsu_ray_compact_points(const float* scratch_t_starts, const float* scratch_t_ends,
+                           int32_t capacity, const int32_t* offsets, const int32_t* counts,
+                           int64_t n_rays, const float* rays_o, const float* rays_d,
+                           float* t_starts, float* t_ends, float* positions, void* stream);
+/* offsets = exclusive prefix sum of counts; stats[0] = total, stats[1] = max(counts)
+ * (nerfacc's packed_info construction; one launch, read back with ONE host copy). */
+int dsu_ray_offsets(const int32_t* counts, int64_t n_rays, int32_t* offsets, int32_t* stats,
+                    void* stream);
+
 /* render_weight_from_alpha (neus.py:147): per ray segment [offsets[r], offsets[r]+cnt[r])
  * w_i = alpha_i * prod_{j<i}(1-alpha_j).  One ray per thread. */
 int dsu_weights_from_alpha_fwd(const float* alpha, const int32_t* offsets, const int32_t* counts,
@@ -207,6 +220,44 @@ int dsu_shade_prep_fwd(const float* grad, const float* feature, int64_t n, float
                        float* tex_in, void* stream);
 int dsu_shade_prep_bwd(const float* grad, const float* d_normal, const float* d_tex_in, int64_t n,
                        float* d_grad, float* d_feature, void* stream);
+
+/* Ray-level loss terms of OrthoNeuSSystem.training_step
+ * (2_charactor_reconstructor/instant_nsr/systems/neus_ortho.py:94-133 with
+ * systems/criterions.py:4-27) and their gradient w.r.t. the raw composite
+ * comp (R,8) = [opacity, depth, rgb(3), sum w*normal(3)], in ONE launch:
+ *   terms[0] rgb_mse  = ranking(sum_c (rgb-gt)^2 | fg, rgb_p_ratio, mean) * lambda_rgb_mse
+ *   terms[1] rgb_l1   = ranking(sum_c |rgb-gt|   | fg, rgb_p_ratio, mean) * lambda_rgb_l1
+ *   terms[2] normal   = ranking(1-cos(normalize(n), gt) [* exp|cos'| / sum exp|cos'| if
+ *                       geo_aware] | fg, normal_p_ratio, view_weights, sum|mean) * lambda_normal
+ *   terms[3] mask     = ranking(BCE(clamp(opacity,1e-3,1-1e-3), mask) | all, mask_p_ratio,
+ *                       view_weights, mean) * lambda_mask
+ * fg = mask > 0 and cosines < -0.1.  ranking() reproduces criterions.py:16-27 exactly,
+ * including its selection rule (sorted errors indexed with the original positions of the k
+ * smallest; k = int(ratio * count)).  n_rays <= DSU_RAY_LOSS_MAX_RAYS. */
+#define DSU_RAY_LOSS_MAX_RAYS 8192
+typedef struct dsu_ray_loss_cfg {
+  double rgb_p_ratio, normal_p_ratio, mask_p_ratio;
+  float lambda_rgb_mse, lambda_rgb_l1, lambda_normal, lambda_mask;
+  int32_t geo_aware;
+  int32_t reserved;
+} dsu_ray_loss_cfg;
+int dsu_ray_losses(const float* comp, const float* rgb, const float* normal, const float* mask,
+                   const float* cosines, const float* view_weights, int32_t n_rays,
+                   const dsu_ray_loss_cfg* cfg, float* terms, float* d_comp, void* stream);
+
+/* Sample-level terms (neus_ortho.py:118-151) over the concatenated evaluation
+ * [n_samples ray samples | n_random random points | n_random perturbed copies]:
+ *   terms[0] eikonal       = mean_i (|grad_i| - 1)^2            * lambda_eikonal   (samples)
+ *   terms[1] sparsity      = mean_r exp(-scale |sdf_r|)         * lambda_sparsity  (random)
+ *   terms[2] normal_smooth = mean_{r,c} |grad_r - grad_perturbed_r| * lambda_smooth
+ * and their gradients: d_grad_all[:n_samples] += eikonal part when accumulate_prefix != 0
+ * (the compositing/shading backward has already written it; d_sdf_all[:n_samples] is left
+ * untouched) or = when 0 (then d_sdf_all[:n_samples] = 0); the random / perturbed rows of
+ * d_sdf_all and d_grad_all are written. */
+int dsu_sample_losses(const float* sdf_all, const float* grad_all, int64_t n_samples,
+                      int64_t n_random, float lambda_eikonal, float lambda_sparsity,
+                      float sparsity_scale, float lambda_smooth, int32_t accumulate_prefix,
+                      float* d_sdf_all, float* d_grad_all, float* terms, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Style translator (3_style_translator/training/models.py).

@@ -1,0 +1,177 @@
+"""Fused per-step kernels of the NSR optimisation loop (csrc/nsr_step.hip) against the op-by-op
+torch formulation that tests/test_host_logic.py pins to the reference's criterions, and the
+hand-sequenced training step against the autograd step."""
+import numpy as np
+import pytest
+import torch
+
+from drawingspinup_amd import ops
+from drawingspinup_amd.nsr.system import (DEFAULT_SYSTEM_CONFIG, Cfg, OrthoData, OrthoNeuSSystem)
+
+pytestmark = pytest.mark.gpu
+
+
+class _LossOnly(OrthoNeuSSystem):
+    """OrthoNeuSSystem.ray_losses / sample_losses without building a model."""
+
+    def __init__(self, loss_cfg, has_mask=True):
+        self.config = Cfg({"loss": loss_cfg})
+
+        class _D:
+            pass
+        self.dataset = _D()
+        self.dataset.has_mask = has_mask
+
+
+def _ray_batch(R, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    u = lambda *s: torch.rand(*s, generator=g)
+    comp = torch.zeros(R, 8)
+    comp[:, 0] = u(R) * 1.2 - 0.1                       # opacity incl. values beyond both clamps
+    comp[: R // 5, 0] = 1e-4                            # tied smallest BCE errors (mask 0 below)
+    comp[:, 1] = u(R) * 2
+    comp[:, 2:5] = u(R, 3)
+    comp[:, 5:8] = (u(R, 3) * 2 - 1) * u(R, 1)
+    mask = (u(R) > 0.4).float()
+    mask[: R // 5] = 0.0
+    comp[R - 7:, 5:8] = 0.0                             # rays without samples: zero composite ...
+    mask[R - 7:] = 0.0                                  # ... are never foreground here
+    nrm = torch.nn.functional.normalize(u(R, 3) * 2 - 1, dim=-1)
+    batch = {"rgb": u(R, 3), "normal": nrm, "mask": mask, "cosines": u(R) * 1.2 - 1.0,
+             "view_weights": u(R) + 0.5}
+    return comp.to(dev), {k: v.to(dev) for k, v in batch.items()}
+
+
+@pytest.mark.parametrize("R,geo,l1", [(1500, True, 0.0), (1024, False, 0.3), (2049, True, 0.2),
+                                      (37, True, 0.0), (8192, True, 0.0)])
+def test_ray_losses_kernel_matches_torch_path(dev, R, geo, l1):
+    L = dict(DEFAULT_SYSTEM_CONFIG.loss)
+    L.update(geo_aware=geo, lambda_rgb_l1=l1)
+    ref = _LossOnly(L)
+    comp, batch = _ray_batch(R, 11 + R, dev)
+    c = comp.clone().requires_grad_(True)
+    terms = ref.ray_losses(c, batch)
+    (g_ref,) = torch.autograd.grad(sum(terms.values()), c)
+    t, d = ops.ray_losses(comp, batch["rgb"], batch["normal"], batch["mask"], batch["cosines"],
+                          batch["view_weights"],
+                          {"rgb_p_ratio": L["rgb_p_ratio"], "normal_p_ratio": L["normal_p_ratio"],
+                           "mask_p_ratio": L["mask_p_ratio"], "lambda_rgb_mse": L["lambda_rgb_mse"],
+                           "lambda_rgb_l1": l1, "lambda_normal": L["lambda_normal"],
+                           "lambda_mask": L["lambda_mask"], "geo_aware": geo})
+    t = t.cpu()
+    # float tolerance: same selection, different summation order
+    np.testing.assert_allclose(float(t[0]), float(terms["rgb_mse"]), rtol=2e-5, atol=1e-7)
+    if l1:
+        np.testing.assert_allclose(float(t[1]), float(terms["rgb_l1"]), rtol=2e-5, atol=1e-7)
+    else:
+        assert float(t[1]) == 0.0
+    np.testing.assert_allclose(float(t[2]), float(terms["normal"]), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(float(t[3]), float(terms["mask"]), rtol=2e-5, atol=1e-7)
+    assert float(d[:, 1].abs().max()) == 0.0
+    scale = float(g_ref.abs().max())
+    assert float((d - g_ref).abs().max()) < 2e-5 * scale + 1e-9
+
+
+def test_ray_losses_kernel_empty_foreground_is_nan_like_the_reference(dev):
+    """k = int(ratio * 0) = 0: torch.mean over an empty selection is NaN in the reference; the
+    gradient is zero."""
+    L = dict(DEFAULT_SYSTEM_CONFIG.loss)
+    comp, batch = _ray_batch(256, 5, dev)
+    batch["mask"].zero_()
+    t, d = ops.ray_losses(comp, batch["rgb"], batch["normal"], batch["mask"], batch["cosines"],
+                          batch["view_weights"], {**L, "lambda_rgb_l1": 0.0})
+    assert torch.isnan(t[0]) and torch.isfinite(t[3])
+    assert float(d[:, 2:8].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("n_s,n_r,smooth", [(100000, 2048, 1.0), (777, 64, 0.0), (0, 2048, 1.0)])
+def test_sample_losses_kernel_matches_torch_path(dev, n_s, n_r, smooth):
+    L = dict(DEFAULT_SYSTEM_CONFIG.loss)
+    L["lambda_3d_normal_smooth"] = smooth
+    ref = _LossOnly(L)
+    g = torch.Generator().manual_seed(3 + n_s)
+    n = n_s + 2 * n_r
+    sdf = (torch.randn(n, generator=g) * 0.02).to(dev)
+    grad = (torch.randn(n, 3, generator=g) * 0.7).to(dev)
+    if n_s:
+        grad[0] = 0.0                                    # |grad| = 0: subgradient 0
+    sdf_r, grad_r = sdf.clone().requires_grad_(True), grad.clone().requires_grad_(True)
+    out = {"sdf_grad_samples": grad_r[:n_s], "random_sdf": sdf_r[n_s:n_s + n_r],
+           "random_sdf_grad": grad_r[n_s:n_s + n_r], "normal_perturb": grad_r[n_s + n_r:]}
+    if n_s == 0:
+        out["sdf_grad_samples"] = grad_r[:1] * 0 + 1     # empty mean is NaN in torch; kernel: 0
+    terms = ref.sample_losses(out)
+    gs, gg = torch.autograd.grad(sum(terms.values()), [sdf_r, grad_r], allow_unused=True)
+    gs = torch.zeros_like(sdf) if gs is None else gs
+    t, d_sdf, d_grad = ops.sample_losses(sdf, grad, n_s, n_r, L["lambda_eikonal"],
+                                         L["lambda_sparsity"], L["sparsity_scale"], smooth)
+    if n_s:
+        np.testing.assert_allclose(float(t[0]), float(terms["eikonal"]), rtol=1e-4)
+    np.testing.assert_allclose(float(t[1]), float(terms["sparsity"]), rtol=1e-4)
+    if smooth:
+        np.testing.assert_allclose(float(t[2]), float(terms["normal_smooth"]), rtol=1e-4)
+    torch.testing.assert_close(d_sdf, gs, rtol=1e-5, atol=1e-9)
+    torch.testing.assert_close(d_grad, gg, rtol=1e-5, atol=1e-9)
+    # accumulate form: prefix rows keep what is there and receive the eikonal part on top
+    pre_s = torch.full((n,), 3.0, device=dev)
+    pre_g = torch.full((n, 3), -2.0, device=dev)
+    ops.sample_losses(sdf, grad, n_s, n_r, L["lambda_eikonal"], L["lambda_sparsity"],
+                      L["sparsity_scale"], smooth, pre_s, pre_g)
+    torch.testing.assert_close(pre_s[:n_s], torch.full((n_s,), 3.0, device=dev))
+    torch.testing.assert_close(pre_g[:n_s], d_grad[:n_s] - 2.0, rtol=1e-6, atol=1e-7)
+    torch.testing.assert_close(pre_s[n_s:], d_sdf[n_s:])
+    torch.testing.assert_close(pre_g[n_s:], d_grad[n_s:])
+
+
+def test_march_points_matches_packed_march(dev):
+    """ray_march_points = ray_march_single_pass + the reference's position arithmetic, bit for
+    bit, with the offsets scan kernel instead of cumsum."""
+    g = torch.Generator().manual_seed(2)
+    n = 3000
+    o = (torch.rand(n, 3, generator=g) * 2 - 1) * 0.3
+    d = torch.nn.functional.normalize(torch.randn(n, 3, generator=g), dim=-1)
+    o = (o - 2.0 * d).to(dev)
+    d = d.to(dev)
+    res = 64
+    occ = (torch.rand(res ** 3, generator=g) < 0.3).to(torch.uint8).to(dev)
+    aabb = [-1.0, -1.0, -1.0, 1.0, 1.0, 1.0]
+    step = 1.732 * 2 / 512
+    tmin, tmax = ops.ray_aabb(o, d, aabb, None, step)
+    ri, ts, te, off, cnt = ops.ray_march_single_pass(o, d, tmin, tmax, aabb, occ, res, step)
+    pts, ts2, te2, off2, cnt2, total = ops.ray_march_points(o, d, tmin, tmax, aabb, occ, res, step,
+                                                            tail_rows=5)
+    assert total == ri.shape[0] > 1000 and pts.shape == (total + 5, 3)
+    assert torch.equal(off, off2) and torch.equal(cnt, cnt2)
+    assert torch.equal(ts, ts2) and torch.equal(te, te2)
+    mid = (ts + te) / 2.0
+    ref = o[ri] + d[ri] * mid[:, None]
+    assert torch.equal(pts[:total], ref)
+
+
+def test_fused_step_gradients_match_autograd_step(dev):
+    """Same parameters, same injected draws: every parameter gradient of the hand-sequenced step
+    equals the autograd step's (learning rate 0 so that the step leaves the parameters alone)."""
+    from test_gpu_nsr_model import _inject, _loss_and_grads
+    ds = OrthoData.synthetic_sphere(256, device=dev)
+    sysm = OrthoNeuSSystem(device=dev, seed=7)
+    sysm.dataset = ds
+    for s in range(20):
+        sysm.train_num_rays = 256
+        sysm.training_step(_inject(sysm, ds, 256, 100 + s, dev))
+    sysm.global_step = 17
+    sysm.train_num_rays = 512
+    sysm._base_lrs = [0.0 for _ in sysm._base_lrs]
+    inj = _inject(sysm, ds, 512, 999, dev)
+    loss_a, out_a, g_a = _loss_and_grads(sysm, True, inj)
+    sysm.train_num_rays = 512
+    last = sysm.training_step_fused(inj)
+    sysm.global_step = 17
+    g_f = {n: p.grad.detach().clone() for n, p in sysm.model.named_parameters()
+           if p.grad is not None}
+    assert last["n_samples"] == int(out_a["num_samples"])
+    assert abs(float(last["loss"]) - loss_a) < 2e-5 * max(1.0, abs(loss_a))
+    assert set(g_f) == set(g_a)
+    for n in g_a:
+        scale = float(g_a[n].abs().max()) + 1e-12
+        err = float((g_f[n] - g_a[n]).abs().max()) / scale
+        assert err < 1e-3, (n, err)
