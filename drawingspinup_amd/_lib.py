@@ -30,6 +30,11 @@ class SdfMlp(C.Structure):
     _fields_ = [("w0", c_vp), ("b0", c_vp), ("w1", c_vp), ("b1", c_vp)]
 
 
+class TexMlp(C.Structure):
+    _fields_ = [("w0", c_vp), ("b0", c_vp), ("w1", c_vp), ("b1", c_vp), ("w2", c_vp),
+                ("b2", c_vp)]
+
+
 class RayLossCfg(C.Structure):
     _fields_ = [("rgb_p_ratio", C.c_double), ("normal_p_ratio", C.c_double),
                 ("mask_p_ratio", C.c_double), ("lambda_rgb_mse", c_f32),
@@ -61,6 +66,9 @@ _PROTOS = {
     "dsu_ray_offsets": [P, c_i64, P, P, P],
     "dsu_ray_losses": [P, P, P, P, P, P, c_i32, C.POINTER(RayLossCfg), P, P, P],
     "dsu_sample_losses": [P, P, c_i64, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, P, P, P, P],
+    "dsu_texture_fwd": [C.POINTER(TexMlp), P, c_i64, P, P],
+    "dsu_texture_bwd_workspace_bytes": [c_i64],
+    "dsu_texture_bwd": [C.POINTER(TexMlp), P, P, P, c_i64, P, P, P, P, P, P, P, P, c_i64, P],
     "dsu_weights_from_alpha_fwd": [P, P, P, c_i64, P, P],
     "dsu_weights_from_alpha_bwd": [P, P, P, P, P, c_i64, P, P],
     "dsu_accumulate_fwd": [P, P, c_i32, P, P, c_i64, P, P],

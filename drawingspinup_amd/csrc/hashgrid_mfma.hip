@@ -594,18 +594,20 @@ template <int NL>
 __global__ void reduce_partials_mfma_kernel(const float* __restrict__ partials, int nblocks,
                                             float* __restrict__ g_w0, float* __restrict__ g_b0,
                                             float* __restrict__ g_w1, float* __restrict__ g_b1) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v >= PART_GB1 + NOUT) return;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  int b = 0;
-  for (; b + 3 < nblocks; b += 4) {
-    s0 += partials[(size_t)b * PART_STRIDE + v];
-    s1 += partials[(size_t)(b + 1) * PART_STRIDE + v];
-    s2 += partials[(size_t)(b + 2) * PART_STRIDE + v];
-    s3 += partials[(size_t)(b + 3) * PART_STRIDE + v];
-  }
-  for (; b < nblocks; ++b) s0 += partials[(size_t)b * PART_STRIDE + v];
-  const float s = (s0 + s1) + (s2 + s3);
+  // 64 elements x 16 slices of the workgroup range per 1024-thread workgroup
+  __shared__ float red[16][64];
+  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int v = blockIdx.x * 64 + e;
+  const bool in_range = v < PART_GB1 + NOUT;
+  float acc = 0.0f;
+  if (in_range)
+    for (int b = sl; b < nblocks; b += 16) acc += partials[(size_t)b * PART_STRIDE + v];
+  red[sl][e] = acc;
+  __syncthreads();
+  if (sl != 0 || !in_range) return;
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += red[k][e];
   if (v < PART_GW1) {
     const int feat = v >> 5, k = v & 31;
     if (k < MC<NL>::KIN) {
@@ -753,7 +755,7 @@ int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu
         (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
         d_grad, d_feature, d_laplace, grad_table, (float*)workspace,
         getenv("DSU_BWD_ABLATE") ? atoi(getenv("DSU_BWD_ABLATE")) : 0);
-    reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 255) / 256), dim3(256), 0, s>>>(
+    reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 63) / 64), dim3(1024), 0, s>>>(
         (const float*)workspace, blocks, g_w0, g_b0, g_w1, g_b1);
   });
   DSU_CHECK_LAUNCH();

@@ -339,13 +339,24 @@ __global__ __launch_bounds__(256) void sample_losses_kernel(
       }
     }
   }
+  // one atomic triple per workgroup (thousands of same-address atomics serialise)
+  __shared__ float red[3][4];
   s_eik = wave_sum(s_eik);
   s_sp = wave_sum(s_sp);
   s_sm = wave_sum(s_sm);
-  if ((threadIdx.x & 63) == 0) {
-    if (s_eik != 0.0f) atomicAdd(&terms[0], s_eik * inv_ns * lambda_eik);
-    if (s_sp != 0.0f) atomicAdd(&terms[1], s_sp * inv_nr * lambda_sp);
-    if (s_sm != 0.0f) atomicAdd(&terms[2], s_sm * inv_3nr * lambda_sm);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (lane == 0) {
+    red[0][wave] = s_eik;
+    red[1][wave] = s_sp;
+    red[2][wave] = s_sm;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3) {
+    const float t = (red[threadIdx.x][0] + red[threadIdx.x][1]) +
+                    (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    const float sc = threadIdx.x == 0 ? inv_ns * lambda_eik
+                                      : (threadIdx.x == 1 ? inv_nr * lambda_sp : inv_3nr * lambda_sm);
+    if (t != 0.0f) atomicAdd(&terms[threadIdx.x], t * sc);
   }
 }
 
@@ -410,7 +421,7 @@ int dsu_sample_losses(const float* sdf_all, const float* grad_all, int64_t n_sam
   hipStream_t s = (hipStream_t)stream;
   if (hipMemsetAsync(terms, 0, 3 * sizeof(float), s) != hipSuccess) return DSU_ELAUNCH;
   if (n == 0) return DSU_OK;
-  sample_losses_kernel<<<dsu_capped_blocks(n, 256, 1024), 256, 0, s>>>(
+  sample_losses_kernel<<<dsu_capped_blocks(n, 256, 512), 256, 0, s>>>(
       sdf_all, grad_all, n_samples, n_random, lambda_eikonal, lambda_sparsity, sparsity_scale,
       lambda_smooth, accumulate_prefix, d_sdf_all, d_grad_all, terms);
   DSU_CHECK_LAUNCH();

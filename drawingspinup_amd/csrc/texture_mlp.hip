@@ -1,0 +1,473 @@
+// Radiance ("texture") MLP of the NeuS model, forward and backward, on the f32 matrix pipe
+// (gfx950, v_mfma_f32_32x32x2_f32).
+//
+// Replaces VolumeRadiance.forward (2_charactor_reconstructor/instant_nsr/models/texture.py:9-30)
+// = VanillaMLP 16 -> 64 -> 64 -> 3 with ReLU (models/network_utils.py:94-138, no weight norm for
+// this network) followed by sigmoid, and its autograd backward.  The reference runs it as three
+// library GEMMs + elementwise kernels forward and ~10 GEMMs / reductions backward over N ~ 2.6e5
+// samples with 16..64 columns: tall-skinny shapes the library handles at a few percent of peak.
+//
+// One wave = 64 samples.  Activations live transposed in MFMA accumulators
+//   H^T[64 hidden x 32 samples] per sample half:  lane = sample, register quad = 4 hidden units,
+// and are fed straight back as the B operand of the next layer (the k-pair of one register is
+// (unit, unit+4) across the two lane halves; the weight operand is permuted to match, exactly as
+// in hashgrid_mfma.hip).  Only the parameter-gradient GEMMs (contraction over samples = lanes)
+// go through LDS, 32 samples at a time.  Exact f32 throughout.
+#include "common.h"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int TIN = 16, THID = 64, TOUT = 3;
+// LDS layout (floats)
+constexpr int W1_ROW = 65;                       // padded row: conflict-free by row AND by column
+constexpr int W0_ROW = 17;
+constexpr int L_W1 = 0;
+constexpr int L_W0 = L_W1 + THID * W1_ROW;       // 4160
+constexpr int L_W2P = L_W0 + THID * W0_ROW;      // 5248: w2perm[h][o][32]
+constexpr int L_B0 = L_W2P + 2 * TOUT * 32;      // 5440
+constexpr int L_B1 = L_B0 + THID;
+constexpr int L_B2 = L_B1 + THID;                // 5568
+constexpr int L_WEND = L_B2 + 8;                 // 5576
+// per-wave staging (backward)
+constexpr int SD_ROW = 68, SIN_ROW = 20, SDO_ROW = 4;
+constexpr int S_P = 0, S_H = 32 * SD_ROW, S_IN = 2 * 32 * SD_ROW, S_DO = S_IN + 32 * SIN_ROW;
+constexpr int STAGE_F = S_DO + 32 * SDO_ROW;     // 5120
+constexpr int BWD_LDS_F = L_WEND + 4 * STAGE_F;  // 26056 floats = 104 KB
+// per-workgroup partial vector
+constexpr int P_GW1 = 0, P_GW0 = 64 * 64, P_GW2 = P_GW0 + 64 * 32, P_GB1 = P_GW2 + 64 * 32,
+              P_GB2 = P_GB1 + 64, PART_N = P_GB2 + 3, PART_STRIDE = 8320;
+constexpr int TEX_MAX_BLOCKS = 256;
+
+__device__ __forceinline__ int feat_of(int T, int r, int h) {
+  return 32 * T + (r & 3) + 8 * (r >> 2) + 4 * h;
+}
+
+__device__ __forceinline__ void swap_halves(float a, float b, float& o0, float& o1) {
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  o0 = __uint_as_float(r[0]);
+  o1 = __uint_as_float(r[1]);
+}
+
+__device__ __forceinline__ void load_weights(float* lds, const dsu_tex_mlp& m) {
+  for (int i = threadIdx.x; i < THID * THID; i += blockDim.x)
+    lds[L_W1 + (i >> 6) * W1_ROW + (i & 63)] = m.w1[i];
+  for (int i = threadIdx.x; i < THID * TIN; i += blockDim.x)
+    lds[L_W0 + (i >> 4) * W0_ROW + (i & 15)] = m.w0[i];
+  for (int i = threadIdx.x; i < 2 * TOUT * 32; i += blockDim.x) {
+    const int h = i / (TOUT * 32), o = (i / 32) % TOUT, tr = i & 31;
+    lds[L_W2P + i] = m.w2[o * THID + feat_of(tr >> 4, tr & 15, h)];
+  }
+  for (int i = threadIdx.x; i < THID; i += blockDim.x) {
+    lds[L_B0 + i] = m.b0[i];
+    lds[L_B1 + i] = m.b1[i];
+  }
+  for (int i = threadIdx.x; i < TOUT; i += blockDim.x) lds[L_B2 + i] = m.b2[i];
+}
+
+// Hidden activations of ONE sample half `a` (0: samples of lanes 0-31, 1: lanes 32-63).
+// in: the lane's OWN sample (16 inputs).  H0/H1: [hidden tile T] accumulators, post-ReLU.
+__device__ __forceinline__ void forward_half(const float* lds, const float* in, int a, int l31,
+                                             int h, f32x16 (&H0)[2], f32x16 (&H1)[2]) {
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) H0[T][r] = 0.0f;
+  // layer 0: H0^T = W0 . In^T (+ b0 as the k-pair (1, 0))
+#pragma unroll
+  for (int t = 0; t < TIN / 2; ++t) {
+    float b0v, b1v;
+    swap_halves(in[2 * t], in[2 * t + 1], b0v, b1v);
+    const float b = a == 0 ? b0v : b1v;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+      H0[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[L_W0 + (32 * T + l31) * W0_ROW + 2 * t + h],
+                                                   b, H0[T], 0, 0, 0);
+  }
+  {
+    const float one = h == 0 ? 1.0f : 0.0f;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+      H0[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(h == 0 ? lds[L_B0 + 32 * T + l31] : 0.0f, one,
+                                                   H0[T], 0, 0, 0);
+  }
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      H0[T][r] = fmaxf(H0[T][r], 0.0f);
+      H1[T][r] = 0.0f;
+    }
+  // layer 1: H1^T = W1 . H0^T ; register (T, r) of H0 is the k-pair (feat_of(T,r,0), +4)
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int k = feat_of(T, r, h);
+#pragma unroll
+      for (int To = 0; To < 2; ++To)
+        H1[To] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[L_W1 + (32 * To + l31) * W1_ROW + k],
+                                                      H0[T][r], H1[To], 0, 0, 0);
+    }
+  {
+    const float one = h == 0 ? 1.0f : 0.0f;
+#pragma unroll
+    for (int To = 0; To < 2; ++To)
+      H1[To] = __builtin_amdgcn_mfma_f32_32x32x2f32(h == 0 ? lds[L_B1 + 32 * To + l31] : 0.0f,
+                                                    one, H1[To], 0, 0, 0);
+  }
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) H1[T][r] = fmaxf(H1[T][r], 0.0f);
+}
+
+// partial dot products of the 3 outputs over the 32 hidden units this lane holds (sample l31 of
+// half a); the other 32 units sit in lane ^ 32
+__device__ __forceinline__ void layer2_partial(const float* lds, const f32x16 (&H1)[2], int h,
+                                               float (&p)[TOUT]) {
+#pragma unroll
+  for (int o = 0; o < TOUT; ++o) {
+    const float4* w4 = reinterpret_cast<const float4*>(lds + L_W2P + (h * TOUT + o) * 32);
+    float s = 0.0f;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float4 w = w4[T * 4 + q];
+        s = fmaf(w.x, H1[T][4 * q + 0], s);
+        s = fmaf(w.y, H1[T][4 * q + 1], s);
+        s = fmaf(w.z, H1[T][4 * q + 2], s);
+        s = fmaf(w.w, H1[T][4 * q + 3], s);
+      }
+    p[o] = s;
+  }
+}
+
+__device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
+
+__global__ __launch_bounds__(256) void texture_fwd_kernel(dsu_tex_mlp m,
+                                                          const float* __restrict__ x, int64_t n,
+                                                          float* __restrict__ rgb) {
+  __shared__ __attribute__((aligned(16))) float lds[L_WEND];
+  const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
+  load_weights(lds, m);
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t base = blockIdx.x * (int64_t)blockDim.x; base < n; base += stride) {
+    const int64_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    const int64_t ii = valid ? i : n - 1;
+    float in[TIN];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(x + ii * TIN + 4 * q);
+      in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+    }
+    float out[TOUT] = {0.0f, 0.0f, 0.0f};
+#pragma unroll 1
+    for (int a = 0; a < 2; ++a) {
+      f32x16 H0[2], H1[2];
+      forward_half(lds, in, a, l31, h, H0, H1);
+      float p[TOUT];
+      layer2_partial(lds, H1, h, p);
+#pragma unroll
+      for (int o = 0; o < TOUT; ++o) {
+        const float tot = p[o] + __shfl_xor(p[o], 32);     // both lanes of the pair get the sum
+        if (h == a) out[o] = tot;                          // the lane whose OWN sample is in half a
+      }
+    }
+    if (valid) {
+#pragma unroll
+      for (int o = 0; o < TOUT; ++o) rgb[i * TOUT + o] = sigmoidf(out[o] + lds[L_B2 + o]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void texture_bwd_kernel(
+    dsu_tex_mlp m, const float* __restrict__ x, const float* __restrict__ rgb,
+    const float* __restrict__ d_rgb, int64_t n, float* __restrict__ d_x,
+    float* __restrict__ partials) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
+  float* st = lds + L_WEND + wave * STAGE_F;
+  float* sP = st + S_P;
+  float* sH = st + S_H;
+  float* sIn = st + S_IN;
+  float* sDo = st + S_DO;
+  load_weights(lds, m);
+  __syncthreads();
+
+  f32x16 gw1[2][2], gw0[2], gw2[2];     // D[i = row unit][j]: W1[i][j], W0[i][k | bias], W2^T[i][o]
+  float gb1[2][16], gb2[TOUT] = {0.0f, 0.0f, 0.0f};
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      gw1[T][0][r] = gw1[T][1][r] = 0.0f;
+      gw0[T][r] = gw2[T][r] = 0.0f;
+      gb1[T][r] = 0.0f;
+    }
+
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t base = blockIdx.x * (int64_t)blockDim.x; base < n; base += stride) {
+    const int64_t i = base + threadIdx.x;
+    const bool valid = i < n;
+    const int64_t ii = valid ? i : n - 1;
+    float in[TIN];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float4 v = *reinterpret_cast<const float4*>(x + ii * TIN + 4 * q);
+      in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+    }
+    // gradient on the pre-sigmoid outputs of the lane's own sample (0 for padding lanes)
+    float dz[TOUT];
+#pragma unroll
+    for (int o = 0; o < TOUT; ++o) {
+      const float s = rgb[ii * TOUT + o];
+      dz[o] = valid ? d_rgb[ii * TOUT + o] * s * (1.0f - s) : 0.0f;
+      gb2[o] += dz[o];
+    }
+#pragma unroll 1
+    for (int a = 0; a < 2; ++a) {
+      f32x16 H0[2], H1[2];
+      forward_half(lds, in, a, l31, h, H0, H1);
+      // dz of the samples of half a, in every lane of the pair
+      float dza[TOUT];
+#pragma unroll
+      for (int o = 0; o < TOUT; ++o) {
+        const float other = __shfl_xor(dz[o], 32);
+        dza[o] = h == a ? dz[o] : other;
+      }
+      // dPre1 = (W2^T dz) * relu'(H1)
+      f32x16 D1[2];
+#pragma unroll
+      for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          float v = 0.0f;
+#pragma unroll
+          for (int o = 0; o < TOUT; ++o)
+            v = fmaf(lds[L_W2P + (h * TOUT + o) * 32 + T * 16 + r], dza[o], v);
+          D1[T][r] = H1[T][r] > 0.0f ? v : 0.0f;
+          gb1[T][r] += D1[T][r];
+        }
+      // ---- gW2^T[unit][o] += sum_samples H1[sample][unit] * dz[sample][o]
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+          *reinterpret_cast<float4*>(&sH[l31 * SD_ROW + 32 * T + 8 * qd + 4 * h]) =
+              make_float4(H1[T][4 * qd], H1[T][4 * qd + 1], H1[T][4 * qd + 2], H1[T][4 * qd + 3]);
+      if (h == a)
+        *reinterpret_cast<float4*>(&sDo[l31 * SDO_ROW]) = make_float4(dz[0], dz[1], dz[2], 0.0f);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+      for (int t = 0; t < 16; ++t) {
+        const int pr = 2 * t + h;
+        const float b = l31 < SDO_ROW ? sDo[pr * SDO_ROW + l31] : 0.0f;
+        gw2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sH[pr * SD_ROW + l31], b, gw2[0], 0, 0, 0);
+        gw2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sH[pr * SD_ROW + 32 + l31], b, gw2[1], 0, 0, 0);
+      }
+      // ---- gW1[i][j] += sum_samples dPre1[sample][i] * H0[sample][j]
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          *reinterpret_cast<float4*>(&sP[l31 * SD_ROW + 32 * T + 8 * qd + 4 * h]) =
+              make_float4(D1[T][4 * qd], D1[T][4 * qd + 1], D1[T][4 * qd + 2], D1[T][4 * qd + 3]);
+          *reinterpret_cast<float4*>(&sH[l31 * SD_ROW + 32 * T + 8 * qd + 4 * h]) =
+              make_float4(H0[T][4 * qd], H0[T][4 * qd + 1], H0[T][4 * qd + 2], H0[T][4 * qd + 3]);
+        }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 2
+      for (int t = 0; t < 16; ++t) {
+        const int pr = 2 * t + h;
+        const float a0 = sP[pr * SD_ROW + l31], a1 = sP[pr * SD_ROW + 32 + l31];
+        const float b0 = sH[pr * SD_ROW + l31], b1 = sH[pr * SD_ROW + 32 + l31];
+        gw1[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, gw1[0][0], 0, 0, 0);
+        gw1[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, gw1[0][1], 0, 0, 0);
+        gw1[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, gw1[1][0], 0, 0, 0);
+        gw1[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, gw1[1][1], 0, 0, 0);
+      }
+      // ---- dH0^T = W1^T . dPre1^T, then dPre0 = dH0 * relu'(H0)
+      f32x16 D0[2];
+#pragma unroll
+      for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) D0[T][r] = 0.0f;
+#pragma unroll
+      for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int k = feat_of(T, r, h);
+#pragma unroll
+          for (int To = 0; To < 2; ++To)
+            D0[To] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[L_W1 + k * W1_ROW + 32 * To + l31],
+                                                          D1[T][r], D0[To], 0, 0, 0);
+        }
+#pragma unroll
+      for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) D0[T][r] = H0[T][r] > 0.0f ? D0[T][r] : 0.0f;
+      // ---- gW0[i][k] += sum_samples dPre0[sample][i] * In[sample][k]  (k = 16: ones -> gb0)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd)
+          *reinterpret_cast<float4*>(&sP[l31 * SD_ROW + 32 * T + 8 * qd + 4 * h]) =
+              make_float4(D0[T][4 * qd], D0[T][4 * qd + 1], D0[T][4 * qd + 2], D0[T][4 * qd + 3]);
+      if (h == a) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          *reinterpret_cast<float4*>(&sIn[l31 * SIN_ROW + 4 * q]) =
+              make_float4(in[4 * q], in[4 * q + 1], in[4 * q + 2], in[4 * q + 3]);
+        sIn[l31 * SIN_ROW + 16] = 1.0f;
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll 4
+      for (int t = 0; t < 16; ++t) {
+        const int pr = 2 * t + h;
+        const float b = l31 <= TIN ? sIn[pr * SIN_ROW + l31] : 0.0f;
+        gw0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sP[pr * SD_ROW + l31], b, gw0[0], 0, 0, 0);
+        gw0[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sP[pr * SD_ROW + 32 + l31], b, gw0[1], 0, 0, 0);
+      }
+      // ---- dIn^T = W0^T . dPre0^T : row k = (r&3) + 8(r>>2) + 4h of the sample in column l31
+      f32x16 din;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) din[r] = 0.0f;
+#pragma unroll
+      for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float wa = l31 < TIN ? lds[L_W0 + feat_of(T, r, h) * W0_ROW + l31] : 0.0f;
+          din = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, D0[T][r], din, 0, 0, 0);
+        }
+      const int64_t si = base + wave * 64 + a * 32 + l31;        // the sample of column l31
+      if (si < n) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          *reinterpret_cast<float4*>(d_x + si * TIN + 8 * q + 4 * h) =
+              make_float4(din[4 * q], din[4 * q + 1], din[4 * q + 2], din[4 * q + 3]);
+      }
+    }
+  }
+
+  // ---- workgroup reduction of the parameter-gradient tiles -> one partial vector per workgroup
+  __syncthreads();
+  float* red = lds + L_WEND;                       // staging area reused: PART_N <= 4 * STAGE_F
+  for (int v = threadIdx.x; v < PART_N; v += blockDim.x) red[v] = 0.0f;
+  __syncthreads();
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = feat_of(T, r, h);
+      atomicAdd(&red[P_GW1 + row * 64 + l31], gw1[T][0][r]);
+      atomicAdd(&red[P_GW1 + row * 64 + 32 + l31], gw1[T][1][r]);
+      atomicAdd(&red[P_GW0 + row * 32 + l31], gw0[T][r]);
+      atomicAdd(&red[P_GW2 + row * 32 + l31], gw2[T][r]);
+      float s = gb1[T][r];                          // sum over the 32 sample columns of this half
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (l31 == 0) atomicAdd(&red[P_GB1 + row], s);
+    }
+#pragma unroll
+  for (int o = 0; o < TOUT; ++o) {
+    float s = gb2[o];
+#pragma unroll
+    for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
+    if (lane == 0) atomicAdd(&red[P_GB2 + o], s);
+  }
+  __syncthreads();
+  float* part = partials + (size_t)blockIdx.x * PART_STRIDE;
+  for (int v = threadIdx.x; v < PART_N; v += blockDim.x) part[v] = red[v];
+}
+
+__global__ void texture_reduce_kernel(const float* __restrict__ partials, int nblocks,
+                                      float* __restrict__ g_w0, float* __restrict__ g_b0,
+                                      float* __restrict__ g_w1, float* __restrict__ g_b1,
+                                      float* __restrict__ g_w2, float* __restrict__ g_b2) {
+  // 64 elements x 16 slices of the workgroup range per 1024-thread workgroup
+  __shared__ float red[16][64];
+  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  const int v = blockIdx.x * 64 + e;
+  const bool in_range = v < PART_N;
+  float acc = 0.0f;
+  if (in_range)
+    for (int b = sl; b < nblocks; b += 16) acc += partials[(size_t)b * PART_STRIDE + v];
+  red[sl][e] = acc;
+  __syncthreads();
+  if (sl != 0 || !in_range) return;
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += red[k][e];
+  if (v < P_GW0) {
+    g_w1[v] += s;                                   // [i][j] row-major = W1's layout
+  } else if (v < P_GW2) {
+    const int i = (v - P_GW0) >> 5, k = (v - P_GW0) & 31;
+    if (k < TIN) g_w0[i * TIN + k] += s;
+    else if (k == TIN) g_b0[i] += s;
+  } else if (v < P_GB1) {
+    const int i = (v - P_GW2) >> 5, o = (v - P_GW2) & 31;
+    if (o < TOUT) g_w2[o * THID + i] += s;
+  } else if (v < P_GB2) {
+    g_b1[v - P_GB1] += s;
+  } else {
+    g_b2[v - P_GB2] += s;
+  }
+}
+
+bool mlp_ok(const dsu_tex_mlp* m) {
+  return m && m->w0 && m->b0 && m->w1 && m->b1 && m->w2 && m->b2;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsu_texture_fwd(const dsu_tex_mlp* mlp, const float* tex_in, int64_t n, float* rgb,
+                    void* stream) {
+  if (!mlp_ok(mlp) || n < 0 || (n && (!tex_in || !rgb))) return DSU_EINVAL;
+  if (n == 0) return DSU_OK;
+  texture_fwd_kernel<<<dsu_capped_blocks(n, 256, 2048), 256, 0, (hipStream_t)stream>>>(
+      *mlp, tex_in, n, rgb);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int64_t dsu_texture_bwd_workspace_bytes(int64_t n) {
+  if (n < 0) return DSU_EINVAL;
+  return (int64_t)dsu_capped_blocks(n, 256, TEX_MAX_BLOCKS) * PART_STRIDE * sizeof(float);
+}
+
+int dsu_texture_bwd(const dsu_tex_mlp* mlp, const float* tex_in, const float* rgb,
+                    const float* d_rgb, int64_t n, float* d_tex_in, float* g_w0, float* g_b0,
+                    float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* workspace,
+                    int64_t workspace_bytes, void* stream) {
+  if (!mlp_ok(mlp) || n < 0) return DSU_EINVAL;
+  if (!g_w0 || !g_b0 || !g_w1 || !g_b1 || !g_w2 || !g_b2) return DSU_EINVAL;
+  if (n && (!tex_in || !rgb || !d_rgb || !d_tex_in)) return DSU_EINVAL;
+  if (n == 0) return DSU_OK;
+  const int64_t need = dsu_texture_bwd_workspace_bytes(n);
+  if (!workspace || workspace_bytes < need) return DSU_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = dsu_capped_blocks(n, 256, TEX_MAX_BLOCKS);
+  const size_t shm = (size_t)BWD_LDS_F * sizeof(float);
+  static_assert(PART_N <= 4 * STAGE_F, "reduction buffer must fit the staging area");
+  if (hipFuncSetAttribute((const void*)texture_bwd_kernel,
+                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+    return DSU_ELAUNCH;
+  texture_bwd_kernel<<<blocks, 256, shm, s>>>(*mlp, tex_in, rgb, d_rgb, n, d_tex_in,
+                                             (float*)workspace);
+  texture_reduce_kernel<<<(PART_N + 63) / 64, 1024, 0, s>>>((const float*)workspace, blocks, g_w0,
+                                                           g_b0, g_w1, g_b1, g_w2, g_b2);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+}  // extern "C"

@@ -188,6 +188,23 @@ class _SplitKLinearFn(torch.autograd.Function):
         return dx, dw, dy.sum(0)
 
 
+class _TextureFn(torch.autograd.Function):
+    """sigmoid(VanillaMLP 16->64->64->3 (x)) on the fused MFMA kernels (texture.py:20-30)."""
+
+    @staticmethod
+    def forward(ctx, x, w0, b0, w1, b1, w2, b2):
+        params = [t.detach().contiguous() for t in (w0, b0, w1, b1, w2, b2)]
+        rgb = ops.texture_fwd(params, x)
+        ctx.save_for_backward(x, rgb, *params)
+        return rgb
+
+    @staticmethod
+    def backward(ctx, d_rgb):
+        x, rgb, *params = ctx.saved_tensors
+        d_x, g = ops.texture_bwd(params, x, rgb, d_rgb.contiguous())
+        return (d_x, *g)
+
+
 class _ShadePrepFn(torch.autograd.Function):
     """normal = F.normalize(sdf_grad); tex_in = cat(feature, normal)  (neus.py:143, texture.py:22)."""
 
@@ -338,6 +355,23 @@ class VolumeRadiance(nn.Module):
             color = torch.sigmoid(color)
         return color
 
+    @property
+    def fused_ok(self):
+        """the fused kernel is built for the reference network: 16 -> 64 -> 64 -> 3, ReLU,
+        sigmoid colour activation, no weight norm"""
+        n = self.network
+        return (self.n_input_dims == 16 and n.n_neurons == 64 and n.n_hidden_layers == 2
+                and not n.weight_norm and not n.sphere_init
+                and self.config.get("color_activation") == "sigmoid")
+
+    def fused_params(self):
+        return [p for m in self.network.layers if isinstance(m, nn.Linear)
+                for p in (m.weight, m.bias)]
+
+    def rgb_fused(self, tex_in):
+        """sigmoid(self.network(tex_in)) in one launch forward, two backward."""
+        return _TextureFn.apply(tex_in, *self.fused_params())
+
     def mlp_split_k(self, x):
         """self.network(x) with the split-K weight-gradient GEMMs (same values)."""
         layers = self.network.layers
@@ -461,7 +495,10 @@ class NeuSModel(nn.Module):
             from .render import RayPacking
             _, off, cnt = RayPacking.last
             normal, tex_in = _ShadePrepFn.apply(sdf_grad.contiguous(), feature.contiguous())
-            rgb = torch.sigmoid(self.texture.mlp_split_k(tex_in))
+            if self.texture.fused_ok:
+                rgb = self.texture.rgb_fused(tex_in)
+            else:
+                rgb = torch.sigmoid(self.texture.mlp_split_k(tex_in))
             comp, weights, alpha = _CompositeFn.apply(
                 sdf.contiguous(), normal, rgb.contiguous(), self.variance.inv_s.reshape(1),
                 rays_d, t_starts.reshape(-1), t_ends.reshape(-1), off, cnt,

@@ -384,10 +384,15 @@ class OrthoNeuSSystem:
             a_sdf, a_grad, a_feat, _ = ops.sdf_fd_fwd(enc.cfg, table, mlp, allp, geo.radius, eps,
                                                       active, True, True, False)
             normal, tex_in = ops.shade_prep_fwd(a_grad[:n_s], a_feat[:n_s])
-        tex_in.requires_grad_(True)
-        rgb = torch.sigmoid(m.texture.mlp_split_k(tex_in))
-        with torch.no_grad():
+        tex_fused = m.texture.fused_ok
+        if tex_fused:
+            tex_params = [p.detach() for p in m.texture.fused_params()]
+            rgb_d = ops.texture_fwd(tex_params, tex_in)
+        else:
+            tex_in.requires_grad_(True)
+            rgb = torch.sigmoid(m.texture.mlp_split_k(tex_in))
             rgb_d = rgb.detach()
+        with torch.no_grad():
             inv_d = inv_s.detach().reshape(1)
             car = float(m.cos_anneal_ratio)
             comp, alpha, w = ops.neus_composite_fwd(a_sdf[:n_s], normal, rgb_d, rays_d, ts, te, off,
@@ -408,9 +413,17 @@ class OrthoNeuSSystem:
             _, d_normal, d_rgb, d_inv = ops.neus_composite_bwd(
                 a_sdf[:n_s], normal, rgb_d, rays_d, ts, te, off, cnt, inv_d, car, alpha, w, d_comp,
                 None, d_sdf_out=d_sdf_all[:n_s])
-        torch.autograd.backward([rgb, inv_s], [d_rgb, d_inv.view_as(inv_s)])
+            if tex_fused:
+                d_tex_in, g_tex = ops.texture_bwd(tex_params, tex_in, rgb_d, d_rgb)
+        if tex_fused:
+            for p_, g_ in zip(m.texture.fused_params(), g_tex):
+                p_.grad = g_
+            torch.autograd.backward([inv_s], [d_inv.view_as(inv_s)])
+        else:
+            torch.autograd.backward([rgb, inv_s], [d_rgb, d_inv.view_as(inv_s)])
+            d_tex_in = tex_in.grad
         with torch.no_grad():
-            ops.shade_prep_bwd(a_grad[:n_s], d_normal, tex_in.grad,
+            ops.shade_prep_bwd(a_grad[:n_s], d_normal, d_tex_in,
                                out=(d_grad_all[:n_s], d_feat_all[:n_s]))
             smooth = L.lambda_3d_normal_smooth if L.lambda_3d_normal_smooth > 0 else 0.0
             sterms, _, _ = ops.sample_losses(a_sdf, a_grad, n_s, n_r, L.lambda_eikonal,

@@ -253,6 +253,44 @@ def ray_march_points(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step,
     return points, t_starts, t_ends, offsets, counts, total
 
 
+def _tex_struct(params):
+    from ._lib import TexMlp
+    for t, shape in zip(params, ((64, 16), (64,), (64, 64), (64,), (3, 64), (3,))):
+        if tuple(t.shape) != shape:
+            raise DsuError(f"texture MLP parameter of shape {tuple(t.shape)}, expected {shape}")
+    return TexMlp(*[ptr(t, torch.float32).value for t in params])
+
+
+def texture_fwd(params, tex_in):
+    """params = [w0 (64,16), b0, w1 (64,64), b1, w2 (3,64), b2] f32 contiguous;
+    returns rgb (n,3) = sigmoid(MLP(tex_in))."""
+    tex_in = _f32c(tex_in)
+    n = tex_in.shape[0]
+    assert tex_in.shape[1] == 16
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=tex_in.device)
+    m = _tex_struct(params)
+    check(lib().dsu_texture_fwd(C.byref(m), ptr(tex_in), n, ptr(rgb), stream()), "dsu_texture_fwd")
+    return rgb
+
+
+def texture_bwd(params, tex_in, rgb, d_rgb):
+    """Returns (d_tex_in (n,16), [g_w0, g_b0, g_w1, g_b1, g_w2, g_b2])."""
+    tex_in, rgb, d_rgb = _f32c(tex_in), _f32c(rgb), _f32c(d_rgb)
+    n = tex_in.shape[0]
+    dev = tex_in.device
+    d_in = torch.empty_like(tex_in)
+    sizes = [t.numel() for t in params]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    g = [v.view_as(t) for v, t in zip(torch.split(flat, sizes), params)]
+    wbytes = int(lib().dsu_texture_bwd_workspace_bytes(n))
+    ws = torch.empty(max(wbytes, 4) // 4, dtype=torch.float32, device=dev)
+    m = _tex_struct(params)
+    check(lib().dsu_texture_bwd(C.byref(m), ptr(tex_in), ptr(rgb), ptr(d_rgb), n, ptr(d_in),
+                                *[ptr(t) for t in g], ptr(ws), wbytes, stream()),
+          "dsu_texture_bwd")
+    return d_in, g
+
+
 RAY_LOSS_MAX_RAYS = 8192      # DSU_RAY_LOSS_MAX_RAYS (include/dsu_hip.h)
 
 

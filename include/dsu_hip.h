@@ -221,6 +221,24 @@ int dsu_shade_prep_fwd(const float* grad, const float* feature, int64_t n, float
 int dsu_shade_prep_bwd(const float* grad, const float* d_normal, const float* d_tex_in, int64_t n,
                        float* d_grad, float* d_feature, void* stream);
 
+/* VolumeRadiance (2_charactor_reconstructor/instant_nsr/models/texture.py:9-30): VanillaMLP
+ * 16 -> 64 -> 64 -> 3, ReLU, no weight norm (models/network_utils.py:94-138), then sigmoid.
+ * Weights row-major (out, in) f32 as nn.Linear stores them (texture.network.layers.{0,2,4}).
+ *   dsu_texture_fwd: rgb (n,3) = sigmoid(MLP(tex_in (n,16)))
+ *   dsu_texture_bwd: d_tex_in (n,16) written; g_* accumulated (+=) with the parameter
+ *     gradients; `rgb` is the forward output (sigmoid' = rgb (1 - rgb)); hidden activations are
+ *     recomputed.  workspace: dsu_texture_bwd_workspace_bytes(n) bytes of device memory. */
+typedef struct dsu_tex_mlp {
+  const float *w0, *b0, *w1, *b1, *w2, *b2;
+} dsu_tex_mlp;
+int dsu_texture_fwd(const dsu_tex_mlp* mlp, const float* tex_in, int64_t n, float* rgb,
+                    void* stream);
+int64_t dsu_texture_bwd_workspace_bytes(int64_t n);
+int dsu_texture_bwd(const dsu_tex_mlp* mlp, const float* tex_in, const float* rgb,
+                    const float* d_rgb, int64_t n, float* d_tex_in, float* g_w0, float* g_b0,
+                    float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* workspace,
+                    int64_t workspace_bytes, void* stream);
+
 /* Ray-level loss terms of OrthoNeuSSystem.training_step
  * (2_charactor_reconstructor/instant_nsr/systems/neus_ortho.py:94-133 with
  * systems/criterions.py:4-27) and their gradient w.r.t. the raw composite

@@ -175,3 +175,44 @@ def test_fused_step_gradients_match_autograd_step(dev):
         scale = float(g_a[n].abs().max()) + 1e-12
         err = float((g_f[n] - g_a[n]).abs().max()) / scale
         assert err < 1e-3, (n, err)
+
+
+@pytest.mark.parametrize("n", [1, 63, 64, 1000, 262144 + 37])
+def test_texture_mlp_kernels_match_torch(dev, n):
+    """sigmoid(VanillaMLP 16->64->64->3) forward and backward (f32 MFMA) vs torch f32
+    (tolerance: different f32 summation order only; reference texture.py:20-30)."""
+    g = torch.Generator().manual_seed(n)
+    mk = lambda *s: (torch.randn(*s, generator=g)).to(dev)
+    params = [mk(64, 16) * 0.3, mk(64) * 0.1, mk(64, 64) * 0.15, mk(64) * 0.1, mk(3, 64) * 0.2,
+              mk(3) * 0.1]
+    x = mk(n, 16)
+    d_rgb = mk(n, 3)
+    px = [p.clone().requires_grad_(True) for p in params]
+    xr = x.clone().requires_grad_(True)
+    h = torch.relu(torch.nn.functional.linear(xr, px[0], px[1]))
+    h = torch.relu(torch.nn.functional.linear(h, px[2], px[3]))
+    ref = torch.sigmoid(torch.nn.functional.linear(h, px[4], px[5]))
+    ref.backward(d_rgb)
+    rgb = ops.texture_fwd(params, x)
+    torch.testing.assert_close(rgb, ref.detach(), rtol=1e-5, atol=2e-6)
+    d_x, gp = ops.texture_bwd(params, x, rgb, d_rgb)
+    torch.testing.assert_close(d_x, xr.grad, rtol=1e-4, atol=1e-5 * float(xr.grad.abs().max()))
+    for got, p in zip(gp, px):
+        scale = float(p.grad.abs().max()) + 1e-12
+        assert float((got - p.grad).abs().max()) < 2e-4 * scale, (tuple(p.shape), scale)
+
+
+def test_texture_autograd_function_in_model(dev):
+    from drawingspinup_amd.nsr.model import DEFAULT_MODEL_CONFIG, VolumeRadiance
+    tex = VolumeRadiance(DEFAULT_MODEL_CONFIG.texture).to(dev)
+    assert tex.fused_ok
+    x = torch.randn(5000, 16, device=dev)
+    x1, x2 = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    y1 = tex.rgb_fused(x1)
+    y2 = torch.sigmoid(tex.network(x2))
+    torch.testing.assert_close(y1, y2, rtol=1e-5, atol=2e-6)
+    gy = torch.randn_like(y1)
+    g1 = torch.autograd.grad(y1, [x1] + list(tex.parameters()), gy)
+    g2 = torch.autograd.grad(y2, [x2] + list(tex.parameters()), gy)
+    for a, b in zip(g1, g2):
+        assert float((a - b).abs().max()) < 2e-4 * (float(b.abs().max()) + 1e-12)
