@@ -299,7 +299,44 @@ constexpr int SD_ROW = 68, SIN_ROW = 36;
 constexpr int STAGE_F = 32 * SD_ROW + 2 * 32 * SIN_ROW;   // 4480 floats per wave
 constexpr int W1P_F = 2 * NOUT * 32 + 16;
 constexpr int BWD_CACHE_OFF = W1P_F + 4 * STAGE_F;
-constexpr int BWD_LDS_F = BWD_CACHE_OFF + 3 * GC_SLOTS;
+// gradient cache: keys u32[GC_SLOTS] | accumulators i64[GC_SLOTS][2] in fixed point (see gc_fix)
+constexpr int BWD_LDS_F = BWD_CACHE_OFF + GC_SLOTS + 4 * GC_SLOTS;
+// per-wave contribution queue (aliases the staging area while the scatter of a half runs)
+constexpr int QCAP = 1408;                                 // (entry, d0, d1) triples
+static_assert(3 * QCAP <= STAGE_F, "queue must fit the staging area");
+static_assert((BWD_CACHE_OFF + GC_SLOTS) % 2 == 0, "i64 accumulators need 8-byte alignment");
+
+// LDS float atomics retire ~1 lane per 3 clocks per CU (measured, profiles/round1_lds_atomics.txt)
+// while integer atomics cost ~10 clocks per instruction whatever the lane count, so the cache
+// accumulates in 64-bit fixed point (2^-40 resolution, +-8.4e6 range): ~20x cheaper per
+// contribution when all lanes are busy, and order-independent.
+constexpr float GC_FIX_SCALE = 1099511627776.0f;           // 2^40
+__device__ __forceinline__ unsigned long long gc_fix(float v) {
+  return (unsigned long long)__float2ll_rn(v * GC_FIX_SCALE);
+}
+__device__ __forceinline__ float gc_unfix(unsigned long long a) {
+  return __ll2float_rn((long long)a) * (1.0f / GC_FIX_SCALE);
+}
+
+// one queued contribution -> cache (3 probes) or, when the cache is full around its slot, a global
+// float atomic
+__device__ __forceinline__ void gc_commit(uint32_t* keys, unsigned long long* acc,
+                                          float* __restrict__ gtable, uint32_t entry, float v0,
+                                          float v1) {
+  uint32_t slot = grad_cache_slot(entry);
+#pragma unroll
+  for (int probe = 0; probe < 3; ++probe) {
+    const uint32_t old = atomicCAS(&keys[slot], GC_EMPTY, entry);
+    if (old == GC_EMPTY || old == entry) {
+      atomicAdd(&acc[2 * slot], gc_fix(v0));               // ds_add_u64, no return
+      atomicAdd(&acc[2 * slot + 1], gc_fix(v1));
+      return;
+    }
+    slot = (slot + 1) & (GC_SLOTS - 1);
+  }
+  unsafeAtomicAdd(gtable + (size_t)entry * 2, v0);
+  unsafeAtomicAdd(gtable + (size_t)entry * 2 + 1, v1);
+}
 // per-workgroup partial vector: gw0p[64 feat][32 k'] | gw1p[64 feat][32 o'] | gb1[16]
 constexpr int PART_GW0 = 0, PART_GW1 = 64 * 32, PART_GB1 = 2 * 64 * 32;
 constexpr int PART_STRIDE = 2 * 64 * 32 + 64;
@@ -321,7 +358,11 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
   float* sin_ = sd + 32 * SD_ROW;
   float* sdo = sin_ + 32 * SIN_ROW;
   uint32_t* c_keys = reinterpret_cast<uint32_t*>(lds + BWD_CACHE_OFF);
-  float* c_vals = lds + BWD_CACHE_OFF + GC_SLOTS;
+  unsigned long long* c_acc =
+      reinterpret_cast<unsigned long long*>(lds + BWD_CACHE_OFF + GC_SLOTS);
+  uint32_t* q_ent = reinterpret_cast<uint32_t*>(sd);       // queue aliases sd/sin/sdo
+  float* q_v0 = sd + QCAP;
+  float* q_v1 = sd + 2 * QCAP;
 
   Frags<NL> fr;
   load_frags<NL>(mlp, fr, lane);
@@ -335,8 +376,8 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
   load_w1perm(w1perm, b1s, mlp);
   for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
     c_keys[t] = GC_EMPTY;
-    c_vals[2 * t] = 0.0f;
-    c_vals[2 * t + 1] = 0.0f;
+    c_acc[2 * t] = 0ull;
+    c_acc[2 * t + 1] = 0ull;
   }
   __syncthreads();
 
@@ -348,6 +389,11 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
   float gb1[NOUT];
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) gb1[o] = 0.0f;
+  float gw1c0[2][16];      // column o = 0 of gW1 from the offset evaluations, per point column
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gw1c0[T][r] = 0.0f;
 
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t bbase = blockIdx.x * (int64_t)blockDim.x; bbase < n; bbase += stride) {
@@ -453,6 +499,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
             if (4 * k4 + 3 < KIN) v.w = in[(4 * k4 + 3) < KIN ? 4 * k4 + 3 : 0];
             *reinterpret_cast<float4*>(&sin_[l31 * SIN_ROW + 4 * k4]) = v;
           }
+          if (e == 0)
 #pragma unroll
           for (int o4 = 0; o4 < 8; ++o4) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -474,40 +521,74 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
           gw0[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + 32 + l31], b, gw0[1], 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
-        // hidden activations of this half's points -> LDS, then gW1[feat][o'] += H^T . dOut
+        if (e == 0) {
+          // hidden activations of this half's points -> LDS, then gW1[feat][o'] += H^T . dOut
 #pragma unroll
-        for (int T = 0; T < 2; ++T)
+          for (int T = 0; T < 2; ++T)
 #pragma unroll
-          for (int qd = 0; qd < 4; ++qd)
-            *reinterpret_cast<float4*>(&sd[l31 * SD_ROW + 32 * T + 8 * qd + 4 * h]) =
-                make_float4(Hh[T][4 * qd], Hh[T][4 * qd + 1], Hh[T][4 * qd + 2], Hh[T][4 * qd + 3]);
-        __builtin_amdgcn_wave_barrier();
-        if (!(ablate & 2))
+            for (int qd = 0; qd < 4; ++qd)
+              *reinterpret_cast<float4*>(&sd[l31 * SD_ROW + 32 * T + 8 * qd + 4 * h]) =
+                  make_float4(Hh[T][4 * qd], Hh[T][4 * qd + 1], Hh[T][4 * qd + 2], Hh[T][4 * qd + 3]);
+          __builtin_amdgcn_wave_barrier();
+          if (!(ablate & 2))
 #pragma unroll 4
-        for (int t = 0; t < 16; ++t) {
-          const int pr = 2 * t + h;
-          const float b = sdo[pr * SIN_ROW + l31];
-          gw1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + l31], b, gw1[0], 0, 0, 0);
-          gw1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + 32 + l31], b, gw1[1], 0, 0, 0);
+          for (int t = 0; t < 16; ++t) {
+            const int pr = 2 * t + h;
+            const float b = sdo[pr * SIN_ROW + l31];
+            gw1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + l31], b, gw1[0], 0, 0, 0);
+            gw1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + 32 + l31], b, gw1[1], 0, 0, 0);
+          }
+        } else {
+          // the six offset evaluations only feed output 0: gW1[feat][0] += H[point][feat] * d0
+          // as per-lane partial sums over this lane's point column (reduced over lanes at the end)
+#pragma unroll
+          for (int T = 0; T < 2; ++T)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) gw1c0[T][r] = fmaf(Hh[T][r], d[0], gw1c0[T][r]);
         }
         // scatter dIn rows held by this lane: input row i = (r&3) + 8(r>>2) + 4h, levels (i>>1)
         if (!(ablate & 1)) {
           const bool own = h == half;
           const float sx = own ? cx : pcx, sy = own ? cy : pcy, sz = own ? cz : pcz;
           const bool pv = __shfl(valid ? 1 : 0, half * 32 + l31) != 0;
+          // The staging area is free from here to the end of this half: it becomes the wave's
+          // queue of (table entry, d0, d1) contributions.  Producers are the few "leader" lanes
+          // of each level step; the queue is drained 64 contributions per instruction.
+          __builtin_amdgcn_wave_barrier();
+          int qn = 0;
+          auto drain = [&]() {
+            __builtin_amdgcn_wave_barrier();
+            for (int i = lane; i < qn; i += 64)
+              gc_commit(c_keys, c_acc, gtable, q_ent[i], q_v0[i], q_v1[i]);
+            __builtin_amdgcn_wave_barrier();
+            qn = 0;
+          };
 #pragma unroll
           for (int r = 0; r < 16; r += 2) {
             const int lev = ((r & 3) + 8 * (r >> 2)) / 2 + 2 * h;   // compile-time part + lane half
-            if (lev < NL && (uint32_t)lev < active) {
+            const bool lev_on = lev < NL && (uint32_t)lev < active;
+            if (((r & 3) + 8 * (r >> 2)) / 2 >= NL) continue;        // no lane has this level
+            // level metadata of BOTH lane halves with compile-time indices + a select: a
+            // lane-varying index into the kernel-argument struct would be served from scratch
+            // memory (a global-memory round trip per lookup at one wave per SIMD)
+            const int la = ((r & 3) + 8 * (r >> 2)) / 2;
+            const int lb = la + 2 < DSU_MAX_LEVELS ? la + 2 : la;
+            const float l_scale = h ? m.scale[lb] : m.scale[la];
+            const uint32_t l_off = h ? m.off[lb] : m.off[la];
+            const uint32_t l_end = h ? m.off[lb + 1] : m.off[la + 1];
+            const uint32_t l_res = h ? m.res[lb] : m.res[la];
+            const uint32_t l_hashed = h ? m.hashed[lb] : m.hashed[la];
+            bool lead = false;
+            float v[16];
+            CellPos cp;
+            if (lev_on) {
               const bool on = pv;
               const float d0 = on ? din[r] : 0.0f, d1 = on ? din[r + 1] : 0.0f;
-              const uint32_t hsize = m.off[lev + 1] - m.off[lev];
-              const CellPos cp = cell_of(m.scale[lev], sx, sy, sz);
+              cp = cell_of(l_scale, sx, sy, sz);
               // Neighbouring lanes are neighbouring samples of a ray and mostly sit in the SAME
               // cell: sum the 8x2 corner contributions over runs of equal cells inside each
-              // 16-lane row with DPP row shifts (segmented suffix scan), so that only the first
-              // lane of a run touches the LDS cache — no same-address LDS-atomic serialisation.
-              float v[16];
+              // 16-lane row with DPP row shifts (segmented suffix scan); only the first lane of
+              // a run (the leader) emits the run's 8 corner contributions.
 #pragma unroll
               for (int c = 0; c < 8; ++c) {
                 const float w = corner_weight(cp, c);
@@ -528,20 +609,32 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
               }
               DSU_SEG_STEP(0x101) DSU_SEG_STEP(0x102) DSU_SEG_STEP(0x104) DSU_SEG_STEP(0x108)
 #undef DSU_SEG_STEP
-              const bool leader = l15 == 0 || dpp_i<0x111>(key) != key;  // first lane of its run
-              if (leader) {
+              lead = (l15 == 0 || dpp_i<0x111>(key) != key) && !(ablate & 4);  // first of its run
+            }
+            const unsigned long long bal = __ballot(lead);
+            if (lead) {
+              const int pos = qn + 8 * __popcll(bal & ((1ull << lane) - 1ull));
+              const uint32_t hsize = l_end - l_off;
+              uint32_t ent[8];
 #pragma unroll
-                for (int c = 0; c < 8; ++c) {
-                  if (v[2 * c] != 0.0f || v[2 * c + 1] != 0.0f) {
-                    const uint32_t idx =
-                        grid_index(m.hashed[lev], hsize, m.res[lev], cp.c[0] + (c & 1),
-                                   cp.c[1] + ((c >> 1) & 1), cp.c[2] + ((c >> 2) & 1));
-                    grad_cache_add(c_keys, c_vals, gtable, m.off[lev] + idx, v[2 * c], v[2 * c + 1]);
-                  }
-                }
+              for (int c = 0; c < 8; ++c)
+                ent[c] = l_off + grid_index(l_hashed, hsize, l_res,
+                                                 cp.c[0] + (c & 1), cp.c[1] + ((c >> 1) & 1),
+                                                 cp.c[2] + ((c >> 2) & 1));
+#pragma unroll
+              for (int q4 = 0; q4 < 2; ++q4) {
+                *reinterpret_cast<uint4*>(&q_ent[pos + 4 * q4]) =
+                    make_uint4(ent[4 * q4], ent[4 * q4 + 1], ent[4 * q4 + 2], ent[4 * q4 + 3]);
+                *reinterpret_cast<float4*>(&q_v0[pos + 4 * q4]) =
+                    make_float4(v[8 * q4], v[8 * q4 + 2], v[8 * q4 + 4], v[8 * q4 + 6]);
+                *reinterpret_cast<float4*>(&q_v1[pos + 4 * q4]) =
+                    make_float4(v[8 * q4 + 1], v[8 * q4 + 3], v[8 * q4 + 5], v[8 * q4 + 7]);
               }
             }
+            qn += 8 * __popcll(bal);
+            if (qn + 512 > QCAP) drain();
           }
+          drain();
         }
       }
     }
@@ -550,11 +643,13 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
       const uint32_t key = c_keys[t];
       if (key != GC_EMPTY) {
-        unsafeAtomicAdd(gtable + (size_t)key * 2, c_vals[2 * t]);
-        unsafeAtomicAdd(gtable + (size_t)key * 2 + 1, c_vals[2 * t + 1]);
+        if (!(ablate & 8)) {
+          unsafeAtomicAdd(gtable + (size_t)key * 2, gc_unfix(c_acc[2 * t]));
+          unsafeAtomicAdd(gtable + (size_t)key * 2 + 1, gc_unfix(c_acc[2 * t + 1]));
+        }
         c_keys[t] = GC_EMPTY;
-        c_vals[2 * t] = 0.0f;
-        c_vals[2 * t + 1] = 0.0f;
+        c_acc[2 * t] = 0ull;
+        c_acc[2 * t + 1] = 0ull;
       }
     }
     __syncthreads();
@@ -570,8 +665,11 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int feat = feat_of(T, r, h);
+        float c0 = gw1c0[T][r];                      // sum over the 32 point columns of this half
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) c0 += __shfl_xor(c0, off);
         r0[PART_GW0 + feat * 32 + l31] = gw0[T][r];
-        r0[PART_GW1 + feat * 32 + l31] = gw1[T][r];
+        r0[PART_GW1 + feat * 32 + l31] = gw1[T][r] + (l31 == 0 ? c0 : 0.0f);
       }
 #pragma unroll
     for (int o = 0; o < NOUT; ++o) gb1[o] += __shfl_xor(gb1[o], 32);
