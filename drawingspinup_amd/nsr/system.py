@@ -239,6 +239,10 @@ class OrthoNeuSSystem:
         # except for the texture MLP and the tiny weight-norm / variance chains);
         # "autograd": the op-by-op step through torch.autograd (cross-check, same numbers)
         self.step_mode = os.environ.get("DSU_STEP", "fused")
+        self.use_prefetch = os.environ.get("DSU_PREFETCH", "1") != "0" and self.device.type == "cuda"
+        self._side, self._prefetched = None, None
+        self._stats_pinned = [torch.empty(2, dtype=torch.int32).pin_memory() for _ in range(2)] \
+            if self.device.type == "cuda" and torch.cuda.is_available() else None
 
     # ----------------------------------------------------------------- data
     def preprocess_data(self, index=None, x=None, y=None):
@@ -328,6 +332,67 @@ class OrthoNeuSSystem:
             return self.training_step_fused(inject)
         return self.training_step_autograd(inject)
 
+    # ------------------------------------------------------------- ray batch + march (prefetchable)
+    def _march_begin(self, inject=None):
+        """preprocess_data + ray/box intersection + single-pass march + offsets scan on the
+        CURRENT stream; nothing waits for the device."""
+        m = self.model
+        inject = inject or {}
+        batch = self.preprocess_data(inject.get("index"), inject.get("x"), inject.get("y"))
+        rays = batch["rays"]
+        rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
+        jitter = inject.get("jitter")
+        if jitter is None and m.randomized:
+            jitter = torch.rand(rays.shape[0], device=rays.device)
+        with torch.no_grad():
+            tmin, tmax = ops.ray_aabb(rays_o, rays_d, m._aabb_host,
+                                      jitter if m.randomized else None, m.render_step_size)
+            occ, res = None, 0
+            if m.config.grid_prune:
+                occ, res = m.occupancy_grid.binary_u8(), m.occupancy_grid.res
+            h = ops.ray_march_begin(rays_o, rays_d, tmin, tmax, m._aabb_host, occ, res,
+                                    m.render_step_size)
+        return {"batch": batch, "handle": h, "keep": (tmin, tmax, jitter, rays)}
+
+    def _launch_prefetch(self):
+        """The next step's ray batch and march depend on the occupancy grid and the RNG, not on
+        the parameters this step is about to update: run them on a side stream, concurrently with
+        this step's geometry / backward kernels (32 marching waves next to a 4-wave-per-CU
+        backward), and hand the sample count to the host through pinned memory.  Skipped when
+        the next step refreshes the occupancy grid (every 16th step) — that must see the updated
+        parameters first."""
+        if not self.use_prefetch:
+            return
+        nxt = self.global_step + 1
+        if self.model.config.grid_prune and nxt % 16 == 0:
+            return
+        main = torch.cuda.current_stream()
+        if self._side is None:
+            self._side = torch.cuda.Stream()
+        done = torch.cuda.Event()
+        done.record(main)                      # compaction of THIS step has been enqueued: the
+        self._side.wait_event(done)            # march scratch rows may be overwritten after it
+        with torch.cuda.stream(self._side):
+            prep = self._march_begin()
+            host = self._stats_pinned[nxt & 1]
+            host.copy_(prep["handle"].stats, non_blocking=True)
+            prep["stats_host"] = host
+            prep["ready"] = torch.cuda.Event()
+            prep["ready"].record(self._side)
+        prep["step"] = nxt
+        h = prep["handle"]
+        for t in (*prep["batch"].values(), h.rays_o, h.rays_d, h.counts, h.offsets, h.stats,
+                  *[k for k in prep["keep"] if k is not None]):
+            t.record_stream(main)              # produced on the side stream, consumed on main
+        self._prefetched = prep
+
+    def _take_prefetch(self):
+        prep, self._prefetched = self._prefetched, None
+        if prep is not None and (prep["step"] != self.global_step
+                                 or prep["handle"].n != self.train_num_rays):
+            return None
+        return prep
+
     def training_step_fused(self, inject=None):
         """Same step as training_step_autograd (neus_ortho.py:84-160 + the model forward
         neus.py:115-196), with the backward pass sequenced by hand over the fused kernels:
@@ -339,15 +404,18 @@ class OrthoNeuSSystem:
         geo, enc = m.geometry, m.geometry.hashgrid
         m.train()
         inject = inject or {}
-        batch = self.preprocess_data(inject.get("index"), inject.get("x"), inject.get("y"))
         m.update_step(0, self.global_step)
-        rays = batch["rays"]
-        dev = rays.device
-        rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
-        n_rays = rays.shape[0]
-        jitter = inject.get("jitter")
-        if jitter is None and m.randomized:
-            jitter = torch.rand(n_rays, device=dev)
+        prep = self._take_prefetch() if not inject else None
+        if prep is None:
+            prep = self._march_begin(inject)
+            total, cmax = prep["handle"].stats.tolist()              # the step's one host sync
+        else:
+            prep["ready"].synchronize()                              # stats are in pinned memory
+            torch.cuda.current_stream().wait_event(prep["ready"])
+            total, cmax = prep["stats_host"].tolist()
+        batch, rays_d, h = prep["batch"], prep["handle"].rays_d, prep["handle"]
+        dev = rays_d.device
+        n_rays = rays_d.shape[0]
         pts_random, perturb = inject.get("pts_random"), inject.get("perturb")
         if pts_random is None:
             pts_random = torch.rand([1024 * 2, 3], device=dev) * 2 - 1
@@ -355,22 +423,18 @@ class OrthoNeuSSystem:
             perturb = torch.randn_like(pts_random)
         n_r = pts_random.shape[0]
         with torch.no_grad():
-            tmin, tmax = ops.ray_aabb(rays_o, rays_d, m._aabb_host,
-                                      jitter if m.randomized else None, m.render_step_size)
-            occ, res = None, 0
-            if m.config.grid_prune:
-                occ, res = m.occupancy_grid.binary_u8(), m.occupancy_grid.res
-            allp, ts, te, off, cnt, n_s = ops.ray_march_points(
-                rays_o, rays_d, tmin, tmax, m._aabb_host, occ, res, m.render_step_size,
-                tail_rows=2 * n_r)
+            allp, ts, te = ops.ray_march_finish(h, total, cmax, tail_rows=2 * n_r)
+            off, cnt, n_s = h.offsets, h.counts, total
             RayPacking.total = n_s
             allp[n_s:n_s + n_r] = pts_random
             torch.add(pts_random, perturb, alpha=1e-2, out=allp[n_s + n_r:])
-        n_all = n_s + 2 * n_r
         if m.config.dynamic_ray_sampling and n_s > 0:
             tr = int(self.train_num_rays * (self.train_num_samples / n_s))
             self.train_num_rays = min(int(self.train_num_rays * 0.9 + tr * 0.1),
                                       m.config.max_train_num_rays)
+        if not inject:
+            self._launch_prefetch()
+        n_all = n_s + 2 * n_r
         self._set_lr()
         self.optimizer.zero_grad(set_to_none=True)
 

@@ -210,12 +210,16 @@ def ray_march_single_pass(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, 
     return ray_indices, t_starts, t_ends, offsets, counts
 
 
-def ray_march_points(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step, tail_rows=0):
-    """Single-pass march for the fused optimisation step: returns
-    (points (total + tail_rows, 3), t_starts, t_ends, offsets, counts, total) where
-    points[:total] = rays_o[r] + rays_d[r] * (t_start + t_end) / 2 and the tail rows are left for
-    the caller (random / perturbed points evaluated in the same geometry launch).  One host copy
-    (total, max count); no ray_indices."""
+class MarchHandle:
+    """State between ray_march_begin (march + offsets scan, all asynchronous) and
+    ray_march_finish (needs the host-side total to size the packed outputs)."""
+    __slots__ = ("rays_o", "rays_d", "counts", "offsets", "stats", "scratch", "cap", "n")
+
+
+def ray_march_begin(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step):
+    """Launch the single-pass march into the scratch rows and the offsets scan.  Nothing here
+    waits for the device; `handle.stats` (int32[2] = total, max count) is read by the caller
+    (directly, or through an asynchronous copy when the march is prefetched on a side stream)."""
     import math
     rays_o, rays_d = _f32c(rays_o), _f32c(rays_d)
     n = rays_o.shape[0]
@@ -230,27 +234,46 @@ def ray_march_points(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step,
         sc = (torch.empty(rows * cap, dtype=torch.float32, device=dev),
               torch.empty(rows * cap, dtype=torch.float32, device=dev))
         _MARCH_SCRATCH[key] = sc
-    counts = torch.empty(n, dtype=torch.int32, device=dev)
-    offsets = torch.empty(n, dtype=torch.int32, device=dev)
-    stats = torch.empty(2, dtype=torch.int32, device=dev)
+    h = MarchHandle()
+    h.rays_o, h.rays_d, h.scratch, h.cap, h.n = rays_o, rays_d, sc, cap, n
+    h.counts = torch.empty(n, dtype=torch.int32, device=dev)
+    h.offsets = torch.empty(n, dtype=torch.int32, device=dev)
+    h.stats = torch.empty(2, dtype=torch.int32, device=dev)
     occp = ptr(occ_binary, torch.uint8) if occ_binary is not None else None
     check(lib().dsu_ray_march_scratch(ptr(rays_o), ptr(rays_d), ptr(t_min), ptr(t_max), n, a, occp,
-                                      int(res), float(step), cap, ptr(counts), ptr(sc[0]),
+                                      int(res), float(step), cap, ptr(h.counts), ptr(sc[0]),
                                       ptr(sc[1]), stream()), "dsu_ray_march_scratch")
-    check(lib().dsu_ray_offsets(ptr(counts), n, ptr(offsets), ptr(stats), stream()),
+    check(lib().dsu_ray_offsets(ptr(h.counts), n, ptr(h.offsets), ptr(h.stats), stream()),
           "dsu_ray_offsets")
-    total, cmax = stats.tolist()                                  # the step's one host sync
-    if cmax > cap:
-        raise DsuError(f"a ray produced {cmax} samples, above the scratch capacity {cap}")
+    return h
+
+
+def ray_march_finish(h, total, cmax, tail_rows=0):
+    """Pack the scratch rows: returns (points (total + tail_rows, 3), t_starts, t_ends)."""
+    if cmax > h.cap:
+        raise DsuError(f"a ray produced {cmax} samples, above the scratch capacity {h.cap}")
+    dev = h.rays_o.device
     points = torch.empty(total + tail_rows, 3, dtype=torch.float32, device=dev)
     t_starts = torch.empty(total, dtype=torch.float32, device=dev)
     t_ends = torch.empty(total, dtype=torch.float32, device=dev)
     if total > 0:
-        check(lib().dsu_ray_compact_points(ptr(sc[0]), ptr(sc[1]), cap, ptr(offsets), ptr(counts),
-                                           n, ptr(rays_o), ptr(rays_d), ptr(t_starts),
-                                           ptr(t_ends), ptr(points), stream()),
-              "dsu_ray_compact_points")
-    return points, t_starts, t_ends, offsets, counts, total
+        check(lib().dsu_ray_compact_points(ptr(h.scratch[0]), ptr(h.scratch[1]), h.cap,
+                                           ptr(h.offsets), ptr(h.counts), h.n, ptr(h.rays_o),
+                                           ptr(h.rays_d), ptr(t_starts), ptr(t_ends), ptr(points),
+                                           stream()), "dsu_ray_compact_points")
+    return points, t_starts, t_ends
+
+
+def ray_march_points(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step, tail_rows=0):
+    """Single-pass march for the fused optimisation step: returns
+    (points (total + tail_rows, 3), t_starts, t_ends, offsets, counts, total) where
+    points[:total] = rays_o[r] + rays_d[r] * (t_start + t_end) / 2 and the tail rows are left for
+    the caller (random / perturbed points evaluated in the same geometry launch).  One host copy
+    (total, max count); no ray_indices."""
+    h = ray_march_begin(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step)
+    total, cmax = h.stats.tolist()                                # the step's one host sync
+    points, t_starts, t_ends = ray_march_finish(h, total, cmax, tail_rows)
+    return points, t_starts, t_ends, h.offsets, h.counts, total
 
 
 def _tex_struct(params):
