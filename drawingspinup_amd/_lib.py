@@ -57,6 +57,11 @@ _PROTOS = {
     "dsu_sdf_fd_bwd": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, c_i64, c_f32, c_f32,
                        c_u32, P, P, P, P, P, P, P, P, P, P, c_i64, P],
     "dsu_sdf_fd_bwd_workspace_bytes": [C.POINTER(HashGridCfg), c_i64],
+    "dsu_sdf_fd_fwd_cached": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, c_i64, c_f32, c_f32,
+                              c_u32, P, P, P, P, P, P],
+    "dsu_sdf_fd_bwd_cached": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, c_i64, c_f32, c_f32,
+                              c_u32, P, P, P, P, P, P, P, P, P, P, c_i64, P, P],
+    "dsu_sdf_fd_enc_cache_bytes": [c_i64, c_u32],
     "dsu_ray_aabb": [P, P, c_i64, P, P, c_f32, P, P, P],
     "dsu_ray_march_count": [P, P, P, P, c_i64, P, P, c_i32, c_f32, P, P],
     "dsu_ray_march_fill": [P, P, P, P, c_i64, P, P, c_i32, c_f32, P, P, P, P, P],

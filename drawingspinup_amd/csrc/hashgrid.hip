@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
     const __half2* __restrict__ table, GridMeta m, dsu_sdf_mlp mlp,
     const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
     uint32_t active, float* __restrict__ sdf, float* __restrict__ grad,
-    float* __restrict__ feature, float* __restrict__ laplace) {
+    float* __restrict__ feature, float* __restrict__ laplace, __half2* __restrict__ enc) {
   using L = MlpLds<NL>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   load_mlp_to_lds<NL>(lds, mlp.w0, mlp.b0, mlp.w1, mlp.b1);
@@ -219,6 +219,14 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
       float in[L::DIN];
       encode_input<NL>(table, m, active, contract(q[0], radius), contract(q[1], radius),
                        contract(q[2], radius), in);
+      if (enc != nullptr) {
+        // interpolated f16 features of this evaluation, kept for the backward pass (exact: the
+        // floats are widened halfs).  Layout [eval][point][active level].
+        __half2* row = enc + ((size_t)e * n + i) * active;
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+          if ((uint32_t)l < active) row[l] = __floats2half2_rn(in[3 + 2 * l], in[3 + 2 * l + 1]);
+      }
       float h[HID];
       layer0<NL>(lds, in, kmax, h);
 #pragma unroll
@@ -674,7 +682,7 @@ int dsu_sdf_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, const d
 int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
                    const float* pts, int64_t n, float radius, float eps,
                    uint32_t active_levels, float* sdf, float* grad, float* feature,
-                   float* laplace, void* stream) {
+                   float* laplace, void* enc_cache, void* stream) {
   if (!cfg || !table_f16 || !mlp || (!pts && n) || (!sdf && n) || n < 0) return DSU_EINVAL;
   if (!mlp->w0 || !mlp->b0 || !mlp->w1 || !mlp->b1) return DSU_EINVAL;
   if (active_levels > cfg->n_levels || !(eps > 0.0f)) return DSU_EINVAL;
@@ -689,7 +697,7 @@ int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, cons
     const size_t shm = MlpLds<NL>::TOTAL * sizeof(float);
     sdf_fd_fwd_kernel<NL><<<dim3(blocks), dim3(256), shm, s>>>(
         (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, sdf, grad,
-        feature, laplace);
+        feature, laplace, (__half2*)enc_cache);
   });
   DSU_CHECK_LAUNCH();
   return DSU_OK;

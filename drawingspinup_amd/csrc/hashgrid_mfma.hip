@@ -110,7 +110,7 @@ __device__ __forceinline__ void encode_input_p(const __half2* __restrict__ table
 // acc[half][T]: hidden pre-activations; then softplus in place.
 template <int NL>
 __device__ __forceinline__ void layer0_mfma(const Frags<NL>& f, const float* in, uint32_t active,
-                                            f32x16 (&acc)[2][2]) {
+                                            f32x16 (&acc)[2][2], int ablate = 0) {
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -128,6 +128,7 @@ __device__ __forceinline__ void layer0_mfma(const Frags<NL>& f, const float* in,
       acc[1][T] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w0[T][t], b1, acc[1][T], 0, 0, 0);
     }
   }
+  if (ablate & 32) return;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -347,7 +348,8 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
     uint32_t active, const float* __restrict__ d_sdf, const float* __restrict__ d_grad,
     const float* __restrict__ d_feature, const float* __restrict__ d_laplace,
-    float* __restrict__ gtable, float* __restrict__ partials, int ablate) {
+    float* __restrict__ gtable, float* __restrict__ partials, const __half2* __restrict__ enc,
+    int ablate) {
   constexpr int KIN = MC<NL>::KIN;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* w1perm = lds;
@@ -414,9 +416,28 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
       const float cx = contract(q[0], radius), cy = contract(q[1], radius),
                   cz = contract(q[2], radius);
       float in[KIN];
-      encode_input_p<NL>(table, m, active, cx, cy, cz, in);
+      if (ablate & 16) {
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) in[k] = cx * (float)k + cy;
+      } else if (enc != nullptr) {
+        // features saved by the forward pass: no table gathers in the backward pass
+        const __half2* row = enc + ((size_t)e * n + ii) * active;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+          float2 f = make_float2(0.0f, 0.0f);
+          if ((uint32_t)l < active) f = __half22float2(row[l]);
+          in[2 * l] = f.x;
+          in[2 * l + 1] = f.y;
+        }
+        in[2 * NL + 0] = cx * 2.0f + -1.0f;
+        in[2 * NL + 1] = cy * 2.0f + -1.0f;
+        in[2 * NL + 2] = cz * 2.0f + -1.0f;
+        in[2 * NL + 3] = 1.0f;
+      } else {
+        encode_input_p<NL>(table, m, active, cx, cy, cz, in);
+      }
       f32x16 H[2][2];
-      layer0_mfma<NL>(fr, in, active, H);
+      layer0_mfma<NL>(fr, in, active, H, ablate);
       // upstream gradient on this evaluation's outputs (own point)
       float dout[NOUT];
 #pragma unroll
@@ -477,6 +498,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
               }
             }
           }
+          if (!(ablate & 64))
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             // softplus'(pre) = sigmoid(100 pre) = 1 - exp(-100 softplus(pre))
@@ -737,7 +759,7 @@ extern "C" int dsu_sdf_fwd_valu(const dsu_hashgrid_cfg*, const void*, const dsu_
                                 const float*, int64_t, float, uint32_t, uint32_t, float*, void*);
 extern "C" int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg*, const void*, const dsu_sdf_mlp*,
                                    const float*, int64_t, float, float, uint32_t, float*, float*,
-                                   float*, float*, void*);
+                                   float*, float*, void*, void*);
 extern "C" int dsu_sdf_fd_bwd_valu(const dsu_hashgrid_cfg*, const void*, const dsu_sdf_mlp*,
                                    const float*, int64_t, float, float, uint32_t, const float*,
                                    const float*, const float*, const float*, float*, float*,
@@ -786,13 +808,13 @@ int dsu_sdf_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sd
   return DSU_OK;
 }
 
-int dsu_sdf_fd_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+int dsu_sdf_fd_fwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
                    const float* pts, int64_t n, float radius, float eps,
                    uint32_t active_levels, float* sdf, float* grad, float* feature,
-                   float* laplace, void* stream) {
-  if (use_valu(true))
+                   float* laplace, void* enc_cache, void* stream) {
+  if (use_valu(true) || enc_cache != nullptr)   // the cache is written by the VALU kernel
     return dsu_sdf_fd_fwd_valu(cfg, table_f16, mlp, pts, n, radius, eps, active_levels, sdf, grad,
-                               feature, laplace, stream);
+                               feature, laplace, enc_cache, stream);
   if (!cfg || !table_f16 || !mlp || (!pts && n) || (!sdf && n) || n < 0) return DSU_EINVAL;
   if (!mlp->w0 || !mlp->b0 || !mlp->w1 || !mlp->b1) return DSU_EINVAL;
   if (active_levels > cfg->n_levels || !(eps > 0.0f)) return DSU_EINVAL;
@@ -812,6 +834,19 @@ int dsu_sdf_fd_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu
   return DSU_OK;
 }
 
+int dsu_sdf_fd_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                   const float* pts, int64_t n, float radius, float eps,
+                   uint32_t active_levels, float* sdf, float* grad, float* feature,
+                   float* laplace, void* stream) {
+  return dsu_sdf_fd_fwd_cached(cfg, table_f16, mlp, pts, n, radius, eps, active_levels, sdf, grad,
+                               feature, laplace, nullptr, stream);
+}
+
+int64_t dsu_sdf_fd_enc_cache_bytes(int64_t n, uint32_t active_levels) {
+  if (n < 0 || active_levels > DSU_MAX_LEVELS) return DSU_EINVAL;
+  return (int64_t)7 * n * active_levels * 4;
+}
+
 int64_t dsu_sdf_fd_bwd_workspace_bytes(const dsu_hashgrid_cfg* cfg, int64_t n) {
   if (use_valu(false)) return dsu_sdf_fd_bwd_workspace_bytes_valu(cfg, n);
   if (!cfg || n < 0) return DSU_EINVAL;
@@ -820,12 +855,12 @@ int64_t dsu_sdf_fd_bwd_workspace_bytes(const dsu_hashgrid_cfg* cfg, int64_t n) {
   return (int64_t)blocks * PART_STRIDE * sizeof(float);
 }
 
-int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+int dsu_sdf_fd_bwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
                    const float* pts, int64_t n, float radius, float eps,
                    uint32_t active_levels, const float* d_sdf, const float* d_grad,
                    const float* d_feature, const float* d_laplace, float* grad_table,
                    float* g_w0, float* g_b0, float* g_w1, float* g_b1, void* workspace,
-                   int64_t workspace_bytes, void* stream) {
+                   int64_t workspace_bytes, const void* enc_cache, void* stream) {
   if (use_valu(false))
     return dsu_sdf_fd_bwd_valu(cfg, table_f16, mlp, pts, n, radius, eps, active_levels, d_sdf,
                                d_grad, d_feature, d_laplace, grad_table, g_w0, g_b0, g_w1, g_b1,
@@ -851,13 +886,24 @@ int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu
       return DSU_ELAUNCH;
     sdf_fd_bwd_mfma_kernel<NL><<<dim3(blocks), dim3(256), shm, s>>>(
         (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
-        d_grad, d_feature, d_laplace, grad_table, (float*)workspace,
+        d_grad, d_feature, d_laplace, grad_table, (float*)workspace, (const __half2*)enc_cache,
         getenv("DSU_BWD_ABLATE") ? atoi(getenv("DSU_BWD_ABLATE")) : 0);
     reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 63) / 64), dim3(1024), 0, s>>>(
         (const float*)workspace, blocks, g_w0, g_b0, g_w1, g_b1);
   });
   DSU_CHECK_LAUNCH();
   return DSU_OK;
+}
+
+int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                   const float* pts, int64_t n, float radius, float eps,
+                   uint32_t active_levels, const float* d_sdf, const float* d_grad,
+                   const float* d_feature, const float* d_laplace, float* grad_table,
+                   float* g_w0, float* g_b0, float* g_w1, float* g_b1, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
+  return dsu_sdf_fd_bwd_cached(cfg, table_f16, mlp, pts, n, radius, eps, active_levels, d_sdf,
+                               d_grad, d_feature, d_laplace, grad_table, g_w0, g_b0, g_w1, g_b1,
+                               workspace, workspace_bytes, nullptr, stream);
 }
 
 }  // extern "C"

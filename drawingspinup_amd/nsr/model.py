@@ -136,9 +136,9 @@ class _SdfFdFn(torch.autograd.Function):
         table = enc.table_f16()
         mlp = [w0.detach().contiguous(), b0.detach().contiguous(), w1.detach().contiguous(),
                b1.detach().contiguous()]
-        sdf, grad, feat, lap = ops.sdf_fd_fwd(enc.cfg, table, mlp, pts, radius, eps, active,
-                                              need[0], need[1], need[2])
-        ctx.save_for_backward(pts, table, *mlp)
+        sdf, grad, feat, lap, cache = ops.sdf_fd_fwd(enc.cfg, table, mlp, pts, radius, eps, active,
+                                                     need[0], need[1], need[2], enc_cache=True)
+        ctx.save_for_backward(pts, table, cache, *mlp)
         ctx.meta = (enc.cfg, radius, eps, active)
         outs = [sdf] + [t for t in (grad, feat, lap) if t is not None]
         ctx.need = need
@@ -146,7 +146,7 @@ class _SdfFdFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, *gouts):
-        pts, table, w0, b0, w1, b1 = ctx.saved_tensors
+        pts, table, cache, w0, b0, w1, b1 = ctx.saved_tensors
         cfg, radius, eps, active = ctx.meta
         it = iter(gouts)
         d_sdf = next(it)
@@ -154,7 +154,7 @@ class _SdfFdFn(torch.autograd.Function):
         d_feat = next(it) if ctx.need[1] else None
         d_lap = next(it) if ctx.need[2] else None
         gt, g = ops.sdf_fd_bwd(cfg, table, [w0, b0, w1, b1], pts, radius, eps, active, d_sdf,
-                               d_grad, d_feat, d_lap)
+                               d_grad, d_feat, d_lap, enc_cache=cache)
         return None, gt, g[0], g[1], g[2], g[3], None, None, None, None, None
 
 

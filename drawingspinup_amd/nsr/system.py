@@ -445,8 +445,9 @@ class OrthoNeuSSystem:
         eps, active = geo._finite_difference_eps, geo.active_levels
         inv_s = m.variance.inv_s
         with torch.no_grad():
-            a_sdf, a_grad, a_feat, _ = ops.sdf_fd_fwd(enc.cfg, table, mlp, allp, geo.radius, eps,
-                                                      active, True, True, False)
+            a_sdf, a_grad, a_feat, _, enc_cache = ops.sdf_fd_fwd(
+                enc.cfg, table, mlp, allp, geo.radius, eps, active, True, True, False,
+                enc_cache=True)
             normal, tex_in = ops.shade_prep_fwd(a_grad[:n_s], a_feat[:n_s])
         tex_fused = m.texture.fused_ok
         if tex_fused:
@@ -494,7 +495,8 @@ class OrthoNeuSSystem:
                                              L.lambda_sparsity, L.sparsity_scale, smooth,
                                              d_sdf_all, d_grad_all)
             g_table, g = ops.sdf_fd_bwd(enc.cfg, table, mlp, allp, geo.radius, eps, active,
-                                        d_sdf_all, d_grad_all, d_feat_all, None)
+                                        d_sdf_all, d_grad_all, d_feat_all, None,
+                                        enc_cache=enc_cache)
         enc.params.grad = g_table
         lin0, lin1 = [l for l in geo.network.layers if isinstance(l, torch.nn.Linear)]
         if w0.requires_grad and w0.grad_fn is not None:

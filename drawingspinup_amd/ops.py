@@ -90,23 +90,31 @@ def sdf_fwd(cfg, table_f16, mlp, pts, radius, active_levels, n_out=1):
 
 
 def sdf_fd_fwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, with_grad=True,
-               with_feature=True, with_laplace=True):
+               with_feature=True, with_laplace=True, enc_cache=None):
+    """enc_cache: True -> also return the feature cache tensor for sdf_fd_bwd (5th value)."""
     pts = _f32c(pts)
     n = pts.shape[0]
     dev = pts.device
+    cache = None
+    if enc_cache:
+        nbytes = int(lib().dsu_sdf_fd_enc_cache_bytes(n, int(active_levels)))
+        cache = torch.empty(max(nbytes, 4) // 2, dtype=torch.float16, device=dev)
     sdf = torch.empty(n, dtype=torch.float32, device=dev)
     grad = torch.empty((n, 3), dtype=torch.float32, device=dev) if with_grad else None
     feat = torch.empty((n, 13), dtype=torch.float32, device=dev) if with_feature else None
     lap = torch.empty(n, dtype=torch.float32, device=dev) if with_laplace else None
     c, m = cfg.c(), _mlp_struct(*mlp)
-    check(lib().dsu_sdf_fd_fwd(C.byref(c), ptr(table_f16, torch.float16), C.byref(m), ptr(pts),
-                               n, float(radius), float(eps), int(active_levels), ptr(sdf),
-                               ptr(grad), ptr(feat), ptr(lap), stream()), "dsu_sdf_fd_fwd")
+    check(lib().dsu_sdf_fd_fwd_cached(C.byref(c), ptr(table_f16, torch.float16), C.byref(m),
+                                      ptr(pts), n, float(radius), float(eps), int(active_levels),
+                                      ptr(sdf), ptr(grad), ptr(feat), ptr(lap), ptr(cache),
+                                      stream()), "dsu_sdf_fd_fwd")
+    if enc_cache:
+        return sdf, grad, feat, lap, cache
     return sdf, grad, feat, lap
 
 
 def sdf_fd_bwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, d_sdf, d_grad, d_feature,
-               d_laplace, grad_table=None):
+               d_laplace, grad_table=None, enc_cache=None):
     pts = _f32c(pts)
     n = pts.shape[0]
     dev = pts.device
@@ -122,11 +130,15 @@ def sdf_fd_bwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, d_sdf, d_gr
     if wbytes < 0:
         check(int(wbytes), "dsu_sdf_fd_bwd_workspace_bytes")
     ws = torch.empty(max(int(wbytes), 4) // 4, dtype=torch.float32, device=dev)
-    check(lib().dsu_sdf_fd_bwd(C.byref(c), ptr(table_f16, torch.float16), C.byref(m), ptr(pts),
-                               n, float(radius), float(eps), int(active_levels), ptr(d[0]),
-                               ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(grad_table), ptr(g[0]),
-                               ptr(g[1]), ptr(g[2]), ptr(g[3]), ptr(ws), int(wbytes), stream()),
-          "dsu_sdf_fd_bwd")
+    if enc_cache is not None:
+        need = int(lib().dsu_sdf_fd_enc_cache_bytes(n, int(active_levels)))
+        if enc_cache.numel() * enc_cache.element_size() < need:
+            raise DsuError("feature cache smaller than dsu_sdf_fd_enc_cache_bytes")
+    check(lib().dsu_sdf_fd_bwd_cached(C.byref(c), ptr(table_f16, torch.float16), C.byref(m),
+                                      ptr(pts), n, float(radius), float(eps), int(active_levels),
+                                      ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(grad_table),
+                                      ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]), ptr(ws),
+                                      int(wbytes), ptr(enc_cache), stream()), "dsu_sdf_fd_bwd")
     return grad_table, g
 
 

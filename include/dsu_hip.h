@@ -115,6 +115,24 @@ int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu
                    const float* d_feature, const float* d_laplace, float* grad_table,
                    float* g_w0, float* g_b0, float* g_w1, float* g_b1, void* workspace,
                    int64_t workspace_bytes, void* stream);
+/* Same two calls with a feature cache between them: the forward pass stores the interpolated
+ * f16 hash-grid features of all 7 evaluations ([eval][point][active level] half2,
+ * dsu_sdf_fd_enc_cache_bytes(n, active_levels) bytes) and the backward pass reads them back
+ * instead of repeating the 7 x active_levels x 8 table gathers per point.  Same results bit
+ * for bit (the cached values ARE the forward's features); enc_cache NULL = the plain calls. */
+int dsu_sdf_fd_fwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16,
+                          const dsu_sdf_mlp* mlp, const float* pts, int64_t n, float radius,
+                          float eps, uint32_t active_levels, float* sdf, float* grad,
+                          float* feature, float* laplace, void* enc_cache, void* stream);
+int dsu_sdf_fd_bwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16,
+                          const dsu_sdf_mlp* mlp, const float* pts, int64_t n, float radius,
+                          float eps, uint32_t active_levels, const float* d_sdf,
+                          const float* d_grad, const float* d_feature, const float* d_laplace,
+                          float* grad_table, float* g_w0, float* g_b0, float* g_w1, float* g_b1,
+                          void* workspace, int64_t workspace_bytes, const void* enc_cache,
+                          void* stream);
+int64_t dsu_sdf_fd_enc_cache_bytes(int64_t n, uint32_t active_levels);
+
 /* Bytes of device scratch dsu_sdf_fd_bwd needs for n points (per-workgroup partial MLP
  * gradients, summed by a second kernel: deterministic, no same-address atomics).  <0 = error. */
 int64_t dsu_sdf_fd_bwd_workspace_bytes(const dsu_hashgrid_cfg* cfg, int64_t n);

@@ -153,6 +153,34 @@ def test_sdf_fd_bwd(dev):
                                    atol=1e-5 * max(np.abs(r).max(), 1.0))
 
 
+def test_sdf_fd_feature_cache_round_trip(dev):
+    """Forward with the feature cache == plain forward (bit for bit); the cache holds exactly
+    the forward's f16 features; backward from the cache == backward that re-gathers, up to the
+    order of the float atomics (the MLP inputs are identical bits)."""
+    tab = _table(21, 0.5).to(dev)
+    mlp = [m.to(dev) for m in _mlp(22)]
+    n = 5000 + 13
+    pts = _pts(n, 23, -1.0, 1.0).to(dev)
+    eps, active, radius = 0.027, 6, 1.0
+    plain = ops.sdf_fd_fwd(CFG, tab, mlp, pts, radius, eps, active)
+    cached = ops.sdf_fd_fwd(CFG, tab, mlp, pts, radius, eps, active, enc_cache=True)
+    for a_, b_ in zip(plain, cached[:4]):
+        assert torch.equal(a_, b_)
+    cache = cached[4].view(7, n, active, 2)
+    enc = ops.hashgrid_encode_fwd(CFG, tab, ((pts + radius) / (2 * radius)).clamp(0, 1), active)
+    assert torch.equal(cache[0].reshape(n, -1), enc[:, :2 * active])
+    g = torch.Generator().manual_seed(24)
+    d = [torch.randn(n, generator=g).to(dev), (torch.randn(n, 3, generator=g) * 0.1).to(dev),
+         torch.randn(n, 13, generator=g).to(dev), (torch.randn(n, generator=g) * 1e-3).to(dev)]
+    gt0, gm0 = ops.sdf_fd_bwd(CFG, tab, mlp, pts, radius, eps, active, *d)
+    gt1, gm1 = ops.sdf_fd_bwd(CFG, tab, mlp, pts, radius, eps, active, *d, enc_cache=cached[4])
+    scale = float(gt0.abs().max())
+    assert float((gt0 - gt1).abs().max()) < 1e-5 * scale
+    assert torch.equal(gt0 != 0, gt1 != 0)
+    for a_, b_ in zip(gm0, gm1):
+        assert float((a_ - b_).abs().max()) < 1e-5 * (float(a_.abs().max()) + 1e-12)
+
+
 def test_sdf_full_size_linearity(dev):
     """BASELINE size (2^21-point export chunk): property check instead of the slow oracle.
     The network is affine in the second-layer bias: out(b1 + c) - out(b1) == c."""
