@@ -310,13 +310,21 @@ static_assert((BWD_CACHE_OFF + GC_SLOTS) % 2 == 0, "i64 accumulators need 8-byte
 // LDS float atomics retire ~1 lane per 3 clocks per CU (measured, profiles/round1_lds_atomics.txt)
 // while integer atomics cost ~10 clocks per instruction whatever the lane count, so the cache
 // accumulates in 64-bit fixed point (2^-40 resolution, +-8.4e6 range): ~20x cheaper per
-// contribution when all lanes are busy, and order-independent.
+// contribution when all lanes are busy, and order-independent.  A single contribution is
+// clamped to +-1023 (a per-sample table gradient that large means the run has diverged).
 constexpr float GC_FIX_SCALE = 1099511627776.0f;           // 2^40
+constexpr float GC_FIX_MAX = 1023.0f;                      // per-contribution clamp (see gc_fix)
+// float -> fixed point without the (slow, emulated) f32->i64 conversion: adding 1.5 * 2^52 to
+// v * 2^40 in double leaves round-to-nearest(v * 2^40) in the low mantissa bits, so the
+// difference of the two bit patterns IS the integer (exact for |v * 2^40| < 2^51).
 __device__ __forceinline__ unsigned long long gc_fix(float v) {
-  return (unsigned long long)__float2ll_rn(v * GC_FIX_SCALE);
+  const double magic = 6755399441055744.0;                 // 1.5 * 2^52
+  const float c = fminf(fmaxf(v, -GC_FIX_MAX), GC_FIX_MAX);
+  const double d = (double)c * (double)GC_FIX_SCALE + magic;
+  return (unsigned long long)(__double_as_longlong(d) - __double_as_longlong(magic));
 }
 __device__ __forceinline__ float gc_unfix(unsigned long long a) {
-  return __ll2float_rn((long long)a) * (1.0f / GC_FIX_SCALE);
+  return (float)((double)(long long)a * (1.0 / (double)GC_FIX_SCALE));
 }
 
 // one queued contribution -> cache (3 probes) or, when the cache is full around its slot, a global
@@ -338,6 +346,7 @@ __device__ __forceinline__ void gc_commit(uint32_t* keys, unsigned long long* ac
   unsafeAtomicAdd(gtable + (size_t)entry * 2, v0);
   unsafeAtomicAdd(gtable + (size_t)entry * 2 + 1, v1);
 }
+
 // per-workgroup partial vector: gw0p[64 feat][32 k'] | gw1p[64 feat][32 o'] | gb1[16]
 constexpr int PART_GW0 = 0, PART_GW1 = 64 * 32, PART_GB1 = 2 * 64 * 32;
 constexpr int PART_STRIDE = 2 * 64 * 32 + 64;
