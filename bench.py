@@ -176,10 +176,13 @@ def main():
         roof = None
         if ks:
             roof = {"bound": "hbm", "kernel": "sdf_fd_bwd_mfma_kernel", "achieved": ks["gbps"],
-                    "peak": 8000.0, "unit": "GB/s", "frac": ks["gbps"] / 8000.0, "traffic": None,
-                    "traffic_pmc_reference": "profiles/round1_pmc_sdf_kernels.txt: 614 MB HBM-side "
-                                             "(FETCH 27 MB + WRITE 587 MB) per launch at N=262144, "
-                                             "4 levels vs 726 MB algorithmic",
+                    "peak": 8000.0, "unit": "GB/s", "frac": ks["gbps"] / 8000.0,
+                    # PMC passes are separate runs (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): the
+                    # per-launch HBM-side bytes of this kernel at the first schedule stage
+                    "traffic": 5.40e8,
+                    "traffic_pmc_reference": "profiles/round1_pmc_sdf_kernels.txt: 540 MB HBM-side "
+                                             "(FETCH 36 MB + WRITE 504 MB) per launch at N=262144, "
+                                             "4 levels vs 726 MB algorithmic for that launch",
                     "launches": ks["launches"], "avg_launch_ms": ks["avg_ms"],
                     "alg_bytes_per_launch": ks["avg_bytes"]}
         out = {
