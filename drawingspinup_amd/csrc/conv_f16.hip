@@ -39,6 +39,8 @@ struct CArgs {
   f16* out;             // (B, OH, OW, O)
   int B, H, W, C, O, OH, OW, KS, stride, pad, up2;
   int Ktot;             // KS*KS*C
+  int split_k;          // > 1: blockIdx.z owns a contiguous range of K chunks, f32 partials -> ws
+  float* ws;            // (split_k, npix, O) f32 when split_k > 1
 };
 
 template <int DUMMY>
@@ -117,11 +119,16 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
-  const int nchunks = (a.Ktot + BK - 1) / BK;
-  load_regs(0);
-  store_lds(0);
+  // K range of this workgroup (split-K: small-spatial levels have too few output tiles to fill
+  // 256 CUs, so the 9*C reduction is spread over blockIdx.z and summed by conv_f16_reduce_kernel)
+  const int total_chunks = (a.Ktot + BK - 1) / BK;
+  const int per = (total_chunks + a.split_k - 1) / a.split_k;
+  const int ch0 = blockIdx.z * per;
+  const int nchunks = min(total_chunks, ch0 + per);
+  load_regs(ch0);
+  store_lds(ch0 & 1);
   __syncthreads();
-  for (int ch = 0; ch < nchunks; ++ch) {
+  for (int ch = ch0; ch < nchunks; ++ch) {
     const int buf = ch & 1;
     if (ch + 1 < nchunks) load_regs(ch + 1);       // global loads in flight during the MFMAs
 #pragma unroll
@@ -147,6 +154,28 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
 
   // epilogue: lane -> pixel (wn*64 + j*32 + l31); register quad r4 -> channels
   //   o = o0 + wm*64 + i*32 + 8*r4 + 4*hh + {0..3}
+  if (a.split_k > 1) {
+    float* ws = a.ws + (size_t)blockIdx.z * npix * a.O;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t p = p0 + wn * 64 + j * 32 + l31;
+      if (p >= npix) continue;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4) {
+          const int o = o0 + wm * 64 + i * 32 + 8 * r4 + 4 * hh;
+          if (o + 3 < a.O) {
+            *reinterpret_cast<float4*>(ws + (size_t)p * a.O + o) =
+                make_float4(acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2],
+                            acc[i][j][4 * r4 + 3]);
+          } else {
+            for (int e = 0; e < 4 && o + e < a.O; ++e) ws[(size_t)p * a.O + o + e] = acc[i][j][4 * r4 + e];
+          }
+        }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
     const int64_t p = p0 + wn * 64 + j * 32 + l31;
@@ -195,15 +224,77 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
   }
 }
 
+// out[p][o] = f16(sum_z ws[z][p][o] + bias[o] + addvec[n][o] + residual[p][o]); 4 channels per thread
+__global__ __launch_bounds__(256) void conv_f16_reduce_kernel(CArgs a, int64_t npix) {
+  const int O4 = (a.O + 3) >> 2;
+  const int64_t total = npix * O4;
+  for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < total;
+       t += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t p = t / O4;
+    const int o = (int)(t - p * O4) * 4;
+    const int n = (int)(p / (a.OH * a.OW));
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool full = o + 3 < a.O && (a.O & 3) == 0;
+    for (int z = 0; z < a.split_k; ++z) {
+      const float* w = a.ws + ((size_t)z * npix + p) * a.O + o;
+      if (full) {
+        const float4 q = *reinterpret_cast<const float4*>(w);
+        v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+      } else {
+        for (int e = 0; e < 4 && o + e < a.O; ++e) v[e] += w[e];
+      }
+    }
+    for (int e = 0; e < 4 && o + e < a.O; ++e) {
+      float tv = v[e];
+      if (a.bias) tv += (float)a.bias[o + e];
+      if (a.addvec) tv += (float)a.addvec[(size_t)n * a.O + o + e];
+      if (a.residual) tv += (float)a.residual[(size_t)p * a.O + o + e];
+      a.out[(size_t)p * a.O + o + e] = (f16)tv;
+    }
+  }
+}
+
+int conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
+
 }  // namespace
 
 extern "C" {
 
-int dsu_conv2d_nhwc_f16_fwd(const void* input, const void* weight_okc, const void* bias,
-                            int32_t B, int32_t H, int32_t W, int32_t C, int32_t O, int32_t k,
-                            int32_t stride, int32_t pad, int32_t upsample2x, const void* addvec,
-                            const void* residual, void* out, void* stream) {
+int32_t dsu_conv2d_nhwc_f16_split_k(int32_t B, int32_t H, int32_t W, int32_t C, int32_t O,
+                                    int32_t k, int32_t stride, int32_t pad, int32_t upsample2x) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || O <= 0 || k <= 0 || stride <= 0 || pad < 0)
+    return 1;
+  const int IH = upsample2x ? 2 * H : H, IW = upsample2x ? 2 * W : W;
+  const int OH = conv_out_dim(IH, k, stride, pad), OW = conv_out_dim(IW, k, stride, pad);
+  if (OH <= 0 || OW <= 0) return 1;
+  const int64_t npix = (int64_t)B * OH * OW;
+  const int64_t tiles = ((npix + TN - 1) / TN) * ((O + TM - 1) / TM);
+  const int chunks = (k * k * C + BK - 1) / BK;
+  if (tiles >= 256 || chunks < 8) return 1;          // the output tiles already fill the chip
+  int64_t s = (512 + tiles - 1) / tiles;             // aim at >= 2 workgroups per CU
+  if (s > chunks / 4) s = chunks / 4;                // keep >= 4 chunks (256 k) per workgroup
+  if (s > 16) s = 16;
+  return s < 2 ? 1 : (int32_t)s;
+}
+
+int64_t dsu_conv2d_nhwc_f16_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t O, int32_t k,
+                                            int32_t stride, int32_t pad, int32_t upsample2x,
+                                            int32_t split_k) {
+  if (split_k <= 1) return 0;
+  const int IH = upsample2x ? 2 * H : H, IW = upsample2x ? 2 * W : W;
+  const int OH = conv_out_dim(IH, k, stride, pad), OW = conv_out_dim(IW, k, stride, pad);
+  if (OH <= 0 || OW <= 0) return DSU_EINVAL;
+  return (int64_t)split_k * B * OH * OW * O * (int64_t)sizeof(float);
+}
+
+int dsu_conv2d_nhwc_f16_fwd_ws(const void* input, const void* weight_okc, const void* bias,
+                               int32_t B, int32_t H, int32_t W, int32_t C, int32_t O, int32_t k,
+                               int32_t stride, int32_t pad, int32_t upsample2x,
+                               const void* addvec, const void* residual, void* out,
+                               int32_t split_k, void* workspace, int64_t workspace_bytes,
+                               void* stream) {
   if (!input || !weight_okc || !out) return DSU_EINVAL;
+  if (split_k < 1 || split_k > 64) return DSU_EINVAL;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || O <= 0 || k <= 0 || stride <= 0 || pad < 0)
     return DSU_EINVAL;
   if (C % 8 != 0) return DSU_EUNSUP;           // 16-byte channel groups
@@ -218,10 +309,35 @@ int dsu_conv2d_nhwc_f16_fwd(const void* input, const void* weight_okc, const voi
   if (a.OH <= 0 || a.OW <= 0) return DSU_EINVAL;
   a.Ktot = k * k * C;
   const int64_t npix = (int64_t)B * a.OH * a.OW;
-  dim3 grid((unsigned)((npix + TN - 1) / TN), (unsigned)((O + TM - 1) / TM));
+  const int chunks = (a.Ktot + BK - 1) / BK;
+  if (split_k > chunks) split_k = chunks;
+  a.split_k = split_k;
+  a.ws = (float*)workspace;
+  if (split_k > 1) {
+    // every z must own at least one chunk: shrink split_k until the last range is non-empty
+    while (split_k > 1 && (split_k - 1) * ((chunks + split_k - 1) / split_k) >= chunks) --split_k;
+    a.split_k = split_k;
+  }
+  if (a.split_k > 1 &&
+      (!workspace || workspace_bytes < (int64_t)a.split_k * npix * O * (int64_t)sizeof(float)))
+    return DSU_EINVAL;
+  dim3 grid((unsigned)((npix + TN - 1) / TN), (unsigned)((O + TM - 1) / TM), (unsigned)a.split_k);
   conv_f16_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  if (a.split_k > 1) {
+    const int64_t total = npix * ((O + 3) / 4);
+    conv_f16_reduce_kernel<<<dsu_capped_blocks(total, 256, 2048), 256, 0, (hipStream_t)stream>>>(
+        a, npix);
+  }
   DSU_CHECK_LAUNCH();
   return DSU_OK;
+}
+
+int dsu_conv2d_nhwc_f16_fwd(const void* input, const void* weight_okc, const void* bias,
+                            int32_t B, int32_t H, int32_t W, int32_t C, int32_t O, int32_t k,
+                            int32_t stride, int32_t pad, int32_t upsample2x, const void* addvec,
+                            const void* residual, void* out, void* stream) {
+  return dsu_conv2d_nhwc_f16_fwd_ws(input, weight_okc, bias, B, H, W, C, O, k, stride, pad,
+                                    upsample2x, addvec, residual, out, 1, nullptr, 0, stream);
 }
 
 }  // extern "C"

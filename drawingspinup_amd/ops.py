@@ -488,8 +488,9 @@ def conv_weight_okc(weight):
 
 
 def conv2d_nhwc_f16(x_nhwc, w_okc, bias=None, k=3, stride=1, pad=1, upsample2x=False, addvec=None,
-                    residual=None):
-    """x_nhwc (B,H,W,C) f16 contiguous -> (B,OH,OW,O) f16."""
+                    residual=None, split_k=None):
+    """x_nhwc (B,H,W,C) f16 contiguous -> (B,OH,OW,O) f16.  split_k None = the library's choice
+    (1 unless the output tiles alone leave most CUs idle), or an explicit factor."""
     B, H, W, Cin = x_nhwc.shape
     O = w_okc.shape[0]
     assert w_okc.shape[1] == k * k and w_okc.shape[2] == Cin
@@ -497,10 +498,18 @@ def conv2d_nhwc_f16(x_nhwc, w_okc, bias=None, k=3, stride=1, pad=1, upsample2x=F
     OH, OW = (IH + 2 * pad - k) // stride + 1, (IW + 2 * pad - k) // stride + 1
     out = torch.empty((B, OH, OW, O), dtype=torch.float16, device=x_nhwc.device)
     f16 = torch.float16
-    check(lib().dsu_conv2d_nhwc_f16_fwd(ptr(x_nhwc, f16), ptr(w_okc, f16), ptr(bias, f16), B, H, W,
-                                        Cin, O, k, stride, pad, int(upsample2x), ptr(addvec, f16),
-                                        ptr(residual, f16), ptr(out), stream()),
-          "dsu_conv2d_nhwc_f16_fwd")
+    up = int(upsample2x)
+    if split_k is None:
+        split_k = int(lib().dsu_conv2d_nhwc_f16_split_k(B, H, W, Cin, O, k, stride, pad, up))
+    ws, wbytes = None, 0
+    if split_k > 1:
+        wbytes = int(lib().dsu_conv2d_nhwc_f16_workspace_bytes(B, H, W, O, k, stride, pad, up,
+                                                               split_k))
+        ws = torch.empty(wbytes // 4, dtype=torch.float32, device=x_nhwc.device)
+    check(lib().dsu_conv2d_nhwc_f16_fwd_ws(ptr(x_nhwc, f16), ptr(w_okc, f16), ptr(bias, f16), B, H,
+                                           W, Cin, O, k, stride, pad, up, ptr(addvec, f16),
+                                           ptr(residual, f16), ptr(out), int(split_k), ptr(ws),
+                                           wbytes, stream()), "dsu_conv2d_nhwc_f16_fwd")
     return out
 
 

@@ -357,6 +357,22 @@ int dsu_conv2d_nhwc_f16_fwd(const void* input, const void* weight_okc, const voi
                             int32_t B, int32_t H, int32_t W, int32_t C, int32_t O, int32_t k,
                             int32_t stride, int32_t pad, int32_t upsample2x, const void* addvec,
                             const void* residual, void* out, void* stream);
+/* Same convolution with split-K: the k*k*C reduction is divided over `split_k` workgroups per
+ * output tile (f32 partials in `workspace`, summed by a second kernel that also applies bias /
+ * addvec / residual).  For the 8x8 and 4x4 levels of the UNet the output tiles alone occupy
+ * 20-120 of the 256 CUs.  dsu_conv2d_nhwc_f16_split_k returns the factor the library would pick
+ * (1 = plain kernel), dsu_conv2d_nhwc_f16_workspace_bytes the f32 scratch it needs. */
+int32_t dsu_conv2d_nhwc_f16_split_k(int32_t B, int32_t H, int32_t W, int32_t C, int32_t O,
+                                    int32_t k, int32_t stride, int32_t pad, int32_t upsample2x);
+int64_t dsu_conv2d_nhwc_f16_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t O, int32_t k,
+                                            int32_t stride, int32_t pad, int32_t upsample2x,
+                                            int32_t split_k);
+int dsu_conv2d_nhwc_f16_fwd_ws(const void* input, const void* weight_okc, const void* bias,
+                               int32_t B, int32_t H, int32_t W, int32_t C, int32_t O, int32_t k,
+                               int32_t stride, int32_t pad, int32_t upsample2x,
+                               const void* addvec, const void* residual, void* out,
+                               int32_t split_k, void* workspace, int64_t workspace_bytes,
+                               void* stream);
 
 /* nn.GroupNorm(G, C, eps) on NHWC f16 (+ optional fused SiLU): diffusers ResnetBlock2D
  * norm1/norm2 + nonlinearity, TransformerMV2DModel.norm (transformer_mv2d.py:304),
