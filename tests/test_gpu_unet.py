@@ -29,8 +29,10 @@ def _init(model, seed):
 
 def test_norm_kernels(dev):
     g = torch.Generator().manual_seed(0)
-    for C in (320, 640, 1920, 2560):
-        x = torch.randn(3, 5, 7, C, generator=g).half()
+    # (3,5,7): one-launch small-tensor kernel; (1,5,7) and (1,64,64): statistics + apply kernels
+    for C, shp in [(320, (3, 5, 7)), (640, (3, 5, 7)), (1920, (3, 5, 7)), (2560, (3, 5, 7)),
+                   (640, (1, 5, 7)), (320, (1, 64, 64)), (960, (12, 32, 32))]:
+        x = torch.randn(*shp, C, generator=g).half()
         w, b = (1 + 0.1 * torch.randn(C, generator=g)).half(), (0.1 * torch.randn(C, generator=g)).half()
         for silu in (False, True):
             ref = torch.nn.functional.group_norm(x.float().permute(0, 3, 1, 2), 32, w.float(),
