@@ -347,6 +347,24 @@ __device__ __forceinline__ void gc_commit(uint32_t* keys, unsigned long long* ac
   unsafeAtomicAdd(gtable + (size_t)entry * 2 + 1, v1);
 }
 
+// continuation of gc_commit after the first probe at `slot` found another key
+__device__ __forceinline__ void gc_commit_from(uint32_t* keys, unsigned long long* acc,
+                                               float* __restrict__ gtable, uint32_t entry,
+                                               uint32_t slot, float v0, float v1) {
+#pragma unroll
+  for (int probe = 1; probe < 3; ++probe) {
+    slot = (slot + 1) & (GC_SLOTS - 1);
+    const uint32_t old = atomicCAS(&keys[slot], GC_EMPTY, entry);
+    if (old == GC_EMPTY || old == entry) {
+      atomicAdd(&acc[2 * slot], gc_fix(v0));
+      atomicAdd(&acc[2 * slot + 1], gc_fix(v1));
+      return;
+    }
+  }
+  unsafeAtomicAdd(gtable + (size_t)entry * 2, v0);
+  unsafeAtomicAdd(gtable + (size_t)entry * 2 + 1, v1);
+}
+
 // per-workgroup partial vector: gw0p[64 feat][32 k'] | gw1p[64 feat][32 o'] | gb1[16]
 constexpr int PART_GW0 = 0, PART_GW1 = 64 * 32, PART_GB1 = 2 * 64 * 32;
 constexpr int PART_STRIDE = 2 * 64 * 32 + 64;
@@ -589,8 +607,36 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
           int qn = 0;
           auto drain = [&]() {
             __builtin_amdgcn_wave_barrier();
-            for (int i = lane; i < qn; i += 64)
-              gc_commit(c_keys, c_acc, gtable, q_ent[i], q_v0[i], q_v1[i]);
+            // 4 queue items per lane per round: their slot claims (returning LDS atomics) are in
+            // flight together instead of one dependent claim -> add round trip per 64 items
+            for (int i0 = 0; i0 < qn; i0 += 256) {
+              uint32_t ent[4], slot[4], old[4];
+              float a0[4], a1[4];
+              bool on[4];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int i = i0 + 64 * u + lane;
+                on[u] = i < qn;
+                const int ii = on[u] ? i : 0;
+                ent[u] = q_ent[ii];
+                a0[u] = q_v0[ii];
+                a1[u] = q_v1[ii];
+                slot[u] = grad_cache_slot(ent[u]);
+              }
+#pragma unroll
+              for (int u = 0; u < 4; ++u)
+                old[u] = on[u] ? atomicCAS(&c_keys[slot[u]], GC_EMPTY, ent[u]) : ent[u];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                if (!on[u]) continue;
+                if (old[u] == GC_EMPTY || old[u] == ent[u]) {
+                  atomicAdd(&c_acc[2 * slot[u]], gc_fix(a0[u]));
+                  atomicAdd(&c_acc[2 * slot[u] + 1], gc_fix(a1[u]));
+                } else {
+                  gc_commit_from(c_keys, c_acc, gtable, ent[u], slot[u], a0[u], a1[u]);
+                }
+              }
+            }
             __builtin_amdgcn_wave_barrier();
             qn = 0;
           };

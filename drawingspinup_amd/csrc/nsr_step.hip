@@ -388,9 +388,66 @@ __global__ __launch_bounds__(1024) void ray_offsets_kernel(const int32_t* __rest
   }
 }
 
+// OrthoNeuSSystem.preprocess_data (systems/neus_ortho.py:26-82, batch_image_sampling) for n random
+// (view, y, x) triples: c2w gather, get_ortho_rays (models/ray_utils.py:36-58), colour / normal /
+// mask / view-weight gathers, cosine between ray and normal, normalised direction.
+__global__ __launch_bounds__(256) void ortho_ray_batch_kernel(
+    const int64_t* __restrict__ index, const int64_t* __restrict__ px, const int64_t* __restrict__ py,
+    int64_t n, const float* __restrict__ c2w /*(V,3,4)*/, const float* __restrict__ origins,
+    const float* __restrict__ directions, const float* __restrict__ images, int img_c,
+    const float* __restrict__ normals, const float* __restrict__ masks,
+    const float* __restrict__ vweights, int H, int W, float* __restrict__ rays /*(n,6)*/,
+    float* __restrict__ rgb, float* __restrict__ normal, float* __restrict__ mask,
+    float* __restrict__ cosines, float* __restrict__ vw) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t v = index[i];
+  const int64_t pix = (v * H + py[i]) * W + px[i];
+  const float* M = c2w + v * 12;
+  const float o0 = origins[pix * 3], o1 = origins[pix * 3 + 1], o2 = origins[pix * 3 + 2];
+  const float d0 = directions[pix * 3], d1 = directions[pix * 3 + 1], d2 = directions[pix * 3 + 2];
+  float ro[3], rd[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    rd[r] = (M[r * 4] * d0 + M[r * 4 + 1] * d1) + M[r * 4 + 2] * d2;
+    ro[r] = M[r * 4 + 3] + ((M[r * 4] * o0 + M[r * 4 + 1] * o1) + M[r * 4 + 2] * o2);
+  }
+  const float nx = normals[pix * 3], ny = normals[pix * 3 + 1], nz = normals[pix * 3 + 2];
+  // F.cosine_similarity(rays_d, normal, eps=1e-6): each vector divided by max(|.|, eps)
+  const float dn = sqrtf((rd[0] * rd[0] + rd[1] * rd[1]) + rd[2] * rd[2]);
+  const float nn = sqrtf((nx * nx + ny * ny) + nz * nz);
+  const float da = fmaxf(dn, 1e-6f), na = fmaxf(nn, 1e-6f);
+  cosines[i] = ((rd[0] / da) * (nx / na) + (rd[1] / da) * (ny / na)) + (rd[2] / da) * (nz / na);
+  const float dz = fmaxf(dn, 1e-12f);                    // F.normalize(rays_d, p=2, eps=1e-12)
+  rays[i * 6 + 0] = ro[0]; rays[i * 6 + 1] = ro[1]; rays[i * 6 + 2] = ro[2];
+  rays[i * 6 + 3] = rd[0] / dz; rays[i * 6 + 4] = rd[1] / dz; rays[i * 6 + 5] = rd[2] / dz;
+  for (int c = 0; c < img_c; ++c) rgb[i * img_c + c] = images[pix * img_c + c];
+  normal[i * 3] = nx; normal[i * 3 + 1] = ny; normal[i * 3 + 2] = nz;
+  mask[i] = masks[pix];
+  vw[i] = vweights[pix];
+}
+
 }  // namespace
 
 extern "C" {
+
+int dsu_ortho_ray_batch(const int64_t* index, const int64_t* x, const int64_t* y, int64_t n,
+                        const float* c2w, const float* origins, const float* directions,
+                        const float* images, int32_t image_channels, const float* normals,
+                        const float* masks, const float* view_weights, int32_t H, int32_t W,
+                        float* rays, float* rgb, float* normal, float* mask, float* cosines,
+                        float* vw, void* stream) {
+  if (n < 0 || H <= 0 || W <= 0 || image_channels <= 0) return DSU_EINVAL;
+  if (n == 0) return DSU_OK;
+  if (!index || !x || !y || !c2w || !origins || !directions || !images || !normals || !masks ||
+      !view_weights || !rays || !rgb || !normal || !mask || !cosines || !vw)
+    return DSU_EINVAL;
+  ortho_ray_batch_kernel<<<dsu_blocks_for(n, 256), 256, 0, (hipStream_t)stream>>>(
+      index, x, y, n, c2w, origins, directions, images, image_channels, normals, masks, view_weights,
+      H, W, rays, rgb, normal, mask, cosines, vw);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
 
 int dsu_ray_losses(const float* comp, const float* rgb, const float* normal, const float* mask,
                    const float* cosines, const float* view_weights, int32_t n_rays,

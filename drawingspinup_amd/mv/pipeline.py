@@ -13,6 +13,8 @@ CUDA and HIP).
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -239,6 +241,8 @@ class MVDiffusionImagePipeline:
         self.scheduler = scheduler or DDIMScheduler()
         self.num_views = num_views
         self.vae_scale_factor = 8
+        self.use_graph = os.environ.get("DSU_MV_GRAPH", "0") == "1"
+        self._graph = None
 
     @property
     def device(self):
@@ -263,6 +267,40 @@ class MVDiffusionImagePipeline:
             emb = emb.expand(images.shape[0], -1, -1)
             lat = lat.expand(images.shape[0], -1, -1, -1)
         return emb.contiguous(), lat.contiguous()
+
+    def _unet_step(self, model_in, t, image_embeddings, cam):
+        """One UNet evaluation.  The denoising loop calls the UNet 75 times on identical shapes
+        and ~600 launches each.  With DSU_MV_GRAPH=1 the forward is captured once into a HIP graph
+        (static input/output buffers) and replayed: bit-identical output, but measured no faster
+        on MI355X (the step is GPU-bound: 14.8 ms either way) and the capture costs ~2.7 s, so
+        eager is the default."""
+        if not self.use_graph:
+            return self.unet(model_in, t, image_embeddings, cam)
+        g = self._graph
+        key = (tuple(model_in.shape), tuple(image_embeddings.shape), tuple(cam.shape))
+        if g is None or g["key"] != key:
+            g = {"key": key, "x": torch.empty_like(model_in), "t": torch.zeros(1, device=model_in.device,
+                                                                           dtype=t.dtype),
+                 "emb": torch.empty_like(image_embeddings), "cam": torch.empty_like(cam),
+                 "graph": None, "out": None}
+            self._graph = g
+        g["x"].copy_(model_in)
+        g["t"].copy_(t.reshape(1))
+        g["emb"].copy_(image_embeddings)
+        g["cam"].copy_(cam)
+        if g["graph"] is None:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):                       # warm-up outside the capture
+                    self.unet(g["x"], g["t"], g["emb"], g["cam"])
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                g["out"] = self.unet(g["x"], g["t"], g["emb"], g["cam"])
+            g["graph"] = graph
+        g["graph"].replay()
+        return g["out"]
 
     def prepare_camera_embedding(self, camera_embedding):
         ce = camera_embedding.to(dtype=torch.float16, device=self.device)
@@ -289,7 +327,7 @@ class MVDiffusionImagePipeline:
         latents = latents.to(dev, dt) * self.scheduler.init_noise_sigma
         for i, t in enumerate(self.scheduler.timesteps):
             model_in = torch.cat([latents, image_latents], dim=1)
-            noise_pred = self.unet(model_in, t, image_embeddings, cam)
+            noise_pred = self._unet_step(model_in, t, image_embeddings, cam)
             vn = None if step_noise is None else step_noise[i].to(dev, dt)
             latents = self.scheduler.step(noise_pred, t, latents, eta=eta, generator=generator,
                                           variance_noise=vn)

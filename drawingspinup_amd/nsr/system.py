@@ -152,6 +152,24 @@ def ranking_loss_masked(error, valid, penalize_ratio=0.7, extra_weights=None, ty
     return total / k.to(total.dtype) if type == "mean" else total
 
 
+class _LazyLoss:
+    """Total loss of a fused step, summed only when somebody looks at it (three launches that the
+    optimisation itself never needs)."""
+
+    def __init__(self, rterms, sterms):
+        self._parts, self._value = (rterms, sterms), None
+
+    def detach(self):
+        if self._value is None:
+            self._value = self._parts[0].sum() + self._parts[1].sum()
+        return self._value
+
+    def __float__(self):
+        return float(self.detach())
+
+    item = __float__
+
+
 class RayLossGraph:
     """HIP-graph capture of OrthoNeuSSystem.ray_losses + d(loss)/d(comp) on fixed-capacity
     buffers.  The ray count changes every step (dynamic ray sampling), so the tensors are padded
@@ -240,6 +258,7 @@ class OrthoNeuSSystem:
         # "autograd": the op-by-op step through torch.autograd (cross-check, same numbers)
         self.step_mode = os.environ.get("DSU_STEP", "fused")
         self.use_prefetch = os.environ.get("DSU_PREFETCH", "1") != "0" and self.device.type == "cuda"
+        self.fused_batch = os.environ.get("DSU_FUSED_BATCH", "1") != "0"
         self._side, self._prefetched = None, None
         self._stats_pinned = [torch.empty(2, dtype=torch.int32).pin_memory() for _ in range(2)] \
             if self.device.type == "cuda" and torch.cuda.is_available() else None
@@ -252,6 +271,19 @@ class OrthoNeuSSystem:
             index = torch.randint(0, len(ds.all_masks), size=(n,), device=dev)
             x = torch.randint(0, ds.w, size=(n,), device=dev)
             y = torch.randint(0, ds.h, size=(n,), device=dev)
+        if self.device.type == "cuda" and self.fused_batch and ds.all_images.dtype == torch.float32 \
+                and all(t.is_contiguous() for t in (ds.all_images, ds.all_normals_world,
+                                                    ds.all_masks, ds.view_weights, ds.origins,
+                                                    ds.directions, ds.all_c2w)):
+            # one launch instead of ~30 (gathers, two batched 3x3 products, norms, cat)
+            return ops.ortho_ray_batch(index, x, y, ds.all_c2w, ds.origins, ds.directions,
+                                       ds.all_images, ds.all_normals_world, ds.all_masks,
+                                       ds.view_weights)
+        return self.preprocess_data_torch(index, x, y)
+
+    def preprocess_data_torch(self, index, x, y):
+        """The op-by-op form of preprocess_data (cross-check for the fused kernel)."""
+        ds = self.dataset
         c2w = ds.all_c2w[index]
         directions, origins = ds.directions[index, y, x], ds.origins[index, y, x]
         rays_o, rays_d = get_ortho_rays(origins, directions, c2w)
@@ -352,9 +384,17 @@ class OrthoNeuSSystem:
                 occ, res = m.occupancy_grid.binary_u8(), m.occupancy_grid.res
             h = ops.ray_march_begin(rays_o, rays_d, tmin, tmax, m._aabb_host, occ, res,
                                     m.render_step_size)
-        return {"batch": batch, "handle": h, "keep": (tmin, tmax, jitter, rays)}
+        # the 2048 random points of the sparsity / smoothness terms and their perturbation
+        # (neus.py:155-162) are independent of the parameters as well
+        pts_random, perturb = inject.get("pts_random"), inject.get("perturb")
+        if pts_random is None:
+            pts_random = torch.rand([1024 * 2, 3], device=rays.device) * 2 - 1
+        if perturb is None:
+            perturb = torch.randn_like(pts_random)
+        return {"batch": batch, "handle": h, "keep": (tmin, tmax, jitter, rays),
+                "pts_random": pts_random, "perturb": perturb}
 
-    def _launch_prefetch(self):
+    def _launch_prefetch(self, done=None):
         """The next step's ray batch and march depend on the occupancy grid and the RNG, not on
         the parameters this step is about to update: run them on a side stream, concurrently with
         this step's geometry / backward kernels (32 marching waves next to a 4-wave-per-CU
@@ -369,9 +409,10 @@ class OrthoNeuSSystem:
         main = torch.cuda.current_stream()
         if self._side is None:
             self._side = torch.cuda.Stream()
-        done = torch.cuda.Event()
-        done.record(main)                      # compaction of THIS step has been enqueued: the
-        self._side.wait_event(done)            # march scratch rows may be overwritten after it
+        if done is None:
+            done = torch.cuda.Event()
+            done.record(main)
+        self._side.wait_event(done)            # compaction of THIS step (and a grid refresh) done
         with torch.cuda.stream(self._side):
             prep = self._march_begin()
             host = self._stats_pinned[nxt & 1]
@@ -382,6 +423,7 @@ class OrthoNeuSSystem:
         prep["step"] = nxt
         h = prep["handle"]
         for t in (*prep["batch"].values(), h.rays_o, h.rays_d, h.counts, h.offsets, h.stats,
+                  prep["pts_random"], prep["perturb"],
                   *[k for k in prep["keep"] if k is not None]):
             t.record_stream(main)              # produced on the side stream, consumed on main
         self._prefetched = prep
@@ -416,11 +458,7 @@ class OrthoNeuSSystem:
         batch, rays_d, h = prep["batch"], prep["handle"].rays_d, prep["handle"]
         dev = rays_d.device
         n_rays = rays_d.shape[0]
-        pts_random, perturb = inject.get("pts_random"), inject.get("perturb")
-        if pts_random is None:
-            pts_random = torch.rand([1024 * 2, 3], device=dev) * 2 - 1
-        if perturb is None:
-            perturb = torch.randn_like(pts_random)
+        pts_random, perturb = prep["pts_random"], prep["perturb"]
         n_r = pts_random.shape[0]
         with torch.no_grad():
             allp, ts, te = ops.ray_march_finish(h, total, cmax, tail_rows=2 * n_r)
@@ -428,12 +466,13 @@ class OrthoNeuSSystem:
             RayPacking.total = n_s
             allp[n_s:n_s + n_r] = pts_random
             torch.add(pts_random, perturb, alpha=1e-2, out=allp[n_s + n_r:])
+        # the march scratch rows may be overwritten by the next prefetch once this has run
+        done_event = torch.cuda.Event()
+        done_event.record(torch.cuda.current_stream())
         if m.config.dynamic_ray_sampling and n_s > 0:
             tr = int(self.train_num_rays * (self.train_num_samples / n_s))
             self.train_num_rays = min(int(self.train_num_rays * 0.9 + tr * 0.1),
                                       m.config.max_train_num_rays)
-        if not inject:
-            self._launch_prefetch()
         n_all = n_s + 2 * n_r
         self._set_lr()
         self.optimizer.zero_grad(set_to_none=True)
@@ -497,6 +536,10 @@ class OrthoNeuSSystem:
             g_table, g = ops.sdf_fd_bwd(enc.cfg, table, mlp, allp, geo.radius, eps, active,
                                         d_sdf_all, d_grad_all, d_feat_all, None,
                                         enc_cache=enc_cache)
+        if not inject:
+            # issued AFTER the long geometry backward has been enqueued: the host spends ~0.4 ms
+            # launching the next batch's ~35 small kernels, time the device needs anyway
+            self._launch_prefetch(done_event)
         enc.params.grad = g_table
         lin0, lin1 = [l for l in geo.network.layers if isinstance(l, torch.nn.Linear)]
         if w0.requires_grad and w0.grad_fn is not None:
@@ -513,8 +556,7 @@ class OrthoNeuSSystem:
                       "sparsity": sterms[1]})
         if L.lambda_3d_normal_smooth > 0:
             terms["normal_smooth"] = sterms[2]
-        loss = rterms.sum() + sterms.sum()
-        self.last = {"loss": loss, "n_samples": n_s, "n_rays": n_rays, **terms}
+        self.last = {"loss": _LazyLoss(rterms, sterms), "n_samples": n_s, "n_rays": n_rays, **terms}
         return self.last
 
     def training_step_autograd(self, inject=None):

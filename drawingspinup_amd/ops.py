@@ -326,6 +326,26 @@ def texture_bwd(params, tex_in, rgb, d_rgb):
     return d_in, g
 
 
+def ortho_ray_batch(index, x, y, c2w, origins, directions, images, normals, masks, view_weights):
+    """Fused preprocess_data: returns the batch dict (rays (n,6), rgb, normal, mask, cosines,
+    view_weights) for int64 (index, x, y) draws.  Dataset tensors (V,H,W,*) f32 contiguous."""
+    n = index.shape[0]
+    dev = images.device
+    V, H, W, ch = images.shape
+    f = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=dev)
+    out = {"rays": f(n, 6), "rgb": f(n, ch), "normal": f(n, 3), "mask": f(n), "cosines": f(n),
+           "view_weights": f(n)}
+    i64 = torch.int64
+    check(lib().dsu_ortho_ray_batch(ptr(index, i64), ptr(x, i64), ptr(y, i64), n, ptr(_f32c(c2w)),
+                                    ptr(origins, torch.float32), ptr(directions, torch.float32),
+                                    ptr(images, torch.float32), ch, ptr(normals, torch.float32),
+                                    ptr(masks, torch.float32), ptr(view_weights, torch.float32), H,
+                                    W, ptr(out["rays"]), ptr(out["rgb"]), ptr(out["normal"]),
+                                    ptr(out["mask"]), ptr(out["cosines"]), ptr(out["view_weights"]),
+                                    stream()), "dsu_ortho_ray_batch")
+    return out
+
+
 RAY_LOSS_MAX_RAYS = 8192      # DSU_RAY_LOSS_MAX_RAYS (include/dsu_hip.h)
 
 

@@ -257,6 +257,18 @@ int dsu_texture_bwd(const dsu_tex_mlp* mlp, const float* tex_in, const float* rg
                     float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* workspace,
                     int64_t workspace_bytes, void* stream);
 
+/* OrthoNeuSSystem.preprocess_data (systems/neus_ortho.py:26-82) for n sampled (view, y, x)
+ * triples (int64, drawn by the caller): c2w gather, get_ortho_rays (models/ray_utils.py:36-58),
+ * colour / normal / mask / view-weight gathers, cosines = cosine_similarity(rays_d, normal,
+ * eps=1e-6), rays = [rays_o | normalize(rays_d)].  Dataset tensors are the resident
+ * (V,H,W,*) f32 arrays of OrthoDatasetBase.setup (datasets/ortho.py:99-151). */
+int dsu_ortho_ray_batch(const int64_t* index, const int64_t* x, const int64_t* y, int64_t n,
+                        const float* c2w, const float* origins, const float* directions,
+                        const float* images, int32_t image_channels, const float* normals,
+                        const float* masks, const float* view_weights, int32_t H, int32_t W,
+                        float* rays, float* rgb, float* normal, float* mask, float* cosines,
+                        float* vw, void* stream);
+
 /* Ray-level loss terms of OrthoNeuSSystem.training_step
  * (2_charactor_reconstructor/instant_nsr/systems/neus_ortho.py:94-133 with
  * systems/criterions.py:4-27) and their gradient w.r.t. the raw composite

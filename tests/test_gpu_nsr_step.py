@@ -216,3 +216,25 @@ def test_texture_autograd_function_in_model(dev):
     g2 = torch.autograd.grad(y2, [x2] + list(tex.parameters()), gy)
     for a, b in zip(g1, g2):
         assert float((a - b).abs().max()) < 2e-4 * (float(b.abs().max()) + 1e-12)
+
+
+def test_fused_ray_batch_matches_op_by_op_preprocess(dev):
+    """dsu_ortho_ray_batch against the op-by-op preprocess_data (neus_ortho.py:26-82) on the same
+    (view, y, x) draws: gathers exact, ray arithmetic to f32 rounding."""
+    ds = OrthoData.synthetic_sphere(128, device=dev)
+    ds.view_weights = torch.rand_like(ds.view_weights) + 0.5
+    sysm = _LossOnly(dict(DEFAULT_SYSTEM_CONFIG.loss))
+    sysm.dataset, sysm.device, sysm.fused_batch = ds, torch.device(dev), True
+    g = torch.Generator().manual_seed(4)
+    n = 3001
+    sysm.train_num_rays = n
+    idx = torch.randint(0, 6, (n,), generator=g).to(dev)
+    x = torch.randint(0, ds.w, (n,), generator=g).to(dev)
+    y = torch.randint(0, ds.h, (n,), generator=g).to(dev)
+    ref = sysm.preprocess_data_torch(idx, x, y)
+    got = sysm.preprocess_data(idx, x, y)
+    assert set(ref) == set(got)
+    for k in ("rgb", "normal", "mask", "view_weights"):
+        assert torch.equal(got[k], ref[k].reshape(got[k].shape)), k
+    torch.testing.assert_close(got["rays"], ref["rays"], rtol=0, atol=1e-6)
+    torch.testing.assert_close(got["cosines"], ref["cosines"], rtol=0, atol=1e-6)
