@@ -50,14 +50,22 @@ class Encoding(nn.Module):
         self.active_levels = self.cfg.n_levels
 
     def table_f16(self):
-        """f16 image of the f32 master parameters (what tcnn's kernels read); refreshed only
-        when the parameter tensor has been written since the last call."""
+        """f16 image of the f32 master parameters (what tcnn's kernels read).  Refreshed when the
+        parameter tensor has been written since the last call.  In-place optimizers are detected
+        through the tensor version counter EXCEPT the fused multi-tensor ones (torch's
+        `_fused_adamw_` does not bump it), so callers that step such an optimizer call
+        `invalidate()`; while the module is in training mode the image is simply rebuilt on every
+        call (one 15 us pass over 12.6 M entries)."""
         p = self.params
-        if (self._shadow is None or self._shadow_version != p._version
+        if (self._shadow is None or self.training or self._shadow_version != p._version
                 or self._shadow.device != p.device):
             self._shadow = p.detach().to(torch.float16).contiguous()
             self._shadow_version = p._version
         return self._shadow
+
+    def invalidate(self):
+        """Force the next table_f16() to re-read the master parameters."""
+        self._shadow_version = -1
 
     def set_shadow(self, table_f16):
         """Used by the fused optimizer step, which writes master and f16 image in one pass."""

@@ -548,6 +548,7 @@ class OrthoNeuSSystem:
             lin0.weight.grad, lin1.weight.grad = g[0], g[2]
         lin0.bias.grad, lin1.bias.grad = g[1], g[3]
         self.optimizer.step()
+        self.model.geometry.hashgrid.invalidate()     # fused AdamW does not bump ._version
         self.global_step += 1
         terms = {"rgb_mse": rterms[0]}
         if L.lambda_rgb_l1:
@@ -593,6 +594,7 @@ class OrthoNeuSSystem:
             loss = sum(terms.values())
             loss.backward()
         self.optimizer.step()
+        self.model.geometry.hashgrid.invalidate()     # fused AdamW does not bump ._version
         self.global_step += 1
         self.last = {"loss": loss.detach(), "n_samples": n_samples,
                      "n_rays": batch["rays"].shape[0], **{k: v.detach() for k, v in terms.items()}}

@@ -238,3 +238,20 @@ def test_fused_ray_batch_matches_op_by_op_preprocess(dev):
         assert torch.equal(got[k], ref[k].reshape(got[k].shape)), k
     torch.testing.assert_close(got["rays"], ref["rays"], rtol=0, atol=1e-6)
     torch.testing.assert_close(got["cosines"], ref["cosines"], rtol=0, atol=1e-6)
+
+
+def test_f16_table_image_follows_the_optimizer(dev):
+    """Regression: torch's fused AdamW updates the master table without bumping its version
+    counter; the f16 image the kernels read must still be rebuilt after every step."""
+    ds = OrthoData.synthetic_sphere(128, device=dev)
+    sysm = OrthoNeuSSystem(device=dev, seed=3)
+    sysm.dataset = ds
+    enc = sysm.model.geometry.hashgrid
+    before = enc.params.detach().clone()
+    for _ in range(3):
+        sysm.training_step()
+    assert not torch.equal(before, enc.params.detach())
+    sysm.model.eval()
+    assert torch.equal(enc.table_f16(), enc.params.detach().half())
+    sysm.model.train()
+    assert torch.equal(enc.table_f16(), enc.params.detach().half())
