@@ -56,58 +56,77 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
   const int C8 = a.C >> 3;                      // 8-channel groups per tap
   const int IH = a.up2 ? a.H * 2 : a.H, IW = a.up2 ? a.W * 2 : a.W;  // logical input size
 
-  // staging assignment: 4 A groups + 4 B groups (16 bytes each) per thread per chunk
-  int a_row[4], b_row[4], grp[4];
-  int b_n[4], b_y[4], b_x[4];
-  bool b_ok[4];
+  // staging assignment: 4 A rows + 4 B rows (16 bytes each) per thread per chunk.  All four rows
+  // of a thread sit at the same k offset (256 % 8 == 0), so (tap, channel) is ONE running state
+  // per thread; everything that does not change along K is folded into per-row constants, and
+  // offsets are 32-bit (the host rejects tensors of 2^31 elements or more).  The first version
+  // recomputed two integer divisions, bounds and 64-bit addresses per row per chunk:
+  // ~400 VALU instructions per 16 MFMAs (PMC: SQ_INSTS_VALU / SQ_INSTS_MFMA = 25, 55 % of wave
+  // cycles in VALU issue) — the kernel was VALU-bound, not MFMA-, LDS- or latency-bound.
+  int a_row[4], b_row[4];
+  const int grp = tid & 7;
+  const int kofs = grp * 8;
+  uint32_t w_off[4], pix_base[4];
+  int iy0[4], ix0[4];
+  bool a_ok[4], b_ok[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int idx = tid + 256 * i;
     a_row[i] = idx >> 3;
     b_row[i] = idx >> 3;
-    grp[i] = idx & 7;
+    const int o = o0 + a_row[i];
+    a_ok[i] = o < a.O;
+    w_off[i] = (uint32_t)(a_ok[i] ? o : 0) * (uint32_t)a.Ktot + (uint32_t)kofs;
     const int64_t p = p0 + b_row[i];
     b_ok[i] = p < npix;
     const int64_t pp = b_ok[i] ? p : 0;
-    b_n[i] = (int)(pp / (a.OH * a.OW));
+    const int n = (int)(pp / (a.OH * a.OW));
     const int rem = (int)(pp % (a.OH * a.OW));
-    b_y[i] = rem / a.OW;
-    b_x[i] = rem % a.OW;
+    iy0[i] = (rem / a.OW) * a.stride - a.pad;
+    ix0[i] = (rem % a.OW) * a.stride - a.pad;
+    pix_base[i] = (uint32_t)n * (uint32_t)(a.H * a.W) * (uint32_t)a.C;
   }
+  const bool kfast = (a.C % BK) == 0;             // every UNet/VAE layer but conv_in (C = 8)
+  int st_tap = 0, st_c = 0, st_chunk = -2;
 
   f16x8 ra[4], rb[4];
   auto load_regs = [&](int chunk) {
-    const int k0 = chunk * BK;
+    if (kfast && chunk == st_chunk + 1) {
+      st_c += BK;
+      if (st_c >= a.C) { st_c -= a.C; ++st_tap; }
+    } else {
+      const int kg = (chunk * BK + kofs) >> 3;
+      st_tap = kg / C8;
+      st_c = (kg - st_tap * C8) << 3;
+    }
+    st_chunk = chunk;
+    const bool kin = chunk * BK + kofs < a.Ktot;
+    int ty, tx;
+    if (a.KS == 3) { ty = (st_tap * 11) >> 5; tx = st_tap - 3 * ty; }       // tap < 9
+    else if (a.KS == 1) { ty = 0; tx = 0; }
+    else { ty = st_tap / a.KS; tx = st_tap - ty * a.KS; }
+    const uint32_t kadv = (uint32_t)(chunk * BK);
+    f16x8 z;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) z[e] = (f16)0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int k = k0 + grp[i] * 8;
-      f16x8 z;
-#pragma unroll
-      for (int e = 0; e < 8; ++e) z[e] = (f16)0.0f;
       ra[i] = z;
       rb[i] = z;
-      if (k < a.Ktot) {
-        const int o = o0 + a_row[i];
-        if (o < a.O) ra[i] = *reinterpret_cast<const f16x8*>(a.w + (size_t)o * a.Ktot + k);
-        if (b_ok[i]) {
-          const int kg = k >> 3;
-          const int tap = kg / C8, c = (kg - tap * C8) << 3;
-          const int ty = tap / a.KS, tx = tap - ty * a.KS;
-          int iy = b_y[i] * a.stride - a.pad + ty, ix = b_x[i] * a.stride - a.pad + tx;
-          if (iy >= 0 && iy < IH && ix >= 0 && ix < IW) {
-            if (a.up2) { iy >>= 1; ix >>= 1; }
-            rb[i] = *reinterpret_cast<const f16x8*>(
-                a.in + (((size_t)b_n[i] * a.H + iy) * a.W + ix) * a.C + c);
-          }
-        }
+      if (kin && a_ok[i]) ra[i] = *reinterpret_cast<const f16x8*>(a.w + (w_off[i] + kadv));
+      int iy = iy0[i] + ty, ix = ix0[i] + tx;
+      if (kin && b_ok[i] && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) {
+        if (a.up2) { iy >>= 1; ix >>= 1; }
+        rb[i] = *reinterpret_cast<const f16x8*>(
+            a.in + (pix_base[i] + (uint32_t)((iy * a.W + ix) * a.C + st_c)));
       }
     }
   };
   auto store_lds = [&](int buf) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<f16x8*>(&sA[buf][a_row[i] * ROW + grp[i] * 8]) = ra[i];
-      *reinterpret_cast<f16x8*>(&sB[buf][b_row[i] * ROW + grp[i] * 8]) = rb[i];
+      *reinterpret_cast<f16x8*>(&sA[buf][a_row[i] * ROW + kofs]) = ra[i];
+      *reinterpret_cast<f16x8*>(&sB[buf][b_row[i] * ROW + kofs]) = rb[i];
     }
   };
 
@@ -298,6 +317,8 @@ int dsu_conv2d_nhwc_f16_fwd_ws(const void* input, const void* weight_okc, const 
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || O <= 0 || k <= 0 || stride <= 0 || pad < 0)
     return DSU_EINVAL;
   if (C % 8 != 0) return DSU_EUNSUP;           // 16-byte channel groups
+  if ((int64_t)B * H * W * C >= (int64_t)1 << 31 || (int64_t)O * k * k * C >= (int64_t)1 << 31)
+    return DSU_EUNSUP;                         // 32-bit element offsets inside the kernel
   CArgs a;
   a.in = (const f16*)input; a.w = (const f16*)weight_okc; a.bias = (const f16*)bias;
   a.addvec = (const f16*)addvec; a.residual = (const f16*)residual; a.out = (f16*)out;
