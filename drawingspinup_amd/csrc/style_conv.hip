@@ -131,25 +131,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 
   const int nchunks = (a.C + KC - 1) / KC;
 
-  auto stage = [&](int chunk, int buf) {
+  // Staging is split in two so that global loads overlap the MFMAs of the current chunk: the
+  // values of chunk ch+1 are LOADED into registers before the MFMA loop of chunk ch and only
+  // CONSUMED (bilinear blend, ReLU, LDS store) after it.  The first version loaded and stored in
+  // one step before the MFMAs: every chunk waited for its own gathers (PMC: 54 % of wave cycles
+  // in s_waitcnt/barrier waits, 12-20 % MFMA busy).
+  constexpr int EH = (KP + 1) / 2;                       // MODE 0: K elements per staging half
+  constexpr int CH = KC / 2 > 0 ? KC / 2 : 1;            // MODE 1: channels per staging half
+  constexpr int NV = MODE == 1 ? CH * 9 * 4 : EH;        // raw values held per thread
+  constexpr int NW = (KP * BN + 255) / 256;              // weight values held per thread
+  float rv[NV], rw[NW];
+  bool cvs[MODE == 1 ? CH : 1];
+
+  auto stage_load = [&](int chunk) {
     const int c0 = chunk * KC;
-    // --- im2col values for pixel sp
     if (MODE == 1) {
-      constexpr int CH = KC / 2;  // channels per staging half
 #pragma unroll
       for (int cc = 0; cc < CH; ++cc) {
         const int c = c0 + sg * CH + cc;
         const bool cv = spv && c < a.C;
+        cvs[cc] = cv;
         const float* pl = in_b + (size_t)(cv ? c : 0) * plane;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
-          float v = sample_tap(pl, taps[t], a.in_relu != 0);
-          sB[buf][(sg * CH + cc) * 9 + t][sp] = cv ? v : 0.0f;
+          const Tap& tp = taps[t];
+          rv[(cc * 9 + t) * 4 + 0] = pl[tp.r0 + tp.c0];
+          rv[(cc * 9 + t) * 4 + 1] = pl[tp.r0 + tp.c1];
+          rv[(cc * 9 + t) * 4 + 2] = pl[tp.r1 + tp.c0];
+          rv[(cc * 9 + t) * 4 + 3] = pl[tp.r1 + tp.c1];
         }
       }
     } else {
-      constexpr int EH = (KP + 1) / 2;
-      for (int e = sg * EH; e < min((sg + 1) * EH, KP); ++e) {
+#pragma unroll
+      for (int q = 0; q < EH; ++q) {
+        const int e = sg * EH + q;
         float v = 0.0f;
         if (e < KE) {
           const int cc = e / KK, t = e % KK;
@@ -157,27 +172,58 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
           const int iy = oy * STRIDE - a.pad + t / KS, ix = ox * STRIDE - a.pad + t % KS;
           if (spv && c < a.C && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
             v = in_b[(size_t)c * plane + (size_t)iy * a.W + ix];
-          if (a.in_relu) v = fmaxf(v, 0.0f);
         }
-        sB[buf][e][sp] = v;
+        rv[q] = v;
       }
     }
     // --- weights: W[o][c0*KK .. c0*KK+KE) is contiguous per o
-    for (int idx = tid; idx < KP * BN; idx += 256) {
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int idx = tid + 256 * q;
       const int o = idx % BN, e = idx / BN;
       float v = 0.0f;
       const int c = c0 + e / KK;
-      if (e < KE && c < a.C && o_base + o < a.O)
+      if (idx < KP * BN && e < KE && c < a.C && o_base + o < a.O)
         v = a.w[((size_t)(o_base + o) * a.C + c0) * KK + e];
-      sA[buf][e][o] = v;
+      rw[q] = v;
+    }
+  };
+  auto stage_store = [&](int buf) {
+    if (MODE == 1) {
+#pragma unroll
+      for (int cc = 0; cc < CH; ++cc)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+          const Tap& tp = taps[t];
+          float v00 = rv[(cc * 9 + t) * 4 + 0], v01 = rv[(cc * 9 + t) * 4 + 1];
+          float v10 = rv[(cc * 9 + t) * 4 + 2], v11 = rv[(cc * 9 + t) * 4 + 3];
+          if (a.in_relu) {
+            v00 = fmaxf(v00, 0.0f); v01 = fmaxf(v01, 0.0f);
+            v10 = fmaxf(v10, 0.0f); v11 = fmaxf(v11, 0.0f);
+          }
+          const float v = tp.w00 * v00 + tp.w01 * v01 + tp.w10 * v10 + tp.w11 * v11;
+          sB[buf][(sg * CH + cc) * 9 + t][sp] = cvs[cc] ? v : 0.0f;
+        }
+    } else {
+#pragma unroll
+      for (int q = 0; q < EH; ++q) {
+        const int e = sg * EH + q;
+        if (e < KP) sB[buf][e][sp] = a.in_relu ? fmaxf(rv[q], 0.0f) : rv[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+      const int idx = tid + 256 * q;
+      if (idx < KP * BN) sA[buf][idx / BN][idx % BN] = rw[q];
     }
   };
 
-  stage(0, 0);
+  stage_load(0);
+  stage_store(0);
   __syncthreads();
   for (int ch = 0; ch < nchunks; ++ch) {
     const int buf = ch & 1;
-    if (ch + 1 < nchunks) stage(ch + 1, buf ^ 1);
+    if (ch + 1 < nchunks) stage_load(ch + 1);
     // wave `wave` owns pixels [32*wave, 32*wave+32) x all BN channels
     const int kh = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -189,6 +235,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[n], 0, 0, 0);
       }
     }
+    if (ch + 1 < nchunks) stage_store(buf ^ 1);
     __syncthreads();
   }
 
