@@ -104,6 +104,34 @@ __global__ __launch_bounds__(256) void mv_attention_kernel(AttnArgs a) {
     for (int r = 0; r < 16; ++r) oacc[n][r] = 0.0f;
   float m_run = -1e30f, l_run = 0.0f;
 
+  // staging roles are fixed per thread (only the tile origin moves): the row/column split of
+  // every staged 16-/8-byte group is computed once here, not per tile (the kernel issues ~45
+  // VALU instructions per MFMA at head dim 40 - softmax and staging arithmetic, not the matrix
+  // pipe, bound it)
+  constexpr int NK = (KVBLK * (DP / 8) + 255) / 256;
+  constexpr int NV = (DT * 32 * (KVBLK / 4) + 255) / 256;
+  int k_key[NK], k_lds[NK], v_k4[NV], v_lds[NV];
+  int64_t k_goff[NK], v_goff[NV];
+  bool k_on[NK], v_on[NV];
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    const int idx = tid + 256 * j;
+    const int key = idx / (DP / 8), c8 = idx % (DP / 8);
+    k_key[j] = key;
+    k_on[j] = idx < KVBLK * (DP / 8) && c8 * 8 < D;
+    k_lds[j] = idx < KVBLK * (DP / 8) ? key * KROW + c8 * 8 : -1;
+    k_goff[j] = (int64_t)key * a.k_ts + c8 * 8;
+  }
+#pragma unroll
+  for (int j = 0; j < NV; ++j) {
+    const int idx = tid + 256 * j;
+    const int d = idx / (KVBLK / 4), k4 = idx % (KVBLK / 4);
+    v_k4[j] = k4 * 4;
+    v_on[j] = idx < DT * 32 * (KVBLK / 4) && d < D;
+    v_lds[j] = idx < DT * 32 * (KVBLK / 4) ? d * VROW + k4 * 4 : -1;
+    v_goff[j] = (int64_t)d * a.vt_ds + k4 * 4;
+  }
+
   const int tiles_per_seg = (a.seg_len + KVBLK - 1) / KVBLK;
   for (int s = 0; s < a.S; ++s) {
     const int kb = a.seg_batch[b * a.S + s];
@@ -113,23 +141,25 @@ __global__ __launch_bounds__(256) void mv_attention_kernel(AttnArgs a) {
       const int key0 = t * KVBLK;
       __syncthreads();   // previous tile fully consumed
       // ---- stage K tile [64 keys][DP] (zero padded) and V^T tile [D rows][64 keys]
-      for (int idx = tid; idx < KVBLK * (DP / 8); idx += 256) {
-        const int key = idx / (DP / 8), c8 = idx % (DP / 8);
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        if (k_lds[j] < 0) continue;
         f16x8 v;
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = (f16)0.0f;
-        if (key0 + key < a.seg_len && c8 * 8 < D)
-          v = *reinterpret_cast<const f16x8*>(kbase + (int64_t)(key0 + key) * a.k_ts + c8 * 8);
-        *reinterpret_cast<f16x8*>(&sK[key * KROW + c8 * 8]) = v;
+        if (k_on[j] && key0 + k_key[j] < a.seg_len)
+          v = *reinterpret_cast<const f16x8*>(kbase + (int64_t)key0 * a.k_ts + k_goff[j]);
+        *reinterpret_cast<f16x8*>(&sK[k_lds[j]]) = v;
       }
-      for (int idx = tid; idx < DT * 32 * (KVBLK / 4); idx += 256) {
-        const int d = idx / (KVBLK / 4), k4 = idx % (KVBLK / 4);
+#pragma unroll
+      for (int j = 0; j < NV; ++j) {
+        if (v_lds[j] < 0) continue;
         f16x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = (f16)0.0f;
-        if (d < D && key0 + k4 * 4 < a.seg_len)   // seg_len % 4 == 0: 4-key groups are whole
-          v = *reinterpret_cast<const f16x4*>(vbase + (int64_t)d * a.vt_ds + key0 + k4 * 4);
-        *reinterpret_cast<f16x4*>(&sV[d * VROW + k4 * 4]) = v;
+        if (v_on[j] && key0 + v_k4[j] < a.seg_len)   // seg_len % 4 == 0: 4-key groups are whole
+          v = *reinterpret_cast<const f16x4*>(vbase + key0 + v_goff[j]);
+        *reinterpret_cast<f16x4*>(&sV[v_lds[j]]) = v;
       }
       __syncthreads();
 
@@ -146,28 +176,35 @@ __global__ __launch_bounds__(256) void mv_attention_kernel(AttnArgs a) {
           st[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[c], st[kt], 0, 0, 0);
         }
       }
-      // ---- online softmax over this tile's 64 keys (in log2 domain)
+      // ---- online softmax over this tile's 64 keys (in log2 domain).  Keys beyond the segment
+      // exist only in a segment's last tile; the scale is positive, so the running maximum is
+      // taken over the raw scores and scaled once, and each probability is ONE fma + v_exp_f32
+      // (arguments are <= 0: the raw hardware exp2 needs no range handling).
+      if (key0 + KVBLK > a.seg_len) {
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (key >= a.seg_len) st[kt][r] = -1e30f;
+          }
+      }
       float mx = -1e30f;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = key0 + kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          float v = st[kt][r] * a.scale_log2e;
-          v = key < a.seg_len ? v : -1e30f;
-          st[kt][r] = v;
-          mx = fmaxf(mx, v);
-        }
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, st[kt][r]);
       mx = fmaxf(mx, __shfl_xor(mx, 32));
+      mx = fmaxf(mx * a.scale_log2e, -1e30f);
       const float m_new = fmaxf(m_run, mx);
-      const float alpha = exp2f(m_run - m_new);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float psum = 0.0f;
       f16x8 pf[4];   // B operand of V^T.P^T per 16-key group g = 2kt + (r>>3)
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const float p = exp2f(st[kt][r] - m_new);
+          const float p = __builtin_amdgcn_exp2f(fmaf(st[kt][r], a.scale_log2e, -m_new));
           psum += p;
           pf[2 * kt + (r >> 3)][r & 7] = (f16)p;
         }

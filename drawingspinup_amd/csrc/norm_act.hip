@@ -105,18 +105,42 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const f16* __restri
                                                              const f16* __restrict__ beta, int HW,
                                                              int C, int G, float eps, int do_silu,
                                                              f16* __restrict__ out) {
+  // channels per group are even for every layer (10..80), so the group's rows are walked as
+  // half2 pairs; up to GN_KEEP pairs per thread stay in registers between the two passes
+  constexpr int GN_KEEP = 16;
+  typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
   __shared__ float red[2][4];
   const int n = blockIdx.x / G, g = blockIdx.x % G;
-  const int cpg = C / G;
-  const int cnt = HW * cpg;
+  const int cpg = C / G, cp2 = cpg >> 1;
+  const int cnt2 = HW * cp2;
   const f16* xb = x + (size_t)n * HW * C + g * cpg;
   f16* ob = out + (size_t)n * HW * C + g * cpg;
+  const bool keep = cnt2 <= GN_KEEP * 256;
+  f16x2 kv[GN_KEEP];
   float s = 0.0f, q = 0.0f;
-  for (int e = threadIdx.x; e < cnt; e += 256) {
-    const int p = e / cpg, c = e - p * cpg;
-    const float f = (float)xb[(size_t)p * C + c];
-    s += f;
-    q += f * f;
+  if (keep) {
+#pragma unroll
+    for (int k = 0; k < GN_KEEP; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      f16x2 v;
+      v[0] = (f16)0.0f; v[1] = (f16)0.0f;
+      if (e < cnt2) {
+        const int p = e / cp2, c = e - p * cp2;
+        v = *reinterpret_cast<const f16x2*>(xb + (size_t)p * C + 2 * c);
+      }
+      kv[k] = v;
+      const float f0 = (float)v[0], f1 = (float)v[1];
+      s += f0 + f1;
+      q += f0 * f0 + f1 * f1;
+    }
+  } else {
+    for (int e = threadIdx.x; e < cnt2; e += 256) {
+      const int p = e / cp2, c = e - p * cp2;
+      const f16x2 v = *reinterpret_cast<const f16x2*>(xb + (size_t)p * C + 2 * c);
+      const float f0 = (float)v[0], f1 = (float)v[1];
+      s += f0 + f1;
+      q += f0 * f0 + f1 * f1;
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -134,12 +158,29 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const f16* __restri
   const float mean = s * inv_cnt;
   const float var = fmaxf(q * inv_cnt - mean * mean, 0.0f);
   const float rstd = rsqrtf(var + eps);
-  for (int e = threadIdx.x; e < cnt; e += 256) {
-    const int p = e / cpg, c = e - p * cpg;
-    const int ch = g * cpg + c;
-    float y = ((float)xb[(size_t)p * C + c] - mean) * rstd * (float)gamma[ch] + (float)beta[ch];
-    if (do_silu) y = silu(y);
-    ob[(size_t)p * C + c] = (f16)y;
+  auto apply = [&](int e, f16x2 v) {
+    const int p = e / cp2, c = e - p * cp2;
+    const int ch = g * cpg + 2 * c;
+    const f16x2 gm = *reinterpret_cast<const f16x2*>(gamma + ch);
+    const f16x2 bt = *reinterpret_cast<const f16x2*>(beta + ch);
+    float y0 = ((float)v[0] - mean) * rstd * (float)gm[0] + (float)bt[0];
+    float y1 = ((float)v[1] - mean) * rstd * (float)gm[1] + (float)bt[1];
+    if (do_silu) { y0 = silu(y0); y1 = silu(y1); }
+    f16x2 o;
+    o[0] = (f16)y0; o[1] = (f16)y1;
+    *reinterpret_cast<f16x2*>(ob + (size_t)p * C + 2 * c) = o;
+  };
+  if (keep) {
+#pragma unroll
+    for (int k = 0; k < GN_KEEP; ++k) {
+      const int e = threadIdx.x + 256 * k;
+      if (e < cnt2) apply(e, kv[k]);
+    }
+  } else {
+    for (int e = threadIdx.x; e < cnt2; e += 256) {
+      const int p = e / cp2, c = e - p * cp2;
+      apply(e, *reinterpret_cast<const f16x2*>(xb + (size_t)p * C + 2 * c));
+    }
   }
 }
 
@@ -230,7 +271,7 @@ int dsu_groupnorm_nhwc_f16(const void* x, const void* gamma, const void* beta, i
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G != 0) return DSU_EINVAL;
   if (C % 8 != 0 || C / 8 > 1024 || (C / 8) % ((C / 8 + 255) / 256) != 0) return DSU_EUNSUP;
   hipStream_t s = (hipStream_t)stream;
-  if ((int64_t)HW * (C / G) <= 32768 && (int64_t)B * G >= 64) {
+  if ((int64_t)HW * (C / G) <= 32768 && (int64_t)B * G >= 64 && (C / G) % 2 == 0) {
     gn_fused_small_kernel<<<B * G, 256, 0, s>>>((const f16*)x, (const f16*)gamma,
                                                 (const f16*)beta, HW, C, G, eps, silu, (f16*)out);
     DSU_CHECK_LAUNCH();

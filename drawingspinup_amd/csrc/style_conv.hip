@@ -143,6 +143,26 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   float rv[NV], rw[NW];
   bool cvs[MODE == 1 ? CH : 1];
 
+  // MODE 0: which tap / channel-in-chunk each of this thread's EH staged elements is, its
+  // offset from the chunk's first channel plane and whether it falls inside the image — all
+  // independent of the chunk, so computed once (the 7x7 layer spent ~9 VALU instructions per
+  // MFMA re-deriving them for every one of its 166 chunks)
+  int tap_rel[MODE == 0 ? EH : 1], tap_cc[MODE == 0 ? EH : 1];
+  uint32_t tap_ok = 0;
+  static_assert(EH <= 32, "validity bits are kept in one 32-bit mask");
+  if (MODE == 0) {
+#pragma unroll
+    for (int q = 0; q < EH; ++q) {
+      const int e = sg * EH + q;
+      const int cc = e / KK, t = e % KK;
+      const int iy = oy * STRIDE - a.pad + t / KS, ix = ox * STRIDE - a.pad + t % KS;
+      const bool ok = e < KE && spv && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+      tap_cc[q] = cc;
+      tap_rel[q] = ok ? cc * (int)plane + iy * a.W + ix : 0;
+      tap_ok |= ok ? (1u << q) : 0u;
+    }
+  }
+
   auto stage_load = [&](int chunk) {
     const int c0 = chunk * KC;
     if (MODE == 1) {
@@ -162,17 +182,11 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
         }
       }
     } else {
+      const float* cb = in_b + (size_t)c0 * plane;
 #pragma unroll
       for (int q = 0; q < EH; ++q) {
-        const int e = sg * EH + q;
         float v = 0.0f;
-        if (e < KE) {
-          const int cc = e / KK, t = e % KK;
-          const int c = c0 + cc;
-          const int iy = oy * STRIDE - a.pad + t / KS, ix = ox * STRIDE - a.pad + t % KS;
-          if (spv && c < a.C && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-            v = in_b[(size_t)c * plane + (size_t)iy * a.W + ix];
-        }
+        if (((tap_ok >> q) & 1u) && c0 + tap_cc[q] < a.C) v = cb[tap_rel[q]];
         rv[q] = v;
       }
     }
