@@ -69,10 +69,11 @@ class OrthoData:
     """The tensors OrthoDatasetBase.setup keeps resident on the GPU (datasets/ortho.py:99-151)."""
 
     def __init__(self, images, masks, normals_world, c2w, device):
-        self.all_images = images.float().to(device)             # (V,H,W,3) in [0,1]
-        self.all_masks = masks.float().to(device)               # (V,H,W)
-        self.all_normals_world = normals_world.float().to(device)
-        self.all_c2w = c2w.float().to(device)                   # (V,3,4)
+        # resident, contiguous (V,H,W,*) f32 arrays: what the fused ray-batch kernel gathers from
+        self.all_images = images.float().to(device).contiguous()           # (V,H,W,3) in [0,1]
+        self.all_masks = masks.float().to(device).contiguous()             # (V,H,W)
+        self.all_normals_world = normals_world.float().to(device).contiguous()
+        self.all_c2w = c2w.float().to(device).contiguous()                 # (V,3,4)
         V, H, W = self.all_masks.shape
         self.h, self.w = H, W
         o, d = ortho_rays_hw(W, H)
