@@ -162,6 +162,46 @@ __device__ __forceinline__ float layer1_row(const float* lds, const float* h, in
   return acc;
 }
 
+// Both layers streamed over groups of four hidden units: pre-activation (same k-ascending fma
+// chain as layer0), Softplus, then the group's contribution to each of the NO outputs (same
+// j-ascending fma chain as layer1_row) — bit-identical results, but the 64 hidden activations
+// never exist at once (199 -> ~90 VGPRs: twice the resident waves to hide the table gathers).
+template <int NL, int NO>
+__device__ __forceinline__ void mlp_stream(const float* lds, const float* in, int kmax,
+                                           float* out /*NO*/) {
+  using L = MlpLds<NL>;
+#pragma unroll
+  for (int o = 0; o < NO; ++o) out[o] = lds[L::B1 + o];
+  const float4* b4 = reinterpret_cast<const float4*>(lds + L::B0);
+#pragma unroll 2
+  for (int j4 = 0; j4 < HID / 4; ++j4) {
+    const float4 b = b4[j4];
+    float p0 = b.x, p1 = b.y, p2 = b.z, p3 = b.w;
+#pragma unroll
+    for (int k = 0; k < L::DIN; ++k) {
+      if (k < kmax) {
+        const float4 w = reinterpret_cast<const float4*>(lds + L::W0T + k * HID)[j4];
+        const float v = in[k];
+        p0 = fmaf(w.x, v, p0);
+        p1 = fmaf(w.y, v, p1);
+        p2 = fmaf(w.z, v, p2);
+        p3 = fmaf(w.w, v, p3);
+      }
+    }
+    p0 = softplus100(p0); p1 = softplus100(p1); p2 = softplus100(p2); p3 = softplus100(p3);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      const float4 w = reinterpret_cast<const float4*>(lds + L::W1 + o * HID)[j4];
+      float acc = out[o];
+      acc = fmaf(w.x, p0, acc);
+      acc = fmaf(w.y, p1, acc);
+      acc = fmaf(w.z, p2, acc);
+      acc = fmaf(w.w, p3, acc);
+      out[o] = acc;
+    }
+  }
+}
+
 template <int NL, int NO>
 __global__ __launch_bounds__(256) void sdf_fwd_kernel(const __half2* __restrict__ table,
                                                       GridMeta m, dsu_sdf_mlp mlp,
@@ -179,12 +219,10 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(const __half2* __restrict_
     float z = contract(pts[i * 3 + 2], radius);
     float in[L::DIN];
     encode_input<NL>(table, m, active, x, y, z, in);
-    float h[HID];
-    layer0<NL>(lds, in, kmax, h);
+    float o_[NO];
+    mlp_stream<NL, NO>(lds, in, kmax, o_);
 #pragma unroll
-    for (int j = 0; j < HID; ++j) h[j] = softplus100(h[j]);
-#pragma unroll
-    for (int o = 0; o < NO; ++o) out[i * NO + o] = layer1_row<NL>(lds, h, o);
+    for (int o = 0; o < NO; ++o) out[i * NO + o] = o_[o];
   }
 }
 
@@ -227,15 +265,16 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
         for (int l = 0; l < NL; ++l)
           if ((uint32_t)l < active) row[l] = __floats2half2_rn(in[3 + 2 * l], in[3 + 2 * l + 1]);
       }
-      float h[HID];
-      layer0<NL>(lds, in, kmax, h);
-#pragma unroll
-      for (int j = 0; j < HID; ++j) h[j] = softplus100(h[j]);
-      s[e] = layer1_row<NL>(lds, h, 0);
       if (e == 0 && feature != nullptr) {
-        feature[i * NOUT] = s[0];
+        float o_[NOUT];
+        mlp_stream<NL, NOUT>(lds, in, kmax, o_);
+        s[0] = o_[0];
 #pragma unroll
-        for (int o = 1; o < NOUT; ++o) feature[i * NOUT + o] = layer1_row<NL>(lds, h, o);
+        for (int o = 0; o < NOUT; ++o) feature[i * NOUT + o] = o_[o];
+      } else {
+        float o_[1];
+        mlp_stream<NL, 1>(lds, in, kmax, o_);
+        s[e] = o_[0];
       }
     }
     sdf[i] = s[0];
