@@ -150,7 +150,10 @@ def ptr(t, dtype=None):
 
 
 def stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    """Raw handle of torch's current stream on the current device.  (The public
+    torch.cuda.current_stream() wrapper costs ~9 us per call: 0.17 ms of a 2 ms optimisation
+    step that launches ~100 kernels.)"""
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
 
 
 def hashgrid_levels(cfg: HashGridCfg):

@@ -409,7 +409,9 @@ class OrthoNeuSSystem:
             return
         main = torch.cuda.current_stream()
         if self._side is None:
-            self._side = torch.cuda.Stream()
+            # high priority: its 32 marching waves must not queue behind the main stream's
+            # chip-filling kernels, or the next step blocks on the sample count
+            self._side = torch.cuda.Stream(priority=-1)
         if done is None:
             done = torch.cuda.Event()
             done.record(main)
@@ -453,8 +455,10 @@ class OrthoNeuSSystem:
             prep = self._march_begin(inject)
             total, cmax = prep["handle"].stats.tolist()              # the step's one host sync
         else:
+            # The host waits for the event, so everything the side stream did before it is
+            # complete: no device-side wait is needed on the main stream (a cross-queue barrier
+            # packet cost ~80 us of main-stream idle time per step even when already signalled).
             prep["ready"].synchronize()                              # stats are in pinned memory
-            torch.cuda.current_stream().wait_event(prep["ready"])
             total, cmax = prep["stats_host"].tolist()
         batch, rays_d, h = prep["batch"], prep["handle"].rays_d, prep["handle"]
         dev = rays_d.device
@@ -479,15 +483,30 @@ class OrthoNeuSSystem:
         self.optimizer.zero_grad(set_to_none=True)
 
         # ---- forward
-        w0, b0, w1, b1 = geo._mlp()                      # weight-norm chain (autograd, tiny)
+        lin0, lin1 = [l for l in geo.network.layers if isinstance(l, torch.nn.Linear)]
+        wn = hasattr(lin0, "weight_g")
+        with torch.no_grad():
+            if wn:      # weight norm through the ATen ops directly (no autograd graph to walk)
+                w0, n0 = torch._weight_norm_interface(lin0.weight_v, lin0.weight_g, 0)
+                w1, n1 = torch._weight_norm_interface(lin1.weight_v, lin1.weight_g, 0)
+            else:
+                w0, w1 = lin0.weight, lin1.weight
+        b0, b1 = lin0.bias, lin1.bias
         mlp = [t.detach().contiguous() for t in (w0, b0, w1, b1)]
         table = enc.table_f16()
         eps, active = geo._finite_difference_eps, geo.active_levels
-        inv_s = m.variance.inv_s
         with torch.no_grad():
+            inv_s = m.variance.inv_s                     # exp(10 * variance)
             a_sdf, a_grad, a_feat, _, enc_cache = ops.sdf_fd_fwd(
                 enc.cfg, table, mlp, allp, geo.radius, eps, active, True, True, False,
                 enc_cache=True)
+            if not inject:
+                # issued once the geometry forward (0.3 ms of device work) is in the queue: the
+                # host's ~0.15 ms of launches for the next batch then cost the device nothing, and
+                # the march has the rest of this step to finish, so the next step never blocks
+                # on it (a cProfile of the loop showed 0.43 ms per step in Event.synchronize when
+                # the prefetch was issued behind the geometry backward)
+                self._launch_prefetch(done_event)
             normal, tex_in = ops.shade_prep_fwd(a_grad[:n_s], a_feat[:n_s])
         tex_fused = m.texture.fused_ok
         if tex_fused:
@@ -520,12 +539,13 @@ class OrthoNeuSSystem:
                 None, d_sdf_out=d_sdf_all[:n_s])
             if tex_fused:
                 d_tex_in, g_tex = ops.texture_bwd(tex_params, tex_in, rgb_d, d_rgb)
+        # d inv_s / d variance = 10 * inv_s
+        m.variance.variance.grad = (d_inv.view_as(inv_s) * inv_s * 10.0).view_as(m.variance.variance)
         if tex_fused:
             for p_, g_ in zip(m.texture.fused_params(), g_tex):
                 p_.grad = g_
-            torch.autograd.backward([inv_s], [d_inv.view_as(inv_s)])
         else:
-            torch.autograd.backward([rgb, inv_s], [d_rgb, d_inv.view_as(inv_s)])
+            torch.autograd.backward([rgb], [d_rgb])
             d_tex_in = tex_in.grad
         with torch.no_grad():
             ops.shade_prep_bwd(a_grad[:n_s], d_normal, d_tex_in,
@@ -537,14 +557,12 @@ class OrthoNeuSSystem:
             g_table, g = ops.sdf_fd_bwd(enc.cfg, table, mlp, allp, geo.radius, eps, active,
                                         d_sdf_all, d_grad_all, d_feat_all, None,
                                         enc_cache=enc_cache)
-        if not inject:
-            # issued AFTER the long geometry backward has been enqueued: the host spends ~0.4 ms
-            # launching the next batch's ~35 small kernels, time the device needs anyway
-            self._launch_prefetch(done_event)
         enc.params.grad = g_table
-        lin0, lin1 = [l for l in geo.network.layers if isinstance(l, torch.nn.Linear)]
-        if w0.requires_grad and w0.grad_fn is not None:
-            torch.autograd.backward([w0, w1], [g[0], g[2]])
+        if wn:
+            with torch.no_grad():
+                bw = torch.ops.aten._weight_norm_interface_backward
+                lin0.weight_v.grad, lin0.weight_g.grad = bw(g[0], lin0.weight_v, lin0.weight_g, n0, 0)
+                lin1.weight_v.grad, lin1.weight_g.grad = bw(g[2], lin1.weight_v, lin1.weight_g, n1, 0)
         else:                                            # no weight norm: w is the parameter
             lin0.weight.grad, lin1.weight.grad = g[0], g[2]
         lin0.bias.grad, lin1.bias.grad = g[1], g[3]
