@@ -184,7 +184,18 @@ def main():
                                              "(FETCH 36 MB + WRITE 504 MB) per launch at N=262144, "
                                              "4 levels vs 726 MB algorithmic for that launch",
                     "launches": ks["launches"], "avg_launch_ms": ks["avg_ms"],
-                    "alg_bytes_per_launch": ks["avg_bytes"]}
+                    "alg_bytes_per_launch": ks["avg_bytes"],
+                    # per-stage view (SURVEY.md §8d algorithmic FLOPs / wall time of the stage):
+                    # diffusion 2.913 TFLOP per UNet forward at B=12 (f16 MFMA peak 2.5 PFLOP/s),
+                    # stylisation 0.30 + 0.54 TFLOP per frame (f32 MFMA peak 157 TFLOP/s)
+                    "stages": {
+                        "mv": {"bound": "mfma", "unit": "TFLOP/s", "peak": 2500.0,
+                               "achieved": 2.913 * args.mv_steps / max(stage_t["mv"] / args.steps, 1e-9)},
+                        "style": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.0,
+                                  "achieved": 0.84 * args.frames / max(stage_t["style"] / args.steps, 1e-9)},
+                    }}
+            for st in roof["stages"].values():
+                st["frac"] = st["achieved"] / st["peak"]
         out = {
             "metric": "drawings/sec end-to-end (512x512, 6 views, 24 frames)",
             "value": drawings / elapsed, "unit": "drawings/s", "n_gpus": world,
