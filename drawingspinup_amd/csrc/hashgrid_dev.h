@@ -127,24 +127,6 @@ __device__ __forceinline__ uint32_t grad_cache_slot(uint32_t entry) {
   return (entry * 2654435761u) >> (32 - GC_LOG2);
 }
 
-// continuation of grad_cache_add after the first probe at `slot` found another key
-__device__ __forceinline__ void grad_cache_add_slow(uint32_t* keys, float* vals,
-                                                    float* __restrict__ gtable, uint32_t entry,
-                                                    uint32_t slot, float v0, float v1) {
-#pragma unroll
-  for (int probe = 1; probe < 3; ++probe) {
-    slot = (slot + 1) & (GC_SLOTS - 1);
-    const uint32_t old = atomicCAS(&keys[slot], GC_EMPTY, entry);
-    if (old == GC_EMPTY || old == entry) {
-      atomicAdd(&vals[2 * slot], v0);
-      atomicAdd(&vals[2 * slot + 1], v1);
-      return;
-    }
-  }
-  unsafeAtomicAdd(gtable + (size_t)entry * 2, v0);
-  unsafeAtomicAdd(gtable + (size_t)entry * 2 + 1, v1);
-}
-
 int make_meta(const dsu_hashgrid_cfg* cfg, GridMeta* m);
 
 }  // namespace dsu_hg

@@ -327,27 +327,8 @@ __device__ __forceinline__ float gc_unfix(unsigned long long a) {
   return (float)((double)(long long)a * (1.0 / (double)GC_FIX_SCALE));
 }
 
-// one queued contribution -> cache (3 probes) or, when the cache is full around its slot, a global
-// float atomic
-__device__ __forceinline__ void gc_commit(uint32_t* keys, unsigned long long* acc,
-                                          float* __restrict__ gtable, uint32_t entry, float v0,
-                                          float v1) {
-  uint32_t slot = grad_cache_slot(entry);
-#pragma unroll
-  for (int probe = 0; probe < 3; ++probe) {
-    const uint32_t old = atomicCAS(&keys[slot], GC_EMPTY, entry);
-    if (old == GC_EMPTY || old == entry) {
-      atomicAdd(&acc[2 * slot], gc_fix(v0));               // ds_add_u64, no return
-      atomicAdd(&acc[2 * slot + 1], gc_fix(v1));
-      return;
-    }
-    slot = (slot + 1) & (GC_SLOTS - 1);
-  }
-  unsafeAtomicAdd(gtable + (size_t)entry * 2, v0);
-  unsafeAtomicAdd(gtable + (size_t)entry * 2 + 1, v1);
-}
-
-// continuation of gc_commit after the first probe at `slot` found another key
+// a queued contribution whose first cache slot is owned by another entry: two more probes, then
+// a global float atomic (the cache is full around that slot)
 __device__ __forceinline__ void gc_commit_from(uint32_t* keys, unsigned long long* acc,
                                                float* __restrict__ gtable, uint32_t entry,
                                                uint32_t slot, float v0, float v1) {
