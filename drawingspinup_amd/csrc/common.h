@@ -23,3 +23,17 @@ static inline int dsu_capped_blocks(int64_t n, int threads, int cap = 2048) {
   if (b < 1) b = 1;
   return (int)(b > cap ? cap : b);
 }
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) costs ~55 us of host time per call (measured with
+// rocprofv3 --hip-runtime-trace): raise the limit once per kernel and process, and again only if a
+// larger size is ever requested.
+#define DSU_ENSURE_DYN_LDS(kernel, bytes)                                                   \
+  do {                                                                                      \
+    static int dsu_lds_set__ = 0;                                                           \
+    if (dsu_lds_set__ < (int)(bytes)) {                                                     \
+      if (hipFuncSetAttribute((const void*)(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)(bytes)) != hipSuccess)                                  \
+        return DSU_ELAUNCH;                                                                 \
+      dsu_lds_set__ = (int)(bytes);                                                         \
+    }                                                                                       \
+  } while (0)

@@ -917,9 +917,7 @@ int dsu_sdf_fd_bwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16, co
   const int blocks = dsu_capped_blocks(n, 256, BWD_MFMA_MAX_BLOCKS);
   const size_t shm = (size_t)BWD_LDS_F * sizeof(float);
   DSU_DISPATCH_NL(cfg->n_levels, {
-    if (hipFuncSetAttribute((const void*)sdf_fd_bwd_mfma_kernel<NL>,
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
-      return DSU_ELAUNCH;
+    DSU_ENSURE_DYN_LDS(sdf_fd_bwd_mfma_kernel<NL>, shm);
     sdf_fd_bwd_mfma_kernel<NL><<<dim3(blocks), dim3(256), shm, s>>>(
         (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
         d_grad, d_feature, d_laplace, grad_table, (float*)workspace, (const __half2*)enc_cache,

@@ -459,9 +459,7 @@ int dsu_ray_losses(const float* comp, const float* rgb, const float* normal, con
   int P = RL_THREADS;
   while (P < n_rays) P <<= 1;
   const size_t shm = (size_t)P * 16 + 256;
-  if (hipFuncSetAttribute((const void*)ray_losses_kernel,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
-    return DSU_ELAUNCH;
+  DSU_ENSURE_DYN_LDS(ray_losses_kernel, shm);
   ray_losses_kernel<<<3, RL_THREADS, shm, (hipStream_t)stream>>>(
       comp, rgb, normal, mask, cosines, view_weights, n_rays, P, *cfg, terms, d_comp);
   DSU_CHECK_LAUNCH();

@@ -459,9 +459,7 @@ int dsu_texture_bwd(const dsu_tex_mlp* mlp, const float* tex_in, const float* rg
   const int blocks = dsu_capped_blocks(n, 256, TEX_MAX_BLOCKS);
   const size_t shm = (size_t)BWD_LDS_F * sizeof(float);
   static_assert(PART_N <= 4 * STAGE_F, "reduction buffer must fit the staging area");
-  if (hipFuncSetAttribute((const void*)texture_bwd_kernel,
-                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
-    return DSU_ELAUNCH;
+  DSU_ENSURE_DYN_LDS(texture_bwd_kernel, shm);
   texture_bwd_kernel<<<blocks, 256, shm, s>>>(*mlp, tex_in, rgb, d_rgb, n, d_tex_in,
                                              (float*)workspace);
   texture_reduce_kernel<<<(PART_N + 63) / 64, 1024, 0, s>>>((const float*)workspace, blocks, g_w0,

@@ -424,11 +424,13 @@ class OrthoNeuSSystem:
             prep["ready"] = torch.cuda.Event()
             prep["ready"].record(self._side)
         prep["step"] = nxt
-        h = prep["handle"]
-        for t in (*prep["batch"].values(), h.rays_o, h.rays_d, h.counts, h.offsets, h.stats,
-                  prep["pts_random"], prep["perturb"],
-                  *[k for k in prep["keep"] if k is not None]):
-            t.record_stream(main)              # produced on the side stream, consumed on main
+        # No tensor.record_stream(main) here.  These tensors come from the side stream's pool and
+        # are read by main-stream kernels of the NEXT step; their blocks return to that pool when
+        # the step drops them and can only be re-used by a later prefetch, which the side stream
+        # starts after waiting for an event recorded on main behind that step's kernels (`done`
+        # above), so the re-use is already ordered.  record_stream would make the allocator put
+        # one hipEventRecord per tensor (16) into the MAIN queue between AdamW and the next step's
+        # compaction: ~80 us of command-processor work per step (hip-runtime trace).
         self._prefetched = prep
 
     def _take_prefetch(self):
