@@ -137,6 +137,33 @@ __device__ __forceinline__ void layer0_mfma(const Frags<NL>& f, const float* in,
       for (int r = 0; r < 16; ++r) acc[a][T][r] = softplus100(acc[a][T][r]);
 }
 
+// Hidden activations of ONE point half (the backward kernel walks the halves one at a time: a
+// `H[half]` array indexed by the run-time half lived in scratch memory, 320 B per lane).
+template <int NL>
+__device__ __forceinline__ void layer0_mfma_half(const Frags<NL>& f, const float* in,
+                                                 uint32_t active, int half, f32x16 (&acc)[2],
+                                                 int ablate = 0) {
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[T][r] = 0.0f;
+#pragma unroll
+  for (int t = 0; t < MC<NL>::KP; ++t) {
+    if (t < NL && (uint32_t)t >= active) continue;   // masked level: both inputs are zero
+    float b0, b1;
+    swap_halves(in[2 * t], in[2 * t + 1], b0, b1);
+    const float b = half ? b1 : b0;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+      acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w0[T][t], b, acc[T], 0, 0, 0);
+  }
+  if (ablate & 32) return;
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[T][r] = softplus100(acc[T][r]);
+}
+
 // out[0] of the lane's OWN point from the hidden activations spread over lane and lane^32
 template <int NL>
 __device__ __forceinline__ float layer1_o0(const Frags<NL>& f, const f32x16 (&H)[2][2], int h) {
@@ -350,14 +377,19 @@ __device__ __forceinline__ void gc_commit_from(uint32_t* keys, unsigned long lon
 constexpr int PART_GW0 = 0, PART_GW1 = 64 * 32, PART_GB1 = 2 * 64 * 32;
 constexpr int PART_STRIDE = 2 * 64 * 32 + 64;
 
-template <int NL>
+// SPLIT = false: one kernel does everything (table-gradient scatter included).
+// SPLIT = true : the kernel stops at dIn — the gradient on the interpolated features of every
+//   (evaluation, point, level) is written to `dinbuf` [eval][point][active level] float2 and
+//   sdf_fd_scatter_kernel turns it into table gradients.  Without the 80 KB gradient cache the
+//   MLP part fits two workgroups per CU (two waves per SIMD instead of one).
+template <int NL, bool SPLIT>
 __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     const __half2* __restrict__ table, GridMeta m, dsu_sdf_mlp mlp,
     const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
     uint32_t active, const float* __restrict__ d_sdf, const float* __restrict__ d_grad,
     const float* __restrict__ d_feature, const float* __restrict__ d_laplace,
     float* __restrict__ gtable, float* __restrict__ partials, const __half2* __restrict__ enc,
-    int ablate) {
+    float2* __restrict__ dinbuf, int ablate) {
   constexpr int KIN = MC<NL>::KIN;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* w1perm = lds;
@@ -384,10 +416,12 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     for (int r = 0; r < 16; ++r)
       w0t[T][r] = l31 < KIN ? w0p<NL>(mlp, feat_of(T, r, h), l31) : 0.0f;
   load_w1perm(w1perm, b1s, mlp);
-  for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
-    c_keys[t] = GC_EMPTY;
-    c_acc[2 * t] = 0ull;
-    c_acc[2 * t + 1] = 0ull;
+  if (!SPLIT) {
+    for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
+      c_keys[t] = GC_EMPTY;
+      c_acc[2 * t] = 0ull;
+      c_acc[2 * t + 1] = 0ull;
+    }
   }
   __syncthreads();
 
@@ -444,8 +478,6 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
       } else {
         encode_input_p<NL>(table, m, active, cx, cy, cz, in);
       }
-      f32x16 H[2][2];
-      layer0_mfma<NL>(fr, in, active, H, ablate);
       // upstream gradient on this evaluation's outputs (own point)
       float dout[NOUT];
 #pragma unroll
@@ -480,7 +512,8 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
           if (o < no) other = __shfl_xor(dout[o], 32);
           d[o] = (h == half) ? dout[o] : other;
         }
-        const f32x16(&Hh)[2] = H[half];
+        f32x16 Hh[2];
+        layer0_mfma_half<NL>(fr, in, active, half, Hh, ablate);
         f32x16 din;
 #pragma unroll
         for (int r = 0; r < 16; ++r) din[r] = 0.0f;
@@ -577,7 +610,19 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
             for (int r = 0; r < 16; ++r) gw1c0[T][r] = fmaf(Hh[T][r], d[0], gw1c0[T][r]);
         }
         // scatter dIn rows held by this lane: input row i = (r&3) + 8(r>>2) + 4h, levels (i>>1)
-        if (!(ablate & 1)) {
+        if (SPLIT) {
+          // dIn of this half's points -> dinbuf: lane (l31, h) holds the feature pairs of levels
+          // {0,1,4,5,8,9} (h = 0) or {2,3,6,7} (h = 1) of point (half, l31)
+          const int64_t pi = bbase + wave * 64 + half * 32 + l31;
+          if (pi < n) {
+            float2* row = dinbuf + ((size_t)e * n + pi) * active;
+#pragma unroll
+            for (int r = 0; r < 16; r += 2) {
+              const int lev = ((r & 3) + 8 * (r >> 2)) / 2 + 2 * h;
+              if (lev < NL && (uint32_t)lev < active) row[lev] = make_float2(din[r], din[r + 1]);
+            }
+          }
+        } else if (!(ablate & 1)) {
           const bool own = h == half;
           const float sx = own ? cx : pcx, sy = own ? cy : pcy, sz = own ? cz : pcz;
           const bool pv = __shfl(valid ? 1 : 0, half * 32 + l31) != 0;
@@ -697,6 +742,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
       }
     }
     // flush the gradient cache: one global atomic pair per touched entry, then reset
+    if (SPLIT) continue;
     __syncthreads();
     for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
       const uint32_t key = c_keys[t];
@@ -744,6 +790,136 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
   float* part = partials + (size_t)blockIdx.x * PART_STRIDE;
   for (int v = threadIdx.x; v < PART_GB1 + NOUT; v += blockDim.x)
     part[v] = (red[v] + red[PART_STRIDE + v]) + (red[2 * PART_STRIDE + v] + red[3 * PART_STRIDE + v]);
+}
+
+// ---------------------------------------------------------------------------- K2: scatter
+// Table gradients from dinbuf (SPLIT path).  One point per thread, 512 threads (8 waves) per
+// workgroup, one LEVEL at a time for the workgroup's 512 points (so the 4096-slot cache only ever
+// holds one level's entries and is flushed per level), all 7 evaluations of that level back to
+// back.  Same segmented DPP merge, per-wave queue and fixed-point cache as the fused kernel.
+constexpr int SC_THREADS = 512;
+constexpr int SC_QCAP = 704;                                  // triples per wave queue
+constexpr int SC_LDS_F = GC_SLOTS + 4 * GC_SLOTS + (SC_THREADS / 64) * 3 * SC_QCAP;
+
+template <int NL>
+__global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
+    GridMeta m, const float* __restrict__ pts, int64_t n, float radius, float eps, uint32_t active,
+    const float2* __restrict__ dinbuf, float* __restrict__ gtable) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  uint32_t* c_keys = reinterpret_cast<uint32_t*>(lds);
+  unsigned long long* c_acc = reinterpret_cast<unsigned long long*>(lds + GC_SLOTS);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* qbase = lds + 5 * GC_SLOTS + wave * 3 * SC_QCAP;
+  uint32_t* q_ent = reinterpret_cast<uint32_t*>(qbase);
+  float* q_v0 = qbase + SC_QCAP;
+  float* q_v1 = qbase + 2 * SC_QCAP;
+  for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
+    c_keys[t] = GC_EMPTY;
+    c_acc[2 * t] = 0ull;
+    c_acc[2 * t + 1] = 0ull;
+  }
+  __syncthreads();
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t bbase = blockIdx.x * (int64_t)blockDim.x; bbase < n; bbase += stride) {
+    const int64_t i = bbase + threadIdx.x;
+    const bool valid = i < n;
+    const int64_t ii = valid ? i : n - 1;
+    const float p[3] = {pts[ii * 3], pts[ii * 3 + 1], pts[ii * 3 + 2]};
+#pragma unroll 1
+    for (int lev = 0; lev < NL; ++lev) {
+      if ((uint32_t)lev >= active) break;
+      const float l_scale = m.scale[lev];
+      const uint32_t l_off = m.off[lev], hsize = m.off[lev + 1] - m.off[lev];
+      const uint32_t l_res = m.res[lev], l_hashed = m.hashed[lev];
+      int qn = 0;
+      auto drain = [&]() {
+        __builtin_amdgcn_wave_barrier();
+        for (int i0 = 0; i0 < qn; i0 += 64) {
+          const int qi = i0 + lane;
+          if (qi < qn) {
+            const uint32_t ent = q_ent[qi];
+            const float a0 = q_v0[qi], a1 = q_v1[qi];
+            const uint32_t slot = grad_cache_slot(ent);
+            const uint32_t old = atomicCAS(&c_keys[slot], GC_EMPTY, ent);
+            if (old == GC_EMPTY || old == ent) {
+              atomicAdd(&c_acc[2 * slot], gc_fix(a0));
+              atomicAdd(&c_acc[2 * slot + 1], gc_fix(a1));
+            } else {
+              gc_commit_from(c_keys, c_acc, gtable, ent, slot, a0, a1);
+            }
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        qn = 0;
+      };
+#pragma unroll 1
+      for (int e = 0; e < 7; ++e) {
+        float q[3];
+        fd_point(p, e, eps, radius, q);
+        const float cx = contract(q[0], radius), cy = contract(q[1], radius),
+                    cz = contract(q[2], radius);
+        float2 d = make_float2(0.0f, 0.0f);
+        if (valid) d = dinbuf[((size_t)e * n + i) * active + lev];
+        const CellPos cp = cell_of(l_scale, cx, cy, cz);
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+          const float w = corner_weight(cp, c);
+          v[2 * c] = w * d.x;
+          v[2 * c + 1] = w * d.y;
+        }
+        const int key = (int)(cp.c[0] | (cp.c[1] << 10) | (cp.c[2] << 20));
+        const int l15 = lane & 15;
+        int ee = (l15 == 15 || dpp_i<0x101>(key) != key) ? 1 : 0;   // run ends at this lane
+#define DSU_SEG_STEP(CTRL)                                              \
+        {                                                               \
+          const int eo = dpp_i<CTRL>(ee);                               \
+          _Pragma("unroll") for (int k = 0; k < 16; ++k) {              \
+            const float vo = dpp_f<CTRL>(v[k]);                         \
+            v[k] += ee ? 0.0f : vo;                                     \
+          }                                                             \
+          ee |= eo;                                                     \
+        }
+        DSU_SEG_STEP(0x101) DSU_SEG_STEP(0x102) DSU_SEG_STEP(0x104) DSU_SEG_STEP(0x108)
+#undef DSU_SEG_STEP
+        const bool lead = l15 == 0 || dpp_i<0x111>(key) != key;
+        const unsigned long long bal = __ballot(lead);
+        if (lead) {
+          const int pos = qn + 8 * __popcll(bal & ((1ull << lane) - 1ull));
+          uint32_t ent[8];
+#pragma unroll
+          for (int c = 0; c < 8; ++c)
+            ent[c] = l_off + grid_index(l_hashed, hsize, l_res, cp.c[0] + (c & 1),
+                                        cp.c[1] + ((c >> 1) & 1), cp.c[2] + ((c >> 2) & 1));
+#pragma unroll
+          for (int q4 = 0; q4 < 2; ++q4) {
+            *reinterpret_cast<uint4*>(&q_ent[pos + 4 * q4]) =
+                make_uint4(ent[4 * q4], ent[4 * q4 + 1], ent[4 * q4 + 2], ent[4 * q4 + 3]);
+            *reinterpret_cast<float4*>(&q_v0[pos + 4 * q4]) =
+                make_float4(v[8 * q4], v[8 * q4 + 2], v[8 * q4 + 4], v[8 * q4 + 6]);
+            *reinterpret_cast<float4*>(&q_v1[pos + 4 * q4]) =
+                make_float4(v[8 * q4 + 1], v[8 * q4 + 3], v[8 * q4 + 5], v[8 * q4 + 7]);
+          }
+        }
+        qn += 8 * __popcll(bal);
+        if (qn + 512 > SC_QCAP) drain();
+      }
+      drain();
+      // flush this level: one global atomic pair per touched entry, then reset
+      __syncthreads();
+      for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
+        const uint32_t key = c_keys[t];
+        if (key != GC_EMPTY) {
+          unsafeAtomicAdd(gtable + (size_t)key * 2, gc_unfix(c_acc[2 * t]));
+          unsafeAtomicAdd(gtable + (size_t)key * 2 + 1, gc_unfix(c_acc[2 * t + 1]));
+          c_keys[t] = GC_EMPTY;
+          c_acc[2 * t] = 0ull;
+          c_acc[2 * t + 1] = 0ull;
+        }
+      }
+      __syncthreads();
+    }
+  }
 }
 
 template <int NL>
@@ -806,6 +982,16 @@ extern "C" int64_t dsu_sdf_fd_bwd_workspace_bytes_valu(const dsu_hashgrid_cfg*, 
 //   forward:  VALU 0.22 ms vs MFMA 0.30 ms  -> VALU (gather-latency bound; 2 waves/SIMD help)
 //   backward: VALU 2.31 ms vs MFMA 1.60 ms  -> MFMA
 // DSU_SDF_IMPL=valu|mfma forces one implementation for everything (A/B runs, tests).
+// DSU_BWD_SPLIT=1: MLP backward and table scatter as two kernels (see sdf_fd_bwd_mfma_kernel)
+static bool bwd_split() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("DSU_BWD_SPLIT");
+    v = (e && atoi(e) != 0) ? 1 : 0;
+  }
+  return v == 1;
+}
+
 static bool use_valu(bool forward) {
   static int v = -1;
   if (v < 0) {
@@ -888,7 +1074,10 @@ int64_t dsu_sdf_fd_bwd_workspace_bytes(const dsu_hashgrid_cfg* cfg, int64_t n) {
   if (!cfg || n < 0) return DSU_EINVAL;
   if (cfg->n_levels != 10 && cfg->n_levels != 12) return DSU_EUNSUP;
   const int blocks = dsu_capped_blocks(n, 256, BWD_MFMA_MAX_BLOCKS);
-  return (int64_t)blocks * PART_STRIDE * sizeof(float);
+  int64_t bytes = (int64_t)blocks * PART_STRIDE * sizeof(float);
+  // split form: + dIn of every (evaluation, point, level) as float2
+  if (bwd_split()) bytes += (int64_t)7 * n * cfg->n_levels * (int64_t)sizeof(float2);
+  return bytes;
 }
 
 int dsu_sdf_fd_bwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
@@ -915,13 +1104,38 @@ int dsu_sdf_fd_bwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16, co
   hipStream_t s = (hipStream_t)stream;
   const float eps2 = (float)((double)eps * (double)eps);
   const int blocks = dsu_capped_blocks(n, 256, BWD_MFMA_MAX_BLOCKS);
+  const int ablate = getenv("DSU_BWD_ABLATE") ? atoi(getenv("DSU_BWD_ABLATE")) : 0;
+  if (bwd_split()) {
+    const size_t shm1 = (size_t)BWD_CACHE_OFF * sizeof(float);         // no gradient cache
+    const size_t shm2 = (size_t)SC_LDS_F * sizeof(float);
+    float2* dinbuf = reinterpret_cast<float2*>((char*)workspace +
+                                               (size_t)blocks * PART_STRIDE * sizeof(float));
+    const int sblocks = dsu_capped_blocks(n, SC_THREADS, 256);
+    DSU_DISPATCH_NL(cfg->n_levels, {
+      auto k1 = sdf_fd_bwd_mfma_kernel<NL, true>;
+      auto k2 = sdf_fd_scatter_kernel<NL>;
+      DSU_ENSURE_DYN_LDS(k1, shm1);
+      DSU_ENSURE_DYN_LDS(k2, shm2);
+      k1<<<dim3(blocks), dim3(256), shm1, s>>>(
+          (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
+          d_grad, d_feature, d_laplace, grad_table, (float*)workspace, (const __half2*)enc_cache,
+          dinbuf, ablate);
+      k2<<<dim3(sblocks), dim3(SC_THREADS), shm2, s>>>(m, pts, n, radius, eps, active_levels,
+                                                      dinbuf, grad_table);
+      reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 63) / 64), dim3(1024), 0, s>>>(
+          (const float*)workspace, blocks, g_w0, g_b0, g_w1, g_b1);
+    });
+    DSU_CHECK_LAUNCH();
+    return DSU_OK;
+  }
   const size_t shm = (size_t)BWD_LDS_F * sizeof(float);
   DSU_DISPATCH_NL(cfg->n_levels, {
-    DSU_ENSURE_DYN_LDS(sdf_fd_bwd_mfma_kernel<NL>, shm);
-    sdf_fd_bwd_mfma_kernel<NL><<<dim3(blocks), dim3(256), shm, s>>>(
+    auto k0 = sdf_fd_bwd_mfma_kernel<NL, false>;
+    DSU_ENSURE_DYN_LDS(k0, shm);
+    k0<<<dim3(blocks), dim3(256), shm, s>>>(
         (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
         d_grad, d_feature, d_laplace, grad_table, (float*)workspace, (const __half2*)enc_cache,
-        getenv("DSU_BWD_ABLATE") ? atoi(getenv("DSU_BWD_ABLATE")) : 0);
+        nullptr, ablate);
     reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 63) / 64), dim3(1024), 0, s>>>(
         (const float*)workspace, blocks, g_w0, g_b0, g_w1, g_b1);
   });
