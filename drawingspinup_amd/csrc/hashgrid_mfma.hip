@@ -382,7 +382,9 @@ constexpr int PART_STRIDE = 2 * 64 * 32 + 64;
 //   (evaluation, point, level) is written to `dinbuf` [eval][point][active level] float2 and
 //   sdf_fd_scatter_kernel turns it into table gradients.  Without the 80 KB gradient cache the
 //   MLP part fits two workgroups per CU (two waves per SIMD instead of one).
-template <int NL, bool SPLIT>
+// ENC = true: the interpolated features come from the forward pass's cache (the table-gather path
+// and its 40+ scalar registers of level metadata are compiled out).
+template <int NL, bool SPLIT, bool ENC>
 __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     const __half2* __restrict__ table, GridMeta m, dsu_sdf_mlp mlp,
     const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
@@ -461,7 +463,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
       if (ablate & 16) {
 #pragma unroll
         for (int k = 0; k < KIN; ++k) in[k] = cx * (float)k + cy;
-      } else if (enc != nullptr) {
+      } else if (ENC) {
         // features saved by the forward pass: no table gathers in the backward pass
         const __half2* row = enc + ((size_t)e * n + ii) * active;
 #pragma unroll
@@ -1112,9 +1114,11 @@ int dsu_sdf_fd_bwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16, co
                                                (size_t)blocks * PART_STRIDE * sizeof(float));
     const int sblocks = dsu_capped_blocks(n, SC_THREADS, 256);
     DSU_DISPATCH_NL(cfg->n_levels, {
-      auto k1 = sdf_fd_bwd_mfma_kernel<NL, true>;
+      auto k1 = enc_cache ? sdf_fd_bwd_mfma_kernel<NL, true, true>
+                          : sdf_fd_bwd_mfma_kernel<NL, true, false>;
       auto k2 = sdf_fd_scatter_kernel<NL>;
-      DSU_ENSURE_DYN_LDS(k1, shm1);
+      DSU_ENSURE_DYN_LDS((sdf_fd_bwd_mfma_kernel<NL, true, true>), shm1);
+      DSU_ENSURE_DYN_LDS((sdf_fd_bwd_mfma_kernel<NL, true, false>), shm1);
       DSU_ENSURE_DYN_LDS(k2, shm2);
       k1<<<dim3(blocks), dim3(256), shm1, s>>>(
           (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
@@ -1130,8 +1134,10 @@ int dsu_sdf_fd_bwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16, co
   }
   const size_t shm = (size_t)BWD_LDS_F * sizeof(float);
   DSU_DISPATCH_NL(cfg->n_levels, {
-    auto k0 = sdf_fd_bwd_mfma_kernel<NL, false>;
-    DSU_ENSURE_DYN_LDS(k0, shm);
+    auto k0 = enc_cache ? sdf_fd_bwd_mfma_kernel<NL, false, true>
+                        : sdf_fd_bwd_mfma_kernel<NL, false, false>;
+    DSU_ENSURE_DYN_LDS((sdf_fd_bwd_mfma_kernel<NL, false, true>), shm);
+    DSU_ENSURE_DYN_LDS((sdf_fd_bwd_mfma_kernel<NL, false, false>), shm);
     k0<<<dim3(blocks), dim3(256), shm, s>>>(
         (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
         d_grad, d_feature, d_laplace, grad_table, (float*)workspace, (const __half2*)enc_cache,
