@@ -100,7 +100,7 @@ __device__ __forceinline__ void load_mlp_to_lds(float* lds, const float* __restr
 }
 
 // Encode one contracted point into the MLP input vector (xyz*2-1, masked features).
-template <int NL>
+template <int NL, int LMAX = NL>
 __device__ __forceinline__ void encode_input(const __half2* __restrict__ table,
                                              const GridMeta& m, uint32_t active, float x,
                                              float y, float z, float* in /*3+2NL*/) {
@@ -110,7 +110,7 @@ __device__ __forceinline__ void encode_input(const __half2* __restrict__ table,
 #pragma unroll
   for (int l = 0; l < NL; ++l) {
     float2 f = make_float2(0.0f, 0.0f);
-    if ((uint32_t)l < active) f = __half22float2(lookup_level(table, m, l, x, y, z));
+    if (l < LMAX && (uint32_t)l < active) f = __half22float2(lookup_level(table, m, l, x, y, z));
     in[3 + 2 * l] = f.x;
     in[4 + 2 * l] = f.y;
   }
@@ -166,7 +166,7 @@ __device__ __forceinline__ float layer1_row(const float* lds, const float* h, in
 // chain as layer0), Softplus, then the group's contribution to each of the NO outputs (same
 // j-ascending fma chain as layer1_row) — bit-identical results, but the 64 hidden activations
 // never exist at once (199 -> ~90 VGPRs: twice the resident waves to hide the table gathers).
-template <int NL, int NO>
+template <int NL, int NO, int LMAX = NL>
 __device__ __forceinline__ void mlp_stream(const float* lds, const float* in, int kmax,
                                            float* out /*NO*/) {
   using L = MlpLds<NL>;
@@ -178,7 +178,7 @@ __device__ __forceinline__ void mlp_stream(const float* lds, const float* in, in
     const float4 b = b4[j4];
     float p0 = b.x, p1 = b.y, p2 = b.z, p3 = b.w;
 #pragma unroll
-    for (int k = 0; k < L::DIN; ++k) {
+    for (int k = 0; k < 3 + 2 * LMAX; ++k) {
       if (k < kmax) {
         const float4 w = reinterpret_cast<const float4*>(lds + L::W0T + k * HID)[j4];
         const float v = in[k];
@@ -227,7 +227,9 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(const __half2* __restrict_
 }
 
 // VolumeSDF.forward with finite differences: 7 evaluations per point.
-template <int NL>
+// LMAX: compile-time bound on the active levels (the 3000-step schedule uses 4..6 of the 10):
+// levels >= LMAX, their metadata scalars and their share of the first-layer loop are compiled out.
+template <int NL, int LMAX>
 __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
     const __half2* __restrict__ table, GridMeta m, dsu_sdf_mlp mlp,
     const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
@@ -255,25 +257,25 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
         }
       }
       float in[L::DIN];
-      encode_input<NL>(table, m, active, contract(q[0], radius), contract(q[1], radius),
-                       contract(q[2], radius), in);
+      encode_input<NL, LMAX>(table, m, active, contract(q[0], radius), contract(q[1], radius),
+                             contract(q[2], radius), in);
       if (enc != nullptr) {
         // interpolated f16 features of this evaluation, kept for the backward pass (exact: the
         // floats are widened halfs).  Layout [eval][point][active level].
         __half2* row = enc + ((size_t)e * n + i) * active;
 #pragma unroll
-        for (int l = 0; l < NL; ++l)
+        for (int l = 0; l < LMAX; ++l)
           if ((uint32_t)l < active) row[l] = __floats2half2_rn(in[3 + 2 * l], in[3 + 2 * l + 1]);
       }
       if (e == 0 && feature != nullptr) {
         float o_[NOUT];
-        mlp_stream<NL, NOUT>(lds, in, kmax, o_);
+        mlp_stream<NL, NOUT, LMAX>(lds, in, kmax, o_);
         s[0] = o_[0];
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) feature[i * NOUT + o] = o_[o];
       } else {
         float o_[1];
-        mlp_stream<NL, 1>(lds, in, kmax, o_);
+        mlp_stream<NL, 1, LMAX>(lds, in, kmax, o_);
         s[e] = o_[0];
       }
     }
@@ -734,9 +736,14 @@ int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, cons
   const int blocks = dsu_capped_blocks(n, 256, 8192);
   DSU_DISPATCH_NL(cfg->n_levels, {
     const size_t shm = MlpLds<NL>::TOTAL * sizeof(float);
-    sdf_fd_fwd_kernel<NL><<<dim3(blocks), dim3(256), shm, s>>>(
-        (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, sdf, grad,
-        feature, laplace, (__half2*)enc_cache);
+    if (active_levels <= 6)
+      sdf_fd_fwd_kernel<NL, 6><<<dim3(blocks), dim3(256), shm, s>>>(
+          (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, sdf, grad,
+          feature, laplace, (__half2*)enc_cache);
+    else
+      sdf_fd_fwd_kernel<NL, NL><<<dim3(blocks), dim3(256), shm, s>>>(
+          (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, sdf, grad,
+          feature, laplace, (__half2*)enc_cache);
   });
   DSU_CHECK_LAUNCH();
   return DSU_OK;
