@@ -35,6 +35,11 @@ class TexMlp(C.Structure):
                 ("b2", c_vp)]
 
 
+class NormCfg(C.Structure):
+    _fields_ = [("batch", c_i32), ("channels", c_i32), ("hw", c_i32), ("instance", c_i32),
+                ("act", c_i32), ("stat_updates", c_i32), ("eps", c_f32), ("momentum", c_f32)]
+
+
 class RayLossCfg(C.Structure):
     _fields_ = [("rgb_p_ratio", C.c_double), ("normal_p_ratio", C.c_double),
                 ("mask_p_ratio", C.c_double), ("lambda_rgb_mse", c_f32),
@@ -101,6 +106,22 @@ _PROTOS = {
     "dsu_groupnorm_nhwc_f16": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, P, P, P],
     "dsu_layernorm_f16": [P, P, P, c_i64, c_i32, c_f32, P, P],
     "dsu_geglu_f16": [P, c_i64, c_i32, P, P],
+    "dsu_deform_tap_table_bytes": [c_i32, c_i32],
+    "dsu_deform_tap_table": [P, c_i32, c_i32, P, P],
+    "dsu_conv2d_wgrad_workspace_bytes": [c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32],
+    "dsu_conv2d_wgrad": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, P, P,
+                         c_i32, P],
+    "dsu_deform_conv3x3_dgrad_gather": [P, P, P, P, c_i64, c_i32, P, P],
+    "dsu_norm_train_fwd": [C.POINTER(NormCfg), P, P, P, P, P, P, P, P, P],
+    "dsu_norm_train_bwd": [C.POINTER(NormCfg), P, P, P, P, P, P, P, P, P, P],
+    "dsu_channel_sum": [P, c_i32, c_i32, c_i32, P, P],
+    "dsu_act_fwd": [P, P, c_i64, c_i32, P],
+    "dsu_act_bwd": [P, P, P, c_i64, c_i32, P],
+    "dsu_maxpool2_fwd": [P, P, c_i64, c_i32, c_i32, P],
+    "dsu_maxpool2_bwd": [P, P, P, c_i64, c_i32, c_i32, P],
+    "dsu_upsample2_fwd": [P, P, c_i64, c_i32, c_i32, P],
+    "dsu_upsample2_bwd": [P, P, c_i64, c_i32, c_i32, P],
+    "dsu_pair_loss": [P, P, c_f32, c_i64, c_i32, c_f32, P, P, P],
     "dsu_conv2d_fwd": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                        P, P, c_i32, P, P, P],
 }

@@ -1,0 +1,104 @@
+"""Shared body of train_stage1.py / train_stage2.py (3_style_translator/train_stage{1,2}.py).
+
+The job description is the reference's configs/config_stage{1,2}.yaml; pass --config to read
+such a file, otherwise the shipped values below are used.
+"""
+import argparse
+import copy
+import os
+import time
+
+import torch
+
+from ..style.training import ModelLogger, Trainer, build_model, build_optimizer
+
+_OPT = {"type": "Adam", "args": {"lr": 0.0004, "betas": [0.9, 0.999], "weight_decay": 0.00001}}
+
+
+def default_job(stage):
+    """configs/config_stage1.yaml / config_stage2.yaml."""
+    return {
+        "generator": {"type": "GeneratorJ_RIC" if stage == 1 else "GeneratorJ",
+                      "args": dict(use_bias=False, tanh=True, append_smoothers=True,
+                                   resnet_blocks=7, filters=[32, 64, 128, 128, 128, 64],
+                                   input_channels=3)},
+        "opt_generator": copy.deepcopy(_OPT),
+        "discriminator": {"type": "DiscriminatorN_IN", "args": dict(num_filters=12, n_layers=2)},
+        "opt_discriminator": copy.deepcopy(_OPT),
+        "perception_loss": {"weight": 6.0,
+                            "perception_model": {"type": "PerceptualVGG19",
+                                                 "args": dict(feature_layers=[0, 3, 5],
+                                                              use_normalization=False)}},
+        "trainer": dict(batch_size=40, num_workers=1, epochs=3 if stage == 1 else 2,
+                        reconstruction_weight=4.0, adversarial_weight=0.5, use_image_loss=True,
+                        reconstruction_criterion="L1Loss", adversarial_criterion="MSELoss",
+                        log_interval=1000, patch_size=32,
+                        pre_dir="color" if stage == 1 else "res_stage1_mask_pos",
+                        post_name="ffc_resnet_inpainted" if stage == 1 else "texture_with_bg"),
+        "device": "cuda:0",
+        "root_dir": "../dataset/AnimatedDrawings/preprocessed",
+    }
+
+
+def run(stage, argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--uid", default="0dd66be9d0534b93a092d8c4c4dfd30a")
+    ap.add_argument("--no_mask", action="store_true")
+    ap.add_argument("--no_pos", action="store_true")
+    if stage == 2:
+        ap.add_argument("--no_edge", action="store_true")
+    ap.add_argument("--config", default=None, help="a configs/config_stageN.yaml of the reference")
+    ap.add_argument("--vgg", default=None, help="vgg19 state_dict (torchvision layout)")
+    args = ap.parse_args(argv)
+
+    if args.config:
+        import yaml
+        with open(args.config) as f:
+            config = yaml.load(f, Loader=yaml.FullLoader)["job"]
+    else:
+        config = default_job(stage)
+    config["data_root"] = os.path.join(config["root_dir"], args.uid, "mesh", "blender_render")
+    use_mask, use_pos = not args.no_mask, not args.no_pos
+    use_edge = stage == 2 and not args.no_edge
+    log_name = f"logs_stage{stage}"
+    if use_mask:
+        log_name += "_mask"
+        config["generator"]["args"]["input_channels"] += 1
+    if use_pos:
+        log_name += "_pos"
+        config["generator"]["args"]["input_channels"] += 2
+    if use_edge:
+        log_name += "_edge"
+    log_folder = os.path.join(config["root_dir"], args.uid, "mesh", log_name)
+    os.makedirs(log_folder, exist_ok=True)
+    model_logger = ModelLogger(log_folder, torch.save)
+    if args.config:
+        model_logger.copy_file(args.config)
+
+    device = config.get("device") or "cuda:0"
+    generator = build_model(config["generator"]["type"], config["generator"]["args"], device)
+    opt_generator = build_optimizer(config["opt_generator"]["type"], generator,
+                                    config["opt_generator"]["args"])
+    discriminator = build_model(config["discriminator"]["type"], config["discriminator"]["args"],
+                                device)
+    opt_discriminator = build_optimizer(config["opt_discriminator"]["type"], discriminator,
+                                        config["opt_discriminator"]["args"])
+    perc_args = dict(config["perception_loss"]["perception_model"]["args"])
+    if args.vgg:
+        perc_args["path"] = args.vgg
+    perception_loss_model = build_model(config["perception_loss"]["perception_model"]["type"],
+                                        perc_args, device)
+
+    trainer_config = dict(config["trainer"])
+    trainer_config["testing_name_list"] = [f for f in os.listdir(config["data_root"])
+                                           if not f.startswith(".")]
+    trainer_config["post_dir"] = os.path.join(config["root_dir"], args.uid, "char")
+    trainer = Trainer(data_root=config["data_root"], trainer_config=trainer_config,
+                      opt_generator=opt_generator, opt_discriminator=opt_discriminator,
+                      model_logger=model_logger, perception_loss_model=perception_loss_model,
+                      perception_loss_weight=config["perception_loss"]["weight"],
+                      use_mask=use_mask, use_pos=use_pos, use_edge=use_edge, device=device)
+    start = time.time()
+    trainer.train(generator, discriminator, int(config["trainer"]["epochs"]),
+                  log_name.replace("logs", "res"), 0)
+    print("Training finished, cost time: ", time.time() - start)

@@ -10,7 +10,7 @@ from dataclasses import dataclass
 import torch
 
 from . import _lib
-from ._lib import DsuError, HashGridCfg, SdfMlp, check, lib, ptr, stream
+from ._lib import DsuError, HashGridCfg, NormCfg, SdfMlp, check, lib, ptr, stream
 
 
 @dataclass(frozen=True)
@@ -472,6 +472,218 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, ep_scale=None, ep_shift=No
                                ptr(residual),
                                ptr(out), stream()), "dsu_conv2d_fwd")
     return out
+
+
+# ------------------------------------------------------------------ style translator: training
+class DeformPlan:
+    """Everything the fixed-offset deformable convolution needs besides the weights, for one
+    (18,H,W) offset map: the per-(pixel, tap) sampling table (dsu_deform_tap_table) and its
+    transpose as CSR over input pixels (built once on the host from that table)."""
+
+    def __init__(self, offset):
+        offset = _f32c(offset)
+        assert offset.dim() == 3 and offset.shape[0] == 18
+        self.offset = offset
+        _, H, W = offset.shape
+        self.H, self.W, self.npix = H, W, H * W
+        nbytes = int(lib().dsu_deform_tap_table_bytes(H, W))
+        self.table = torch.empty(nbytes, dtype=torch.uint8, device=offset.device)
+        check(lib().dsu_deform_tap_table(ptr(offset), H, W, ptr(self.table), stream()),
+              "dsu_deform_tap_table")
+        rowptr, src, wgt = transpose_tap_table(self.table.cpu().numpy(), self.npix)
+        dev = offset.device
+        self.rowptr = torch.from_numpy(rowptr).to(dev)
+        self.src = torch.from_numpy(src).to(dev)
+        self.wgt = torch.from_numpy(wgt).to(dev)
+
+
+def transpose_tap_table(table_bytes, npix):
+    """(npix*9 records of 4 int32 corner offsets + 4 f32 weights) -> CSR over input pixels:
+    rowptr (npix+1) int32, src = tap*npix + output_pixel int32, wgt f32.  Zero-weight corners
+    (outside the image) are dropped; entries of a row keep (pixel, tap, corner) order."""
+    import numpy as np
+    rec = np.frombuffer(table_bytes, dtype=np.int32).reshape(npix * 9, 8)
+    idx = rec[:, :4].reshape(-1)                                  # (npix*9*4,)
+    w = rec[:, 4:].copy().view(np.float32).reshape(-1)
+    pt = np.repeat(np.arange(npix * 9, dtype=np.int64), 4)        # record index = pix*9 + tap
+    pix, tap = pt // 9, pt % 9
+    keep = w != 0.0
+    idx, w, srcv = idx[keep].astype(np.int64), w[keep], (tap * npix + pix)[keep]
+    order = np.argsort(idx, kind="stable")
+    counts = np.bincount(idx, minlength=npix)
+    rowptr = np.zeros(npix + 1, dtype=np.int32)
+    rowptr[1:] = np.cumsum(counts)
+    return rowptr, srcv[order].astype(np.int32), w[order].astype(np.float32)
+
+
+_DEFORM_PLANS = {}
+
+
+def deform_plan(offset):
+    """Cached DeformPlan for an offset map (keyed by storage, shape and device)."""
+    key = (offset.data_ptr(), tuple(offset.shape), str(offset.device))
+    plan = _DEFORM_PLANS.get(key)
+    if plan is None:
+        plan = _DEFORM_PLANS[key] = DeformPlan(offset)
+    return plan
+
+
+def conv2d_wgrad(x, dout, k, stride=1, padding=0, plan=None, out=None, accumulate=False):
+    """dW of nn.Conv2d, or of the fixed-offset deformable convolution when plan is given."""
+    x, dout = _f32c(x), _f32c(dout)
+    B, Cin, H, W = x.shape
+    O, OH, OW = dout.shape[1], dout.shape[2], dout.shape[3]
+    nbytes = int(lib().dsu_conv2d_wgrad_workspace_bytes(1 if plan is not None else 0, B, Cin, O,
+                                                        OH, OW, k))
+    if nbytes <= 0:
+        raise DsuError("dsu_conv2d_wgrad_workspace_bytes: unsupported shape")
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    dw = out if out is not None else torch.empty((O, Cin, k, k), dtype=torch.float32,
+                                                 device=x.device)
+    check(lib().dsu_conv2d_wgrad(ptr(x), ptr(dout), ptr(plan.table) if plan is not None else None,
+                                 B, Cin, H, W, O, k, stride, padding, ptr(ws), ptr(dw),
+                                 int(accumulate), stream()), "dsu_conv2d_wgrad")
+    return dw
+
+
+def conv2d_dgrad(dout, weight, in_hw, stride=1, padding=0):
+    """dX of nn.Conv2d: the forward kernel on (zero-dilated, for stride > 1) dout with the
+    spatially flipped, channel-transposed weight and padding k-1-p."""
+    O, Cin, k, _ = weight.shape
+    H, W = in_hw
+    wt = weight.flip(2, 3).transpose(0, 1).contiguous()
+    dout = _f32c(dout)
+    if stride != 1:
+        B, _, OH, OW = dout.shape
+        d = torch.zeros((B, O, H - k + 1 + 2 * padding, W - k + 1 + 2 * padding),
+                        dtype=torch.float32, device=dout.device)
+        d[:, :, ::stride, ::stride][:, :, :OH, :OW] = dout
+        dout = d
+    dx = conv2d(dout, wt, None, 1, k - 1 - padding)
+    assert tuple(dx.shape[2:]) == (H, W), (dx.shape, in_hw)
+    return dx
+
+
+def deform_conv3x3_dgrad(dout, weight, plan):
+    """dX of the fixed-offset deformable convolution: dcol = W^T dout (1x1 convolution), then
+    the transposed sampling operator as a gather."""
+    dout = _f32c(dout)
+    B, O, H, W = dout.shape
+    Cin = weight.shape[1]
+    wt = weight.permute(1, 2, 3, 0).reshape(Cin * 9, O, 1, 1).contiguous()
+    dcol = conv2d(dout, wt, None, 1, 0)
+    dx = torch.empty((B, Cin, H, W), dtype=torch.float32, device=dout.device)
+    check(lib().dsu_deform_conv3x3_dgrad_gather(ptr(dcol), ptr(plan.rowptr), ptr(plan.src),
+                                                ptr(plan.wgt), B * Cin, H * W, ptr(dx), stream()),
+          "dsu_deform_conv3x3_dgrad_gather")
+    return dx
+
+
+def _norm_cfg(x, instance, act, eps, momentum, stat_updates):
+    B, Cn = x.shape[0], x.shape[1]
+    return NormCfg(B, Cn, x[0, 0].numel(), int(instance), ACT[act], int(stat_updates), float(eps),
+                   float(momentum))
+
+
+def norm_train_fwd(x, gamma=None, beta=None, running_mean=None, running_var=None, instance=False,
+                   act=None, eps=1e-5, momentum=0.1, stat_updates=1):
+    """BatchNorm2d (training) / InstanceNorm2d + activation.  Returns y, save_mean, save_invstd."""
+    x = _f32c(x)
+    cfg = _norm_cfg(x, instance, act, eps, momentum, stat_updates)
+    groups = x.shape[0] * x.shape[1] if instance else x.shape[1]
+    y = torch.empty_like(x)
+    stats = torch.empty((2, groups), dtype=torch.float32, device=x.device)
+    check(lib().dsu_norm_train_fwd(C.byref(cfg), ptr(x), ptr(gamma), ptr(beta), ptr(running_mean),
+                                   ptr(running_var), ptr(y), ptr(stats[0]), ptr(stats[1]),
+                                   stream()), "dsu_norm_train_fwd")
+    return y, stats[0], stats[1]
+
+
+def norm_train_bwd(x, y, dy, gamma, save_mean, save_invstd, instance=False, act=None,
+                   affine_grads=True):
+    x, y, dy = _f32c(x), _f32c(y), _f32c(dy)
+    cfg = _norm_cfg(x, instance, act, 0.0, 0.0, 0)
+    dx = torch.empty_like(x)
+    dgb = None
+    if affine_grads and not instance:
+        dgb = torch.empty((2, x.shape[1]), dtype=torch.float32, device=x.device)
+    check(lib().dsu_norm_train_bwd(C.byref(cfg), ptr(x), ptr(y), ptr(dy), ptr(gamma),
+                                   ptr(save_mean), ptr(save_invstd), ptr(dx),
+                                   ptr(dgb[0]) if dgb is not None else None,
+                                   ptr(dgb[1]) if dgb is not None else None, stream()),
+          "dsu_norm_train_bwd")
+    return (dx, dgb[0], dgb[1]) if dgb is not None else (dx, None, None)
+
+
+def channel_sum(x):
+    x = _f32c(x)
+    B, Cn = x.shape[0], x.shape[1]
+    out = torch.empty(Cn, dtype=torch.float32, device=x.device)
+    check(lib().dsu_channel_sum(ptr(x), B, Cn, x[0, 0].numel(), ptr(out), stream()),
+          "dsu_channel_sum")
+    return out
+
+
+def act_fwd(x, act):
+    x = _f32c(x)
+    y = torch.empty_like(x)
+    check(lib().dsu_act_fwd(ptr(x), ptr(y), x.numel(), ACT[act], stream()), "dsu_act_fwd")
+    return y
+
+
+def act_bwd(dy, y, act):
+    dy, y = _f32c(dy), _f32c(y)
+    dx = torch.empty_like(y)
+    check(lib().dsu_act_bwd(ptr(dy), ptr(y), ptr(dx), y.numel(), ACT[act], stream()), "dsu_act_bwd")
+    return dx
+
+
+def maxpool2_fwd(x):
+    x = _f32c(x)
+    B, Cn, H, W = x.shape
+    y = torch.empty((B, Cn, H // 2, W // 2), dtype=torch.float32, device=x.device)
+    check(lib().dsu_maxpool2_fwd(ptr(x), ptr(y), B * Cn, H, W, stream()), "dsu_maxpool2_fwd")
+    return y
+
+
+def maxpool2_bwd(x, dy):
+    x, dy = _f32c(x), _f32c(dy)
+    B, Cn, H, W = x.shape
+    dx = torch.empty_like(x)
+    check(lib().dsu_maxpool2_bwd(ptr(x), ptr(dy), ptr(dx), B * Cn, H, W, stream()),
+          "dsu_maxpool2_bwd")
+    return dx
+
+
+def upsample2_fwd(x):
+    x = _f32c(x)
+    B, Cn, H, W = x.shape
+    y = torch.empty((B, Cn, 2 * H, 2 * W), dtype=torch.float32, device=x.device)
+    check(lib().dsu_upsample2_fwd(ptr(x), ptr(y), B * Cn, H, W, stream()), "dsu_upsample2_fwd")
+    return y
+
+
+def upsample2_bwd(dy):
+    dy = _f32c(dy)
+    B, Cn, H2, W2 = dy.shape
+    dx = torch.empty((B, Cn, H2 // 2, W2 // 2), dtype=torch.float32, device=dy.device)
+    check(lib().dsu_upsample2_bwd(ptr(dy), ptr(dx), B * Cn, H2 // 2, W2 // 2, stream()),
+          "dsu_upsample2_bwd")
+    return dx
+
+
+def pair_loss(x, target, kind, grad_scale=None):
+    """kind 'l1' | 'mse'; target: tensor like x or a float.  Returns (sum of |d| or d^2 as a
+    0-dim tensor, grad or None) with grad = d(grad_scale * sum)/dx."""
+    x = _f32c(x)
+    t = _f32c(target) if torch.is_tensor(target) else None
+    tconst = 0.0 if t is not None else float(target)
+    partial = torch.empty(256, dtype=torch.float32, device=x.device)
+    grad = torch.empty_like(x) if grad_scale is not None else None
+    check(lib().dsu_pair_loss(ptr(x), ptr(t), tconst, x.numel(), {"l1": 0, "mse": 1}[kind],
+                              float(grad_scale or 0.0), ptr(grad), ptr(partial), stream()),
+          "dsu_pair_loss")
+    return partial.sum(), grad
 
 
 # ------------------------------------------------------------------ multi-view attention

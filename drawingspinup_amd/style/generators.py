@@ -2,10 +2,13 @@
 keys (3_style_translator/training/models.py:24-192, 200-356), evaluated with the gfx950
 f32-MFMA convolution kernels.
 
-Inference only (the reference's test_stage1.py / test_stage2.py path): eval-mode BatchNorm is
-folded into the convolution epilogue together with the activation; the resnet blocks' leading
-ReLU is applied as the input is read; the residual add is fused.  Calling forward() in
-train() mode raises — training is outside this path.
+eval() (the reference's test_stage1.py / test_stage2.py path): BatchNorm is folded into the
+convolution epilogue together with the activation; the resnet blocks' leading ReLU is applied
+as the input is read; the residual add is fused.  No autograd graph is built.
+
+train() (train_stage1.py / train_stage2.py): the same module tree evaluated
+op by op through style/functions.py — batch-statistics BatchNorm with running-stat updates,
+every forward and backward a libdsu_hip kernel under torch.autograd.
 """
 import math
 
@@ -14,6 +17,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from . import functions as Fn
 
 
 def deform_conv2d(input, offset, weight, bias=None, stride=(1, 1), padding=(0, 0),
@@ -196,11 +200,28 @@ class _GeneratorBase(nn.Module):
                           residual, in_relu)
 
     def _check(self, x):
-        if self.training:
-            raise RuntimeError("the gfx950 generators are inference-only: call .eval() "
-                               "(per-character training is not part of this path)")
         if not x.is_cuda:
             raise RuntimeError("gfx950 generators need a device tensor (no CPU fallback)")
+
+    # ---- training-mode building blocks (batch statistics; one kernel per op)
+    #: how many times the running statistics take each batch.  The reference evaluates the
+    #: generator twice per iteration on the same batch with unchanged weights (discriminator
+    #: step, then generator step: trainers.py:88,102); a trainer that shares one forward between
+    #: the two steps sets this to 2 so that the BatchNorm buffers end up identical.
+    stat_updates = 1
+
+    def _tconv(self, x, conv, plan=None, act=None):
+        if plan is not None:
+            return Fn.conv(x, conv.weight, None, 1, 1, act, plan)
+        return Fn.conv(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], act)
+
+    def _tbn(self, x, bn, act=None):
+        return Fn.batch_norm_train(x, bn, act, self.stat_updates)
+
+    def _tfinal(self, output, plan=None):
+        if isinstance(self.conv_12, nn.Sequential):
+            return self._tconv(output, self.conv_12[0], act="tanh")
+        return self._tconv(output, self.conv_12)
 
 
 class GeneratorJ(_GeneratorBase):
@@ -210,6 +231,8 @@ class GeneratorJ(_GeneratorBase):
     def forward(self, x):
         self._check(x)
         x = x.float().contiguous()
+        if self.training:
+            return self._forward_train(x)
         c0, c1, c2 = self.conv0, self.conv1, self.conv2
         output_0 = self._conv(x, c0.conv, c0.normalization, "leaky_relu")
         output_1 = self._conv(output_0, c1.conv, c1.normalization, "leaky_relu")
@@ -234,6 +257,28 @@ class GeneratorJ(_GeneratorBase):
         x = F.interpolate(x, scale_factor=2, mode="nearest")
         return self._conv(x, seq[1], seq[2], _act_name(seq[3]))
 
+    def _forward_train(self, x):
+        """models.py:113-129 with train-mode BatchNorm."""
+        assert self.norm_layer is not None, "training path expects norm_layer='batch_norm'"
+        c0, c1, c2 = self.conv0, self.conv1, self.conv2
+        output_0 = self._tbn(self._tconv(x, c0.conv), c0.normalization, "leaky_relu")
+        output_1 = self._tbn(self._tconv(output_0, c1.conv), c1.normalization, "leaky_relu")
+        output_2 = self._tbn(self._tconv(output_1, c2.conv), c2.normalization, "leaky_relu")
+        output = output_2
+        for layer in self.resnets:
+            tmp = self._tconv(Fn.activation(output, "relu"), layer.conv_0)
+            tmp = self._tbn(tmp, layer.normalization, "relu")
+            output = self._tconv(tmp, layer.conv_1) + output
+        for seq, skip in ((self.upconv2, output_2), (self.upconv1, output_1)):
+            tmp = Fn.upsample2(torch.cat((output, skip), 1))
+            output = self._tbn(self._tconv(tmp, seq[1]), seq[2], _act_name(seq[3]))
+        output = self._tconv(torch.cat((output, output_0, x), 1), self.conv_11[0], act="relu")
+        if self.append_smoothers:
+            a = self.conv_11_a           # conv -> ReLU -> BN -> conv -> ReLU (models.py:98-104)
+            tmp = self._tbn(self._tconv(output, a[0], act="relu"), a[2])
+            output = self._tconv(tmp, a[3], act="relu")
+        return self._tfinal(output)
+
     def _final(self, output):
         if isinstance(self.conv_12, nn.Sequential):
             return self._conv(output, self.conv_12[0], act="tanh")
@@ -250,6 +295,36 @@ class GeneratorJ_RIC(_GeneratorBase):
         self.coords_0 = self.coords_1 = self.coords_2 = None
         self.current_x_shape = None
 
+    def _forward_train(self, x):
+        """models.py:293-356 with train-mode BatchNorm.  The offset maps depend on the
+        resolution only, so each has one cached DeformPlan (sampling table + its transpose)."""
+        assert self.norm_layer is not None, "training path expects norm_layer='batch_norm'"
+        p0, p1, p2 = (ops.deform_plan(c[0]) for c in (self.coords_0, self.coords_1, self.coords_2))
+        c0, c1, c2 = self.conv0, self.conv1, self.conv2
+        output_0 = self._tbn(self._tconv(x, c0.conv, p0), c0.normalization, "leaky_relu")
+        tmp = self._tconv(Fn.maxpool2(output_0), c1.conv, p1)
+        output_1 = self._tbn(tmp, c1.normalization, "leaky_relu")
+        tmp = self._tconv(Fn.maxpool2(output_1), c2.conv, p2)
+        output_2 = self._tbn(tmp, c2.normalization, "leaky_relu")
+        output = output_2
+        for layer in self.resnets:
+            tmp = self._tconv(Fn.activation(output, "relu"), layer.conv_0, p2)
+            tmp = self._tbn(tmp, layer.normalization, "relu")
+            output = self._tconv(tmp, layer.conv_1, p2) + output
+        tmp = Fn.upsample2(torch.cat((output, output_2), 1))
+        output = self._tbn(self._tconv(tmp, self.upconv2[1], p1), self.upconv2[2], "relu")
+        tmp = Fn.upsample2(torch.cat((output, output_1), 1))
+        output = self._tbn(self._tconv(tmp, self.upconv1[1], p0), self.upconv1[2], "relu")
+        output = self._tconv(torch.cat((output, output_0, x), 1), self.conv_11[0], p0, "relu")
+        if self.append_smoothers:
+            a = self.conv_11_a
+            # models.py:347-352: conv_11_a[0..2] run (their BatchNorm buffers move) but the
+            # second convolution reads `output`, so they receive no gradient.
+            with torch.no_grad():
+                self._tbn(self._tconv(output, a[0], p0, "relu"), a[2])
+            output = self._tconv(output, a[3], p0, "relu")
+        return self._tfinal(output)
+
     def forward(self, x):
         self._check(x)
         x = x.float().contiguous()
@@ -259,6 +334,8 @@ class GeneratorJ_RIC(_GeneratorBase):
             self.coords_0 = generate_coordinates(B, H, W, x.device)
             self.coords_1 = generate_coordinates(B, int(H / 2), int(W / 2), x.device)
             self.coords_2 = generate_coordinates(B, int(H / 4), int(W / 4), x.device)
+        if self.training:
+            return self._forward_train(x)
         k0, k1, k2 = self.coords_0[0], self.coords_1[0], self.coords_2[0]
         c0, c1, c2 = self.conv0, self.conv1, self.conv2
         output_0 = self._conv(x, c0.conv, c0.normalization, "leaky_relu", coords=k0)

@@ -329,12 +329,98 @@ int dsu_deform_conv3x3_fwd(const float* input, const float* offset, int64_t offs
                            const float* ep_shift, int32_t act, const float* residual, float* out,
                            void* stream);
 
-/* nn.Conv2d forward, NCHW f32, square kernel k in {1,3,7}, stride in {1,2}, zero padding,
- * same fused epilogue (GeneratorJ, models.py:41-129).  bias may be NULL. */
+/* nn.Conv2d forward, NCHW f32, square kernel k in {1,3,7} with stride in {1,2} (GeneratorJ,
+ * models.py:41-129; PerceptualVGG19 features 0/2/5, models.py:536-544) or k = 4 with stride in
+ * {1,2} (DiscriminatorN_IN, models.py:441-462), zero padding, same fused epilogue.  bias may be
+ * NULL. */
 int dsu_conv2d_fwd(const float* input, const float* weight, const float* bias, int32_t B,
                    int32_t C, int32_t H, int32_t W, int32_t O, int32_t k, int32_t stride,
                    int32_t pad, int32_t in_relu, const float* ep_scale, const float* ep_shift,
                    int32_t act, const float* residual, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------
+ * Style translator, per-character TRAINING (3_style_translator/training/trainers.py:140-192:
+ * autograd through GeneratorJ / GeneratorJ_RIC, DiscriminatorN_IN and PerceptualVGG19 on
+ * batch_size x C x 32 x 32 patches, configs/config_stage{1,2}.yaml).  SURVEY.md 8f-1.
+ * The data gradient of nn.Conv2d is dsu_conv2d_fwd on dout with flipped/transposed weights.
+ * ---------------------------------------------------------------------------------- */
+
+/* Fixed sampling table of the 3x3 deformable convolution for an (18,H,W) offset map shared by
+ * the batch (models.py:297-300: coords_k depend on the resolution only): 9 records per pixel
+ * with the four clamped corner offsets and bilinear weights, computed with the forward
+ * kernel's own arithmetic.  table: caller-owned device buffer of dsu_deform_tap_table_bytes
+ * (0 = invalid arguments). */
+int64_t dsu_deform_tap_table_bytes(int32_t H, int32_t W);
+int dsu_deform_tap_table(const float* offset, int32_t H, int32_t W, void* table, void* stream);
+
+/* Weight gradient of nn.Conv2d (tap_table == NULL; k in {1,3,4,7}, any stride/pad) or of
+ * torchvision.ops.deform_conv2d with the fixed offsets of tap_table (k = 3, stride 1, pad 1):
+ *   dweight[o][c][ty][tx] (= or +=, accumulate) sum_{b,pixel} dout[b][o][pixel] * col[b][c][tap][pixel]
+ * input (B,C,H,W), dout (B,O,OH,OW), O <= 128.  workspace: per-slice partial sums, size from
+ * dsu_conv2d_wgrad_workspace_bytes (same B,C,O,k and the OUTPUT size OH,OW); summed in a
+ * fixed order, so results are run-to-run identical. */
+int64_t dsu_conv2d_wgrad_workspace_bytes(int32_t deform, int32_t B, int32_t C, int32_t O,
+                                         int32_t OH, int32_t OW, int32_t k);
+int dsu_conv2d_wgrad(const float* input, const float* dout, const void* tap_table, int32_t B,
+                     int32_t C, int32_t H, int32_t W, int32_t O, int32_t k, int32_t stride,
+                     int32_t pad, float* workspace, float* dweight, int32_t accumulate,
+                     void* stream);
+
+/* Input gradient of the fixed-offset deformable convolution, second half: dcol (planes = B*C,
+ * 9, npix) = W^T dout (a 1x1 dsu_conv2d_fwd with the (C*9, O) transposed weight) is pulled back
+ * through the transposed sampling operator given as CSR over INPUT pixels: row q lists
+ * src = tap * npix + output_pixel and the bilinear weight of every sample that read q.
+ *   dx[plane][q] = sum_e wgt[e] * dcol[plane][src[e]],  e in [rowptr[q], rowptr[q+1]) */
+int dsu_deform_conv3x3_dgrad_gather(const float* dcol, const int32_t* rowptr, const int32_t* src,
+                                    const float* wgt, int64_t planes, int32_t npix, float* dx,
+                                    void* stream);
+
+/* nn.BatchNorm2d in training mode (instance = 0: statistics over (batch, hw) per channel;
+ * running_mean/var, when given, take `stat_updates` momentum updates with the unbiased batch
+ * variance) or nn.InstanceNorm2d without affine/running stats (instance = 1, DiscriminatorN_IN
+ * models.py:436-439), followed by act (0 none, 1 ReLU, 2 LeakyReLU(0.2)).  x,y (B,C,HW) f32;
+ * save_mean/save_invstd: one value per channel (instance = 0) or per (image, channel). */
+typedef struct dsu_norm_cfg {
+  int32_t batch, channels, hw;
+  int32_t instance;
+  int32_t act;
+  int32_t stat_updates;
+  float eps;
+  float momentum;
+} dsu_norm_cfg;
+int dsu_norm_train_fwd(const dsu_norm_cfg* cfg, const float* x, const float* gamma,
+                       const float* beta, float* running_mean, float* running_var, float* y,
+                       float* save_mean, float* save_invstd, void* stream);
+/* Backward of the above through the activation (derivative taken from the output y):
+ * dx, and for instance = 0 dgamma/dbeta (C) when non-NULL. */
+int dsu_norm_train_bwd(const dsu_norm_cfg* cfg, const float* x, const float* y, const float* dy,
+                       const float* gamma, const float* save_mean, const float* save_invstd,
+                       float* dx, float* dgamma, float* dbeta, void* stream);
+
+/* out[c] = sum over (b, hw) of x[b][c][hw]: the bias gradient of a convolution. */
+int dsu_channel_sum(const float* x, int32_t B, int32_t C, int32_t HW, float* out, void* stream);
+
+/* Activations (act: 1 ReLU, 2 LeakyReLU(0.2), 3 tanh) and their backward from the OUTPUT y. */
+int dsu_act_fwd(const float* x, float* y, int64_t n, int32_t act, void* stream);
+int dsu_act_bwd(const float* dy, const float* y, float* dx, int64_t n, int32_t act, void* stream);
+
+/* nn.MaxPool2d(2,2) (GeneratorJ_RIC.maxpool models.py:214, VGG19 features[4]) on `planes`
+ * images of H x W (H, W even); backward routes to the first maximum of each window. */
+int dsu_maxpool2_fwd(const float* x, float* y, int64_t planes, int32_t H, int32_t W, void* stream);
+int dsu_maxpool2_bwd(const float* x, const float* dy, float* dx, int64_t planes, int32_t H,
+                     int32_t W, void* stream);
+
+/* nn.Upsample(scale_factor=2) nearest (UpsamplingLayer, models.py:8-14): H x W -> 2H x 2W. */
+int dsu_upsample2_fwd(const float* x, float* y, int64_t planes, int32_t H, int32_t W,
+                      void* stream);
+int dsu_upsample2_bwd(const float* dy, float* dx, int64_t planes, int32_t H, int32_t W,
+                      void* stream);
+
+/* nn.L1Loss (kind 0) / nn.MSELoss (kind 1) terms of trainers.py:97-135 before the division by
+ * n: partial256[256] partial sums of |x - t| or (x - t)^2 (t = target[i], or target_const when
+ * target is NULL); grad (may be NULL) = d/dx of (grad_scale * sum). */
+int dsu_pair_loss(const float* x, const float* target, float target_const, int64_t n,
+                  int32_t kind, float grad_scale, float* grad, float* partial256, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Multi-view diffusion UNet (2_charactor_reconstructor/mvdiffusion/models).
