@@ -279,7 +279,14 @@ template <int MODE, int KS, int STRIDE, int KC>
 int launch_conv(const ConvArgs& a, hipStream_t s) {
   const int npix = a.OH * a.OW;
   const int gx = (npix + BM - 1) / BM;
-  if (a.O > 64) {
+  // Small images (the 8x8 / 16x16 levels of the 32x32 training patches): with 128-channel
+  // tiles the launch has fewer workgroups than the chip has CUs.  32-channel tiles give 4x
+  // the workgroups; each repeats the im2col staging, but on CUs that would otherwise idle.
+  // Every output element accumulates in the same order whatever the tile width.
+  if (a.O > 32 && (int64_t)gx * ((a.O + 127) / 128) * a.B < 256) {
+    dim3 grid(gx, (a.O + 31) / 32, a.B);
+    conv_igemm_kernel<MODE, KS, STRIDE, KC, 32><<<grid, 256, 0, s>>>(a);
+  } else if (a.O > 64) {
     dim3 grid(gx, (a.O + 127) / 128, a.B);
     conv_igemm_kernel<MODE, KS, STRIDE, KC, 128><<<grid, 256, 0, s>>>(a);
   } else if (a.O > 32) {

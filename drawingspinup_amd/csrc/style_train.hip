@@ -122,6 +122,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   float rv[NRAW];
   float rwt[MODE == 1 ? 36 : 1];     // MODE 1: bilinear weights (4 per tap, 9 taps)
   float rd[ND];
+  // All staging loads are issued unconditionally from clamped (always mapped) addresses and
+  // invalid values are zeroed when they are written to LDS: a `cond ? load : 0` per element
+  // compiled to one exec-mask branch region per load (330 of them in the first version).
+  uint32_t okm = 0;                  // MODE 0: validity of the 32 staged columns
+  uint32_t cvm = 0;                  // MODE 1: validity of the 4 staged channels
+  bool dvalid = false;
 
   auto stage_load = [&](int q) {
     const int64_t g = (int64_t)q * WG_PB + p;
@@ -130,10 +136,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     const int pix = valid ? (int)(g - (int64_t)b * npix) : 0;
     // ---- dout[b][o][pix], o in [half*ND, half*ND + ND)
     const float* dp = a.dout + ((size_t)b * a.O) * npix + pix;
+    dvalid = valid;
 #pragma unroll
     for (int j = 0; j < ND; ++j) {
       const int o = half * ND + j;
-      rd[j] = (valid && o < a.O) ? dp[(size_t)o * npix] : 0.0f;
+      rd[j] = dp[(size_t)min(o, a.O - 1) * npix];
     }
     if constexpr (MODE == 1) {
       const TapRec* tr = a.taps + (size_t)pix * 9;
@@ -146,35 +153,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         rwt[4 * t + 0] = ww.x; rwt[4 * t + 1] = ww.y; rwt[4 * t + 2] = ww.z; rwt[4 * t + 3] = ww.w;
       }
       // half 0: tile channels 0..3, half 1: tile channels 4..6
+      cvm = 0;
 #pragma unroll
       for (int cl = 0; cl < 4; ++cl) {
         const int c = blockIdx.x * 7 + half * 4 + cl;
-        const bool cv = valid && c < a.C && (half * 4 + cl) < 7;
+        const bool cv = valid & (c < a.C) & ((half * 4 + cl) < 7);
+        cvm |= cv ? (1u << cl) : 0u;
         const float* pl = a.in + ((size_t)b * a.C + (cv ? c : 0)) * plane;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
 #pragma unroll
-          for (int k = 0; k < 4; ++k)
-            rv[(cl * 9 + t) * 4 + k] = cv ? pl[ti[4 * t + k]] : 0.0f;
+          for (int k = 0; k < 4; ++k) rv[(cl * 9 + t) * 4 + k] = pl[ti[4 * t + k]];
         }
       }
     } else {
       const int oy = pix / a.OW, ox = pix - oy * a.OW;
       const int iy0 = oy * a.stride - a.pad, ix0 = ox * a.stride - a.pad;
       const float* ib = a.in + (size_t)b * a.C * plane;
+      okm = 0;
 #pragma unroll
       for (int j = 0; j < 32; ++j) {
         const uint32_t u = pk[j];
-        const int c = (int)(u >> 8), ty = (int)((u >> 4) & 15u), tx = (int)(u & 15u);
-        const int iy = iy0 + ty, ix = ix0 + tx;
-        const bool ok = valid && u != 0xFFFFFFFFu && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
-        rv[j] = ok ? ib[(size_t)c * plane + (size_t)iy * a.W + ix] : 0.0f;
+        const uint32_t c = u >> 8;
+        const int iy = iy0 + (int)((u >> 4) & 15u), ix = ix0 + (int)(u & 15u);
+        // branch-free validity (a short-circuit && chain became nested exec-mask branches)
+        const bool ok = valid & (u != 0xFFFFFFFFu) & ((uint32_t)iy < (uint32_t)a.H) &
+                        ((uint32_t)ix < (uint32_t)a.W);
+        okm |= ok ? (1u << j) : 0u;
+        // 32-bit element offsets: the host rejects tensors of 2^31 elements or more
+        const uint32_t off = c * (uint32_t)plane + (uint32_t)iy * (uint32_t)a.W + (uint32_t)ix;
+        rv[j] = ib[ok ? off : 0u];
       }
     }
   };
   auto stage_store = [&]() {
 #pragma unroll
-    for (int j = 0; j < ND; ++j) sD[p * SD + half * ND + j] = rd[j];
+    for (int j = 0; j < ND; ++j)
+      sD[p * SD + half * ND + j] = (dvalid & (half * ND + j < a.O)) ? rd[j] : 0.0f;
     if constexpr (MODE == 1) {
 #pragma unroll
       for (int cl = 0; cl < 4; ++cl) {
@@ -186,14 +201,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
                             rwt[4 * t + 1] * rv[(cl * 9 + t) * 4 + 1] +
                             rwt[4 * t + 2] * rv[(cl * 9 + t) * 4 + 2] +
                             rwt[4 * t + 3] * rv[(cl * 9 + t) * 4 + 3];
-            sC[p * SC + (half * 4 + cl) * 9 + t] = s;
+            sC[p * SC + (half * 4 + cl) * 9 + t] = ((cvm >> cl) & 1u) ? s : 0.0f;
           }
         }
       }
       if (half == 1) sC[p * SC + 63] = 0.0f;   // padding column
     } else {
 #pragma unroll
-      for (int j = 0; j < 32; ++j) sC[p * SC + half * 32 + j] = rv[j];
+      for (int j = 0; j < 32; ++j) sC[p * SC + half * 32 + j] = ((okm >> j) & 1u) ? rv[j] : 0.0f;
     }
   };
 
@@ -256,19 +271,43 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, int slice
 //   dcol (B, C*9, npix) = W^T dout;  dX[b][c][q] = sum_e w[e] * dcol[b][c*9 + t_e][p_e]
 //   with src[e] = t_e * npix + p_e, rows of the CSR = input pixels q.
 // ------------------------------------------------------------------------------------------
-__global__ void deform_gather_kernel(const float* __restrict__ dcol,
-                                     const int* __restrict__ rowptr, const int* __restrict__ src,
-                                     const float* __restrict__ wgt, int64_t planes, int npix,
-                                     float* __restrict__ dx) {
+constexpr int GATHER_PL = 8;   // planes per thread: the (src, weight) pair of an entry is read once for 8 gathers
+
+__global__ __launch_bounds__(256) void deform_gather_kernel(
+    const float* __restrict__ dcol, const int* __restrict__ rowptr, const int* __restrict__ src,
+    const float* __restrict__ wgt, int64_t planes, int npix, float* __restrict__ dx) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= planes * npix) return;
-  const int64_t bc = idx / npix;
-  const int q = (int)(idx - bc * npix);
-  const float* base = dcol + (size_t)bc * 9 * npix;
+  const int64_t groups = (planes + GATHER_PL - 1) / GATHER_PL;
+  if (idx >= groups * npix) return;
+  const int64_t pg = idx / npix;
+  const int q = (int)(idx - pg * npix);
+  const int64_t p0 = pg * GATHER_PL;
+  const size_t pstride = (size_t)9 * npix;
+  const float* base = dcol + (size_t)p0 * pstride;
+  const int np = planes - p0 < GATHER_PL ? (int)(planes - p0) : GATHER_PL;
   const int e0 = rowptr[q], e1 = rowptr[q + 1];
-  float s = 0.0f;
-  for (int e = e0; e < e1; ++e) s += wgt[e] * base[src[e]];
-  dx[idx] = s;
+  float s[GATHER_PL];
+#pragma unroll
+  for (int j = 0; j < GATHER_PL; ++j) s[j] = 0.0f;
+  if (np == GATHER_PL) {
+    for (int e = e0; e < e1; ++e) {
+      const float w = wgt[e];
+      const float* b = base + src[e];
+#pragma unroll
+      for (int j = 0; j < GATHER_PL; ++j) s[j] += w * b[(size_t)j * pstride];
+    }
+  } else {
+    for (int e = e0; e < e1; ++e) {
+      const float w = wgt[e];
+      const float* b = base + src[e];
+#pragma unroll
+      for (int j = 0; j < GATHER_PL; ++j)
+        if (j < np) s[j] += w * b[(size_t)j * pstride];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < GATHER_PL; ++j)
+    if (j < np) dx[(size_t)(p0 + j) * npix + q] = s[j];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -316,6 +355,26 @@ struct NormArgs {
   int act;                // 0 none, 1 ReLU, 2 LeakyReLU(0.2)
 };
 
+// Thread-strided walk over a group's n = n_outer * inner elements without a division per
+// element: i = threadIdx.x, += 256; (k, r) = (i / inner, i % inner) kept incrementally.
+struct GroupWalk {
+  int64_t off;   // k * outer_stride + r
+  int r;
+  __device__ __forceinline__ GroupWalk(int inner, int64_t outer_stride) {
+    const int k = (int)threadIdx.x / inner;
+    r = (int)threadIdx.x - k * inner;
+    off = (int64_t)k * outer_stride + r;
+  }
+  __device__ __forceinline__ void next(int inner, int64_t outer_stride) {
+    r += 256;
+    off += 256;
+    while (r >= inner) {
+      r -= inner;
+      off += outer_stride - inner;
+    }
+  }
+};
+
 __global__ __launch_bounds__(256) void norm_fwd_kernel(NormArgs a) {
   __shared__ float red[4];
   const int g = blockIdx.x;
@@ -323,25 +382,29 @@ __global__ __launch_bounds__(256) void norm_fwd_kernel(NormArgs a) {
   float* yg = a.out + (size_t)g * a.group_stride;
   const int64_t n = (int64_t)a.n_outer * a.inner;
   float s = 0.0f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const int64_t k = i / a.inner, r = i - k * a.inner;
-    s += xg[k * a.outer_stride + r];
+  {
+    GroupWalk w(a.inner, a.outer_stride);
+    for (int64_t i = threadIdx.x; i < n; i += 256, w.next(a.inner, a.outer_stride)) s += xg[w.off];
   }
   const float mean = block_sum(s, red) / (float)n;
   float v = 0.0f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const int64_t k = i / a.inner, r = i - k * a.inner;
-    const float d = xg[k * a.outer_stride + r] - mean;
-    v += d * d;
+  {
+    GroupWalk w(a.inner, a.outer_stride);
+    for (int64_t i = threadIdx.x; i < n; i += 256, w.next(a.inner, a.outer_stride)) {
+      const float d = xg[w.off] - mean;
+      v += d * d;
+    }
   }
   const float var = block_sum(v, red) / (float)n;
   const float invstd = 1.0f / sqrtf(var + a.eps);
   const int c = g % a.channels;
   const float ga = a.gamma ? a.gamma[c] : 1.0f, be = a.beta ? a.beta[c] : 0.0f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const int64_t k = i / a.inner, r = i - k * a.inner;
-    const float xh = (xg[k * a.outer_stride + r] - mean) * invstd;
-    yg[k * a.outer_stride + r] = apply_act(xh * ga + be, a.act);
+  {
+    GroupWalk w(a.inner, a.outer_stride);
+    for (int64_t i = threadIdx.x; i < n; i += 256, w.next(a.inner, a.outer_stride)) {
+      const float xh = (xg[w.off] - mean) * invstd;
+      yg[w.off] = apply_act(xh * ga + be, a.act);
+    }
   }
   if (threadIdx.x == 0) {
     a.mean[g] = mean;
@@ -380,12 +443,14 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(NormArgs a) {
   const int64_t n = (int64_t)a.n_outer * a.inner;
   const float mean = a.mean[g], invstd = a.invstd[g];
   float s1 = 0.0f, s2 = 0.0f;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const int64_t k = i / a.inner, r = i - k * a.inner;
-    const int64_t off = k * a.outer_stride + r;
-    const float gr = dg[off] * act_grad_from_output(yg[off], a.act);
-    s1 += gr;
-    s2 += gr * ((xg[off] - mean) * invstd);
+  {
+    GroupWalk w(a.inner, a.outer_stride);
+    for (int64_t i = threadIdx.x; i < n; i += 256, w.next(a.inner, a.outer_stride)) {
+      const int64_t off = w.off;
+      const float gr = dg[off] * act_grad_from_output(yg[off], a.act);
+      s1 += gr;
+      s2 += gr * ((xg[off] - mean) * invstd);
+    }
   }
   s1 = block_sum(s1, red);
   s2 = block_sum(s2, red);
@@ -393,12 +458,14 @@ __global__ __launch_bounds__(256) void norm_bwd_kernel(NormArgs a) {
   const float ga = a.gamma ? a.gamma[c] : 1.0f;
   const float m1 = s1 / (float)n, m2 = s2 / (float)n;
   const float k0 = ga * invstd;
-  for (int64_t i = threadIdx.x; i < n; i += 256) {
-    const int64_t k = i / a.inner, r = i - k * a.inner;
-    const int64_t off = k * a.outer_stride + r;
-    const float gr = dg[off] * act_grad_from_output(yg[off], a.act);
-    const float xh = (xg[off] - mean) * invstd;
-    og[off] = k0 * (gr - m1 - xh * m2);
+  {
+    GroupWalk w(a.inner, a.outer_stride);
+    for (int64_t i = threadIdx.x; i < n; i += 256, w.next(a.inner, a.outer_stride)) {
+      const int64_t off = w.off;
+      const float gr = dg[off] * act_grad_from_output(yg[off], a.act);
+      const float xh = (xg[off] - mean) * invstd;
+      og[off] = k0 * (gr - m1 - xh * m2);
+    }
   }
   if (threadIdx.x == 0) {
     if (a.dgamma) a.dgamma[g] = s2;
@@ -645,7 +712,8 @@ int dsu_deform_conv3x3_dgrad_gather(const float* dcol, const int32_t* rowptr, co
                                     const float* wgt, int64_t planes, int32_t npix, float* dx,
                                     void* stream) {
   if (!dcol || !rowptr || !src || !wgt || !dx || planes <= 0 || npix <= 0) return DSU_EINVAL;
-  deform_gather_kernel<<<dsu_blocks_for(planes * npix, 256), 256, 0, (hipStream_t)stream>>>(
+  const int64_t groups = (planes + GATHER_PL - 1) / GATHER_PL;
+  deform_gather_kernel<<<dsu_blocks_for(groups * npix, 256), 256, 0, (hipStream_t)stream>>>(
       dcol, rowptr, src, wgt, planes, npix, dx);
   DSU_CHECK_LAUNCH();
   return DSU_OK;

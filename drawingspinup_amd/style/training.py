@@ -290,6 +290,20 @@ class DatasetPatches_M:
         self.device = torch.device(device)
         self.load_image()
 
+    @classmethod
+    def from_images(cls, pre_color, post_color, mask, pre_pos=None, patch_size=32, use_mask=False,
+                    use_pos=False, device="cuda"):
+        """The same dataset from in-memory PIL images (no PNG round trip through
+        blender_render/rest_pose): pre_color RGBA render, post_color RGB(A) target already on
+        white, mask 'L'."""
+        self = object.__new__(cls)
+        self.data_root = self.pre_dir = self.post_dir = self.post_name = None
+        self.patch_size = patch_size
+        self.use_mask, self.use_pos, self.use_edge = use_mask, use_pos, False
+        self.device = torch.device(device)
+        self.set_images(pre_color, post_color, mask, pre_pos)
+        return self
+
     def load_image(self, fileName="0001.png"):
         pre_color = Image.open(os.path.join(self.data_root, self.pre_dir, fileName))
         mask = pre_color.split()[-1]
