@@ -213,6 +213,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   };
 
   const int nblk = wave & 1;
+  // accumulator i of this wave covers output-channel block mrow[i]; always a valid block, so the
+  // MFMAs below are unconditional.  (A `if (m < MB)` around them made the accumulators flow
+  // through phi copies: ~100 v_accvgpr_mov + an s_nop 15 per MFMA in the first version.)  With
+  // one block (MB == 1) waves 2 and 3 repeat block 0 and do not write.
+  int mrow[NACC];
+#pragma unroll
+  for (int i = 0; i < NACC; ++i) mrow[i] = MB == 1 ? 0 : (wave >> 1) + 2 * i;
+  const bool writer = MB > 1 || (wave >> 1) == 0;
   if (q_begin < q_end) {
     stage_load(q_begin);
     stage_store();
@@ -225,11 +233,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
         const float bv = sC[pkx * SC + nblk * 32 + l31];
 #pragma unroll
         for (int i = 0; i < NACC; ++i) {
-          const int m = (wave >> 1) + 2 * i;
-          if (m < MB) {
-            const float av = sD[pkx * SD + m * 32 + l31];
-            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
-          }
+          const float av = sD[pkx * SD + mrow[i] * 32 + l31];
+          acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[i], 0, 0, 0);
         }
       }
       __syncthreads();
@@ -241,17 +246,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   // ---- epilogue: accumulator row = output channel, column (lane & 31) = n
   const int nl = nblk * 32 + l31;
   const int n = n0 + nl;
-  if (nl < TNR && n < a.ntot) {
+  if (writer && nl < TNR && n < a.ntot) {
 #pragma unroll
     for (int i = 0; i < NACC; ++i) {
-      const int m = (wave >> 1) + 2 * i;
-      if (m < MB) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int o = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-          if (o < a.O)
-            a.partial[((size_t)blockIdx.y * a.O + o) * a.ntot + n] = acc[i][r];
-        }
+      for (int r = 0; r < 16; ++r) {
+        const int o = mrow[i] * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+        if (o < a.O)
+          a.partial[((size_t)blockIdx.y * a.O + o) * a.ntot + n] = acc[i][r];
       }
     }
   }
@@ -626,8 +628,10 @@ int launch_wgrad(const WgradArgs& a, int slices, hipStream_t s) {
 }
 
 int wgrad_slices(int ntiles, int nchunks) {
-  // enough workgroups to cover the 256 CUs about twice, at least 2 chunks per slice
-  int s = (512 + ntiles - 1) / ntiles;
+  // the kernel runs one workgroup per CU (99 KB of LDS): aim for at most two full rounds over
+  // the 256 CUs (rounding the slice count UP gave 518-532 workgroups = a third, nearly empty
+  // round on the two largest layers), at least 2 chunks per slice
+  int s = 512 / ntiles;
   if (s > (nchunks + 1) / 2) s = (nchunks + 1) / 2;
   if (s < 1) s = 1;
   if (s > 64) s = 64;
