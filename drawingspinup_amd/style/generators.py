@@ -14,7 +14,6 @@ import math
 
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from .. import ops
 from . import functions as Fn
@@ -254,8 +253,7 @@ class GeneratorJ(_GeneratorBase):
         return self._final(output)
 
     def _up(self, seq, x):
-        x = F.interpolate(x, scale_factor=2, mode="nearest")
-        return self._conv(x, seq[1], seq[2], _act_name(seq[3]))
+        return self._conv(ops.upsample2_fwd(x), seq[1], seq[2], _act_name(seq[3]))
 
     def _forward_train(self, x):
         """models.py:113-129 with train-mode BatchNorm."""
@@ -348,9 +346,9 @@ class GeneratorJ_RIC(_GeneratorBase):
             tmp = self._conv(output, layer.conv_0, layer.normalization, "relu", in_relu=True,
                              coords=k2)
             output = self._conv(tmp, layer.conv_1, residual=output, coords=k2)
-        tmp = F.interpolate(torch.cat((output, output_2), 1), scale_factor=2, mode="nearest")
+        tmp = ops.upsample2_fwd(torch.cat((output, output_2), 1))
         output = self._conv(tmp, self.upconv2[1], self.upconv2[2], "relu", coords=k1)
-        tmp = F.interpolate(torch.cat((output, output_1), 1), scale_factor=2, mode="nearest")
+        tmp = ops.upsample2_fwd(torch.cat((output, output_1), 1))
         output = self._conv(tmp, self.upconv1[1], self.upconv1[2], "relu", coords=k0)
         output = self._conv(torch.cat((output, output_0, x), 1), self.conv_11[0], act="relu",
                             coords=k0)

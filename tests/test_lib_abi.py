@@ -57,6 +57,32 @@ def test_argument_validation_without_gpu():
     assert lib.dsu_ric_offsets(0, 4, None, None) == -1
 
 
+def test_style_training_host_side_sizes():
+    """Host-only planning of the training kernels: workspace of the sliced weight gradient and
+    the sampling-table size; argument checks return before any launch."""
+    from drawingspinup_amd import _lib
+    lib = _lib.lib()
+    assert lib.dsu_deform_tap_table_bytes(32, 32) == 32 * 32 * 9 * 32
+    assert lib.dsu_deform_tap_table_bytes(0, 32) == 0
+    # resnet level of the shipped config: 40 x 128 x 8 x 8, 128 -> 128 deformable: 19 column
+    # tiles of 7 channels, 20 chunks of 128 pixels -> 10 slices of 2 chunks
+    per_slice = 128 * 128 * 9 * 4
+    assert lib.dsu_conv2d_wgrad_workspace_bytes(1, 40, 128, 128, 8, 8, 3) == 10 * per_slice
+    # upconv1 (192 -> 128 at 32x32): 28 tiles -> 18 slices = 504 workgroups, two full rounds
+    assert lib.dsu_conv2d_wgrad_workspace_bytes(1, 40, 192, 128, 32, 32, 3) == \
+        18 * 128 * 192 * 9 * 4
+    # plain 7x7: flattened (channel, tap) columns in tiles of 64
+    n = lib.dsu_conv2d_wgrad_workspace_bytes(0, 40, 166, 64, 32, 32, 7)
+    assert n > 0 and n % (64 * 166 * 49 * 4) == 0
+    assert lib.dsu_conv2d_wgrad_workspace_bytes(0, 0, 3, 3, 8, 8, 3) == 0
+    assert lib.dsu_conv2d_wgrad(None, None, None, 1, 1, 8, 8, 1, 3, 1, 1, None, None, 0, None) == -1
+    cfg = _lib.NormCfg(4, 8, 64, 0, 7, 1, 1e-5, 0.1)                     # act 7: invalid
+    assert lib.dsu_norm_train_fwd(ctypes.byref(cfg), None, None, None, None, None, None, None,
+                                  None, None) == -1
+    assert lib.dsu_maxpool2_fwd(None, None, 1, 8, 8, None) == -1
+    assert lib.dsu_pair_loss(None, None, 0.0, 4, 0, 1.0, None, None, None) == -1
+
+
 def test_no_cpu_fallback():
     from drawingspinup_amd import ops, _lib
     cfg = ops.HashGridConfig()
