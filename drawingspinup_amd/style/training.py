@@ -31,6 +31,11 @@ from . import functions as Fn
 from .generators import GeneratorJ, GeneratorJ_RIC
 
 
+def _require_device(x, what):
+    if not x.is_cuda:
+        raise RuntimeError(f"gfx950 {what} needs a device tensor (no CPU fallback)")
+
+
 # ------------------------------------------------------------------ losses (torch.nn names)
 class L1Loss(nn.Module):
     def forward(self, x, target):
@@ -90,8 +95,7 @@ class DiscriminatorN_IN(nn.Module):
         return m
 
     def forward(self, x):
-        if not x.is_cuda:
-            raise RuntimeError("gfx950 discriminator needs a device tensor (no CPU fallback)")
+        _require_device(x, "discriminator")
         h = x.float()
         for block in self.net:
             conv = block.conv
@@ -177,8 +181,7 @@ class PerceptualVGG19(nn.Module):
         return None, torch.cat(feats, dim=1)
 
     def forward(self, x):
-        if not x.is_cuda:
-            raise RuntimeError("gfx950 VGG features need a device tensor (no CPU fallback)")
+        _require_device(x, "VGG feature stack")
         return self.run(self.normalize(x.float()))
 
 

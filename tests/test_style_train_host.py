@@ -161,3 +161,147 @@ def test_default_job_is_the_shipped_config():
                                            "weight_decay": 0.00001}
     assert j1["perception_loss"]["weight"] == 6.0
     assert j2["trainer"]["pre_dir"] == "res_stage1_mask_pos"
+
+
+# ------------------------------------------------------------------ graph wiring on the CPU
+# The modules and the Trainer are evaluated with torch stand-ins for the HIP kernels (TEST
+# INFRASTRUCTURE: the product has no such path) so that the wiring — layer order, skip
+# connections, the dead smoother branch, the single shared generator forward with doubled
+# BatchNorm updates, loss composition, frozen discriminator, both Adam steps — is pinned
+# against the reference's own trainer fixture on every CPU run, independently of the kernels.
+import types
+
+import torch.nn.functional as F
+
+from drawingspinup_amd.style import functions as Fn
+from drawingspinup_amd.style import generators as G
+
+_ACT = {None: lambda t: t, "relu": F.relu, "leaky_relu": lambda t: F.leaky_relu(t, 0.2),
+        "tanh": torch.tanh}
+
+
+def _cpu_conv(x, weight, bias=None, stride=1, padding=0, act=None, plan=None):
+    if plan is not None:
+        off = plan.offset[None].expand(x.shape[0], -1, -1, -1)
+        y = sr.deform_conv2d(x, off, weight).to(x.dtype)
+    else:
+        y = F.conv2d(x, weight, bias, stride, padding)
+    return _ACT[act](y)
+
+
+def _cpu_bn(x, bn, act=None, stat_updates=1):
+    y = F.batch_norm(x, None, None, bn.weight, bn.bias, True, bn.momentum, bn.eps)
+    with torch.no_grad():
+        for _ in range(stat_updates):
+            F.batch_norm(x, bn.running_mean, bn.running_var, None, None, True, bn.momentum, bn.eps)
+        bn.num_batches_tracked += stat_updates
+    return _ACT[act](y)
+
+
+def _cpu_loss(f):
+    def loss(x, target):
+        if not torch.is_tensor(target):
+            target = torch.full_like(x, float(target))
+        return f(x, target.detach())
+    return loss
+
+
+@pytest.fixture
+def cpu_kernels(monkeypatch):
+    monkeypatch.setattr(Fn, "conv", _cpu_conv)
+    monkeypatch.setattr(Fn, "batch_norm_train", _cpu_bn)
+    monkeypatch.setattr(Fn, "instance_norm", lambda x, act=None, eps=1e-5:
+                        _ACT[act](F.instance_norm(x, eps=eps)))
+    monkeypatch.setattr(Fn, "activation", lambda x, act: _ACT[act](x))
+    monkeypatch.setattr(Fn, "maxpool2", lambda x: F.max_pool2d(x, 2, 2))
+    monkeypatch.setattr(Fn, "upsample2", lambda x: F.interpolate(x, scale_factor=2))
+    monkeypatch.setattr(Fn, "l1_loss", _cpu_loss(F.l1_loss))
+    monkeypatch.setattr(Fn, "mse_loss", _cpu_loss(F.mse_loss))
+    monkeypatch.setattr(G.ops, "deform_plan", lambda off: types.SimpleNamespace(offset=off))
+    monkeypatch.setattr(G._GeneratorBase, "_check", lambda self, x: None)
+    monkeypatch.setattr(T, "_require_device", lambda x, what: None)
+
+
+G_ARGS = dict(use_bias=False, tanh=True, append_smoothers=True, resnet_blocks=2,
+              filters=[8, 16, 24, 24, 24, 16], input_channels=6)
+OPT = dict(lr=0.0004, betas=[0.9, 0.999], weight_decay=0.00001)
+
+
+def _setup(name):
+    pre = name + "."
+    gen = T.build_model(name, dict(G_ARGS), "cpu")
+    gen.load_state_dict({k[len(pre) + 3:]: torch.from_numpy(GOLD[k]) for k in GOLD.files
+                         if k.startswith(pre + "g0.")})
+    disc = T.build_model("DiscriminatorN_IN", dict(num_filters=4, n_layers=2), "cpu")
+    disc.load_state_dict({k[len(pre) + 3:]: torch.from_numpy(GOLD[k]) for k in GOLD.files
+                          if k.startswith(pre + "d0.")})
+    perc = T.build_model("PerceptualVGG19", dict(feature_layers=[0, 3, 5],
+                                                 use_normalization=False), "cpu")
+    sd = perc.state_dict()
+    for f in (0, 2, 5):
+        sd[f"model.features.{f}.weight"] = torch.from_numpy(GOLD[f"vgg.features.{f}.weight"])
+        sd[f"model.features.{f}.bias"] = torch.from_numpy(GOLD[f"vgg.features.{f}.bias"])
+    perc.load_state_dict(sd)
+    cfg = dict(batch_size=4, reconstruction_criterion="L1Loss", adversarial_criterion="MSELoss",
+               reconstruction_weight=4.0, adversarial_weight=0.5, log_interval=2,
+               use_image_loss=True, pre_dir="color", patch_size=32)
+    tr = T.Trainer(None, cfg, T.build_optimizer("Adam", disc, OPT),
+                   T.build_optimizer("Adam", gen, OPT), None, perc, 6.0, True, True, False, "cpu",
+                   dataset=object())
+    tr.use_adversarial_loss = True
+    return gen, disc, tr
+
+
+@pytest.mark.parametrize("name", ["GeneratorJ_RIC", "GeneratorJ"])
+def test_trainer_wiring_matches_reference_on_cpu(cpu_kernels, name):
+    pre = name + "."
+    gen, disc, tr = _setup(name)
+    for it in range(2):
+        batch = {k: torch.from_numpy(GOLD[pre + f"it{it}.batch.{k}"])
+                 for k in ("pre", "pre_mask", "post", "already", "already_mask")}
+        log = tr.train_step(gen, disc, batch)
+        got = [float(log[k]) for k in ("discriminator_loss", "g_image_loss", "g_perc_loss",
+                                       "g_adv_loss", "generator_loss")]
+        np.testing.assert_allclose(got, GOLD[pre + f"it{it}.losses"], rtol=2e-5)
+        if it == 0:
+            for k, p in gen.named_parameters():
+                key = pre + "it0.ggrad." + k
+                if key in GOLD.files:
+                    want = torch.from_numpy(GOLD[key])
+                    torch.testing.assert_close(p.grad, want, rtol=1e-3,
+                                               atol=1e-4 * float(want.abs().max()) + 1e-9)
+                else:                                   # the dead smoother branch (models.py:347)
+                    assert p.grad is None, k
+            # the discriminator was frozen only for the generator's backward
+            assert all(p.requires_grad for p in disc.parameters())
+    sd = gen.state_dict()
+    for k in GOLD.files:
+        if k.startswith(pre + "g2.") and ("running_" in k or "num_batches" in k):
+            torch.testing.assert_close(sd[k[len(pre) + 3:]], torch.from_numpy(GOLD[k]),
+                                       rtol=1e-4, atol=1e-6)
+    assert gen.stat_updates == 2
+
+
+def test_trainer_loop_bookkeeping(cpu_kernels, tmp_path, capsys):
+    """Trainer.train: epochs x (len // batch) iterations, evaluation + checkpoint at iteration 1
+    and every log_interval, final checkpoint 99999 (trainers.py:140-192)."""
+    gen, disc, tr = _setup("GeneratorJ")
+    ds = _dataset(0)
+    ds.valid_indices = ds.valid_indices[:13]                 # 13 pixels -> 3 batches of 4
+    ds.valid_indices_left = list(range(13))
+    tr.dataset = ds
+    tr.model_logger = T.ModelLogger(str(tmp_path), torch.save)
+    tr.testing_name_list = []
+    steps = []
+    orig = tr.train_step
+    tr.train_step = lambda g, d, b: (steps.append(b["pre"].shape), orig(g, d, b))[1]
+    tr.train(gen, disc, 2, "res_x", 0)
+    assert len(steps) == 2 * 3 and steps[0] == (4, 6, 32, 32)
+    saved = sorted(os.listdir(tmp_path))
+    # saves at batch 1, 2, 4, 6 (log_interval = 2) + the final one
+    assert saved == ["model_00000.pth", "model_00001.pth", "model_00002.pth", "model_00003.pth",
+                     "model_99999.pth"]
+    out = capsys.readouterr().out
+    assert "[1] " in out and "[generator_loss]" in out and "[6] " in out
+    sd = torch.load(os.path.join(tmp_path, "model_99999.pth"))
+    assert set(sd.keys()) == set(gen.state_dict().keys())
