@@ -169,55 +169,17 @@ def test_default_job_is_the_shipped_config():
 # connections, the dead smoother branch, the single shared generator forward with doubled
 # BatchNorm updates, loss composition, frozen discriminator, both Adam steps — is pinned
 # against the reference's own trainer fixture on every CPU run, independently of the kernels.
-import types
-
-import torch.nn.functional as F
-
 from drawingspinup_amd.style import functions as Fn
 from drawingspinup_amd.style import generators as G
-
-_ACT = {None: lambda t: t, "relu": F.relu, "leaky_relu": lambda t: F.leaky_relu(t, 0.2),
-        "tanh": torch.tanh}
-
-
-def _cpu_conv(x, weight, bias=None, stride=1, padding=0, act=None, plan=None):
-    if plan is not None:
-        off = plan.offset[None].expand(x.shape[0], -1, -1, -1)
-        y = sr.deform_conv2d(x, off, weight).to(x.dtype)
-    else:
-        y = F.conv2d(x, weight, bias, stride, padding)
-    return _ACT[act](y)
-
-
-def _cpu_bn(x, bn, act=None, stat_updates=1):
-    y = F.batch_norm(x, None, None, bn.weight, bn.bias, True, bn.momentum, bn.eps)
-    with torch.no_grad():
-        for _ in range(stat_updates):
-            F.batch_norm(x, bn.running_mean, bn.running_var, None, None, True, bn.momentum, bn.eps)
-        bn.num_batches_tracked += stat_updates
-    return _ACT[act](y)
-
-
-def _cpu_loss(f):
-    def loss(x, target):
-        if not torch.is_tensor(target):
-            target = torch.full_like(x, float(target))
-        return f(x, target.detach())
-    return loss
+from oracle import style_train_ref as tref
 
 
 @pytest.fixture
 def cpu_kernels(monkeypatch):
-    monkeypatch.setattr(Fn, "conv", _cpu_conv)
-    monkeypatch.setattr(Fn, "batch_norm_train", _cpu_bn)
-    monkeypatch.setattr(Fn, "instance_norm", lambda x, act=None, eps=1e-5:
-                        _ACT[act](F.instance_norm(x, eps=eps)))
-    monkeypatch.setattr(Fn, "activation", lambda x, act: _ACT[act](x))
-    monkeypatch.setattr(Fn, "maxpool2", lambda x: F.max_pool2d(x, 2, 2))
-    monkeypatch.setattr(Fn, "upsample2", lambda x: F.interpolate(x, scale_factor=2))
-    monkeypatch.setattr(Fn, "l1_loss", _cpu_loss(F.l1_loss))
-    monkeypatch.setattr(Fn, "mse_loss", _cpu_loss(F.mse_loss))
-    monkeypatch.setattr(G.ops, "deform_plan", lambda off: types.SimpleNamespace(offset=off))
+    for name in ("conv", "batch_norm_train", "instance_norm", "activation", "maxpool2",
+                 "upsample2", "l1_loss", "mse_loss"):
+        monkeypatch.setattr(Fn, name, getattr(tref, name))
+    monkeypatch.setattr(G.ops, "deform_plan", tref.deform_plan)
     monkeypatch.setattr(G._GeneratorBase, "_check", lambda self, x: None)
     monkeypatch.setattr(T, "_require_device", lambda x, what: None)
 
