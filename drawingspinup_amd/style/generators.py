@@ -151,6 +151,16 @@ class _GeneratorBase(nn.Module):
         else:
             self.conv_12 = nn.Conv2d(filters[5], 3, kernel_size=1, stride=1, padding=0, bias=True)
 
+    def train(self, mode=True):
+        """Entering or leaving training drops the folded eval-BatchNorm constants: the training
+        kernels update running statistics through raw pointers and the fused Adam step does not
+        bump `Parameter._version`, so `_bn_fold`'s version check alone would keep serving the
+        constants of the last evaluation (e.g. Trainer.test_on_full_image every log_interval)."""
+        for m in self.modules():
+            if hasattr(m, "_dsu_fold"):
+                del m._dsu_fold
+        return super().train(mode)
+
     # ---- constructors with the reference's sub-module names (state_dict keys)
     @staticmethod
     def relu_layer(in_filters, out_filters, size, stride, padding, bias, norm_layer, nonlinearity):

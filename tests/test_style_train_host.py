@@ -267,3 +267,20 @@ def test_trainer_loop_bookkeeping(cpu_kernels, tmp_path, capsys):
     assert "[1] " in out and "[generator_loss]" in out and "[6] " in out
     sd = torch.load(os.path.join(tmp_path, "model_99999.pth"))
     assert set(sd.keys()) == set(gen.state_dict().keys())
+
+
+def test_eval_after_training_refolds_batchnorm():
+    """The folded eval-BatchNorm constants must not survive a training phase: running statistics
+    are written through raw pointers (no tensor version bump)."""
+    g = T.build_model("GeneratorJ", dict(resnet_blocks=1, input_channels=6), "cpu").eval()
+    bn = g.conv0.normalization
+    scale0, shift0 = G._bn_fold(bn)
+    assert hasattr(bn, "_dsu_fold")
+    g.train()
+    bn.running_var.detach().numpy()[:] = 4.0          # in place, version counter untouched
+    bn.running_mean.detach().numpy()[:] = 1.0
+    g.eval()
+    scale1, shift1 = G._bn_fold(bn)
+    want = bn.weight / torch.sqrt(bn.running_var + bn.eps)
+    assert torch.allclose(scale1, want) and not torch.allclose(scale1, scale0)
+    assert torch.allclose(shift1, bn.bias - bn.running_mean * want)
