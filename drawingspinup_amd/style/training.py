@@ -356,26 +356,45 @@ class DatasetPatches_M:
                 self.valid_indices_left = list(range(len(self.valid_indices)))
         return np.asarray(mids), np.asarray(mids_r)
 
-    def cut(self, image, mids):
+    def patch_index(self, mids, H, W):
+        """patch_rows for both axes, evaluated on the device: row / column gather indices
+        (n, size) and the (n, size, size) mask of positions that receive image data."""
+        size, hs = self.patch_size, self.patch_size // 2
+        ar = torch.arange(size, device=mids.device)
+
+        def axis(m, extent):
+            lo = (m - hs).clamp_min(0)
+            hi = (m + hs).clamp_max(extent - 1)
+            src = lo[:, None] + ar[None, :]
+            return src.clamp_max(extent - 1), src < hi[:, None]
+        ry, vy = axis(mids[:, 0], H)
+        rx, vx = axis(mids[:, 1], W)
+        return ry, rx, vy[:, :, None] & vx[:, None, :]
+
+    @staticmethod
+    def cut(image, index):
         """cut_patch for a batch of centres: (n, C, size, size) gathered on the device."""
-        size = self.patch_size
-        _, H, W = image.shape
-        ry, vy = patch_rows(mids[:, 0], size, H)
-        rx, vx = patch_rows(mids[:, 1], size, W)
-        dev = image.device
-        ry_t = torch.from_numpy(np.minimum(ry, H - 1)).to(dev)
-        rx_t = torch.from_numpy(np.minimum(rx, W - 1)).to(dev)
-        ok = torch.from_numpy(vy[:, :, None] & vx[:, None, :]).to(dev)
-        patches = image[:, ry_t[:, :, None], rx_t[:, None, :]]      # (C, n, size, size)
-        return (patches * ok.unsqueeze(0)).permute(1, 0, 2, 3).contiguous()
+        ry, rx, ok = index
+        patches = image[:, ry[:, :, None], rx[:, None, :]]          # (C, n, size, size)
+        zero = torch.zeros((), dtype=image.dtype, device=image.device)
+        return torch.where(ok.unsqueeze(0), patches, zero).permute(1, 0, 2, 3).contiguous()
 
     def batch(self, n):
         mids, mids_r = self.draw_midpoints(n)
-        return {"pre": self.cut(self.images_pre, mids),
-                "pre_mask": self.cut(self.images_mask, mids),
-                "post": self.cut(self.images_post, mids),
-                "already": self.cut(self.images_post, mids_r),
-                "already_mask": self.cut(self.images_mask, mids_r)}
+        # the only host -> device traffic of an iteration: 2n centre coordinates, from pinned
+        # memory and without blocking the host (a pageable copy would wait for the device to
+        # drain and stop the host from queueing the next iteration)
+        both = torch.from_numpy(np.concatenate([mids, mids_r]).astype(np.int64))
+        if self.device.type == "cuda":
+            both = both.pin_memory().to(self.device, non_blocking=True)
+        _, H, W = self.images_pre.shape
+        assert self.images_post.shape[1:] == (H, W) and self.images_mask.shape[1:] == (H, W)
+        idx, idx_r = self.patch_index(both[:n], H, W), self.patch_index(both[n:], H, W)
+        return {"pre": self.cut(self.images_pre, idx),
+                "pre_mask": self.cut(self.images_mask, idx),
+                "post": self.cut(self.images_post, idx),
+                "already": self.cut(self.images_post, idx_r),
+                "already_mask": self.cut(self.images_mask, idx_r)}
 
     def batches(self, batch_size):
         """One epoch: len(self) // batch_size batches (DataLoader(drop_last=True))."""
