@@ -1,0 +1,56 @@
+"""CPU (cross-compile only): static guards against code-generation pitfalls that have already
+cost a measurable factor on the MI355X ("Compiler / runtime pitfalls").  hipcc emits
+gfx950 assembly without a GPU; tools/isa_stats.py parses it."""
+import importlib.util
+import os
+import shutil
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+spec = importlib.util.spec_from_file_location("isa_stats", os.path.join(ROOT, "tools", "isa_stats.py"))
+isa = importlib.util.module_from_spec(spec)
+spec.loader.exec_module(isa)
+
+pytestmark = pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc") and not shutil.which("hipcc"),
+                                reason="hipcc not available")
+
+
+def _kernels(fname):
+    txt = isa.compile_asm(os.path.join(isa.CSRC, fname))
+    md = isa.metadata(txt)
+    out = {}
+    for name, body in isa.bodies(txt):
+        ops = [ln.split()[0] for ln in body if ln[:1] in " \t" and ln.split()]
+        out[isa.demangle_short(name)] = (md[name], ops)
+    return out
+
+
+def test_weight_gradient_kernel_keeps_its_accumulators_in_place():
+    ks = _kernels("style_train.hip")
+    wg = {k: v for k, v in ks.items() if k.startswith("conv_wgrad_kernel")}
+    assert len(wg) == 15
+    for name, (md, ops) in wg.items():
+        mfma = sum(o.startswith("v_mfma") for o in ops)
+        movs = ops.count("v_accvgpr_mov_b32")
+        assert mfma in (4, 8), name
+        assert movs <= 16, f"{name}: {movs} accumulator copies around {mfma} MFMAs"
+        assert md["scratch"] == 0 and md["vspill"] <= 1, (name, md)
+        assert sum(o.startswith("scratch_") for o in ops) == 0, name
+    for name, (md, ops) in ks.items():
+        assert md["scratch"] == 0, (name, md)
+
+
+def test_dominant_nsr_kernels_have_no_scratch():
+    ks = _kernels("hashgrid_mfma.hip")
+    hot = [k for k in ks if k.startswith("sdf_fd_bwd_mfma_kernel") or k.startswith("sdf_fd_scatter")]
+    assert len(hot) >= 5
+    for name in hot:
+        md, ops = ks[name]
+        assert md["scratch"] == 0 and md["vspill"] == 0, (name, md)
+        assert sum(o.startswith("scratch_") for o in ops) == 0, name
+        assert md["vgpr"] <= 512
+    # the production variant <NL=10, fused scatter, feature cache>: the gather path and its level
+    # metadata are compiled out (SGPR spills 130 -> 36 when that was introduced)
+    md, _ = ks["sdf_fd_bwd_mfma_kernel<10,0,1>"]
+    assert md["sspill"] <= 48, md
