@@ -10,7 +10,9 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdsu_hip.so")
+# DSU_HIP_LIB=<path>: load a variant built by `python -m drawingspinup_amd.build --variant ...`
+# (A/B measurements); unset = the in-tree library.
+LIB_PATH = os.environ.get("DSU_HIP_LIB") or os.path.join(_HERE, "libdsu_hip.so")
 MAX_LEVELS = 16
 
 c_i32, c_i64, c_u32, c_f32, c_vp = C.c_int32, C.c_int64, C.c_uint32, C.c_float, C.c_void_p

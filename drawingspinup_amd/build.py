@@ -1,6 +1,12 @@
 """Build libdsu_hip.so (gfx950) in-tree with hipcc.
 
     python -m drawingspinup_amd.build [--force]
+    python -m drawingspinup_amd.build --variant NAME -DFOO=1 [-DBAR ...]
+
+The second form compiles every source with extra preprocessor definitions into
+drawingspinup_amd/variants/libdsu_hip_NAME.so (objects under csrc/_obj/NAME/); a process started
+with DSU_HIP_LIB=<that path> loads it instead of the default library.  Several variants can thus
+be measured in ONE visit to a GPU box (build here, run `DSU_HIP_LIB=... python tools/...` there).
 
 The library has no torch / pybind dependency: it is a plain C-ABI shared object
 (include/dsu_hip.h) loaded through ctypes by drawingspinup_amd._lib.
@@ -32,9 +38,9 @@ def _sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
 
-def _stamp(src):
+def _stamp(src, extra=()):
     h = hashlib.sha1()
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join([*FLAGS, *extra]).encode())
     for p in [src] + sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")) + \
             [os.path.join(HERE, "..", "include", "dsu_hip.h")]:
         with open(p, "rb") as f:
@@ -42,14 +48,14 @@ def _stamp(src):
     return h.hexdigest()
 
 
-def _compile(src, force):
-    obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
+def _compile(src, force, extra=(), objdir=None):
+    obj = os.path.join(objdir or OBJ, os.path.basename(src)[:-4] + ".o")
     stamp_file = obj + ".stamp"
-    stamp = _stamp(src)
+    stamp = _stamp(src, extra)
     if not force and os.path.exists(obj) and os.path.exists(stamp_file) \
             and open(stamp_file).read() == stamp:
         return obj, False
-    cmd = [_hipcc(), *FLAGS, "-c", src, "-o", obj]
+    cmd = [_hipcc(), *FLAGS, *extra, "-c", src, "-o", obj]
     r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -76,5 +82,30 @@ def build(force=False, verbose=True):
     return LIB
 
 
+def build_variant(name, defines, verbose=True):
+    """Every source compiled with the extra -D... flags -> variants/libdsu_hip_<name>.so."""
+    if not name.replace("_", "").isalnum():
+        raise ValueError("variant name: letters, digits, underscore")
+    objdir = os.path.join(OBJ, name)
+    os.makedirs(objdir, exist_ok=True)
+    outdir = os.path.join(HERE, "variants")
+    os.makedirs(outdir, exist_ok=True)
+    lib = os.path.join(outdir, f"libdsu_hip_{name}.so")
+    srcs = _sources()
+    with ThreadPoolExecutor(max_workers=min(8, len(srcs))) as ex:
+        objs = [o for o, _ in ex.map(lambda s: _compile(s, False, tuple(defines), objdir), srcs)]
+    r = subprocess.run([_hipcc(), "-shared", "-fPIC", f"--offload-arch={ARCH}", *objs, "-o", lib],
+                       capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+    if verbose:
+        print(f"[dsu build] variant {name} ({' '.join(defines)}): {lib}")
+    return lib
+
+
 if __name__ == "__main__":
-    build(force="--force" in sys.argv)
+    if "--variant" in sys.argv:
+        i = sys.argv.index("--variant")
+        build_variant(sys.argv[i + 1], [a for a in sys.argv[1:] if a.startswith("-D")])
+    else:
+        build(force="--force" in sys.argv)

@@ -83,6 +83,25 @@ def test_style_training_host_side_sizes():
     assert lib.dsu_pair_loss(None, None, 0.0, 4, 0, 1.0, None, None, None) == -1
 
 
+def test_variant_library_override(tmp_path):
+    """DSU_HIP_LIB points a process at a variant library (A/B measurements of kernel builds)."""
+    import shutil
+    import subprocess
+    import sys
+    from drawingspinup_amd import _lib
+    alt = tmp_path / "libdsu_hip_alt.so"
+    shutil.copy(_lib.LIB_PATH, alt)
+    code = ("from drawingspinup_amd import _lib; assert _lib.lib().dsu_abi_version() >= 1; "
+            "print(_lib.LIB_PATH)")
+    env = dict(os.environ, DSU_HIP_LIB=str(alt), PYTHONPATH=ROOT)
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.strip().endswith("libdsu_hip_alt.so")
+    env["DSU_HIP_LIB"] = str(tmp_path / "missing.so")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True)
+    assert out.returncode != 0 and "missing" in out.stderr       # fails loudly, no fallback
+
+
 def test_no_cpu_fallback():
     from drawingspinup_amd import ops, _lib
     cfg = ops.HashGridConfig()
