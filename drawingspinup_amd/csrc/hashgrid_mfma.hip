@@ -23,6 +23,14 @@
 
 using namespace dsu_hg;
 
+// Timing ablations (DSU_BWD_ABLATE=<bits>, tools/sdf_bwd_ablation.py) switch phases of the backward
+// off at run time.  -DDSU_NO_ABLATE (variant build) compiles the checks out.
+#ifdef DSU_NO_ABLATE
+#define DSU_ABL(bits) false
+#else
+#define DSU_ABL(bits) ((ablate & (bits)) != 0)
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -128,7 +136,7 @@ __device__ __forceinline__ void layer0_mfma(const Frags<NL>& f, const float* in,
       acc[1][T] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w0[T][t], b1, acc[1][T], 0, 0, 0);
     }
   }
-  if (ablate & 32) return;
+  if (DSU_ABL(32)) return;
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -157,7 +165,7 @@ __device__ __forceinline__ void layer0_mfma_half(const Frags<NL>& f, const float
     for (int T = 0; T < 2; ++T)
       acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w0[T][t], b, acc[T], 0, 0, 0);
   }
-  if (ablate & 32) return;
+  if (DSU_ABL(32)) return;
 #pragma unroll
   for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -460,7 +468,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
       const float cx = contract(q[0], radius), cy = contract(q[1], radius),
                   cz = contract(q[2], radius);
       float in[KIN];
-      if (ablate & 16) {
+      if (DSU_ABL(16)) {
 #pragma unroll
         for (int k = 0; k < KIN; ++k) in[k] = cx * (float)k + cy;
       } else if (ENC) {
@@ -541,7 +549,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
               }
             }
           }
-          if (!(ablate & 64))
+          if (!DSU_ABL(64))
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             // softplus'(pre) = sigmoid(100 pre) = 1 - exp(-100 softplus(pre))
@@ -577,7 +585,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
         }
         __builtin_amdgcn_wave_barrier();
         // gW0[feat][k'] += sum_points dPre[point][feat] * In'[point][k']
-        if (!(ablate & 2))
+        if (!DSU_ABL(2))
 #pragma unroll 4
         for (int t = 0; t < 16; ++t) {
           const int pr = 2 * t + h;
@@ -595,7 +603,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
               *reinterpret_cast<float4*>(&sd[l31 * SD_ROW + 32 * T + 8 * qd + 4 * h]) =
                   make_float4(Hh[T][4 * qd], Hh[T][4 * qd + 1], Hh[T][4 * qd + 2], Hh[T][4 * qd + 3]);
           __builtin_amdgcn_wave_barrier();
-          if (!(ablate & 2))
+          if (!DSU_ABL(2))
 #pragma unroll 4
           for (int t = 0; t < 16; ++t) {
             const int pr = 2 * t + h;
@@ -624,7 +632,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
               if (lev < NL && (uint32_t)lev < active) row[lev] = make_float2(din[r], din[r + 1]);
             }
           }
-        } else if (!(ablate & 1)) {
+        } else if (!DSU_ABL(1)) {
           const bool own = h == half;
           const float sx = own ? cx : pcx, sy = own ? cy : pcy, sz = own ? cz : pcz;
           const bool pv = __shfl(valid ? 1 : 0, half * 32 + l31) != 0;
@@ -714,7 +722,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
               }
               DSU_SEG_STEP(0x101) DSU_SEG_STEP(0x102) DSU_SEG_STEP(0x104) DSU_SEG_STEP(0x108)
 #undef DSU_SEG_STEP
-              lead = (l15 == 0 || dpp_i<0x111>(key) != key) && !(ablate & 4);  // first of its run
+              lead = (l15 == 0 || dpp_i<0x111>(key) != key) && !DSU_ABL(4);  // first of its run
             }
             const unsigned long long bal = __ballot(lead);
             if (lead) {
@@ -749,7 +757,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
       const uint32_t key = c_keys[t];
       if (key != GC_EMPTY) {
-        if (!(ablate & 8)) {
+        if (!DSU_ABL(8)) {
           unsafeAtomicAdd(gtable + (size_t)key * 2, gc_unfix(c_acc[2 * t]));
           unsafeAtomicAdd(gtable + (size_t)key * 2 + 1, gc_unfix(c_acc[2 * t + 1]));
         }
