@@ -708,6 +708,11 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
                 v[2 * c] = w * d0;
                 v[2 * c + 1] = w * d1;
               }
+#ifdef DSU_BWD_NOSCAN
+              // variant build for A/B runs: no merge, every valid lane emits its own 8 corners
+              // (≈500 fewer VALU instructions per evaluation, 2-4x the queue items)
+              lead = on && !DSU_ABL(4);
+#else
               const int key = (int)(cp.c[0] | (cp.c[1] << 10) | (cp.c[2] << 20));
               const int l15 = lane & 15;
               int e = (l15 == 15 || dpp_i<0x101>(key) != key) ? 1 : 0;   // run ends at this lane
@@ -723,6 +728,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
               DSU_SEG_STEP(0x101) DSU_SEG_STEP(0x102) DSU_SEG_STEP(0x104) DSU_SEG_STEP(0x108)
 #undef DSU_SEG_STEP
               lead = (l15 == 0 || dpp_i<0x111>(key) != key) && !DSU_ABL(4);  // first of its run
+#endif
             }
             const unsigned long long bal = __ballot(lead);
             if (lead) {
