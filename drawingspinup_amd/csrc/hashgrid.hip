@@ -230,14 +230,7 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(const __half2* __restrict_
 // LMAX: compile-time bound on the active levels (the 3000-step schedule uses 4..6 of the 10):
 // levels >= LMAX, their metadata scalars and their share of the first-layer loop are compiled out.
 template <int NL, int LMAX>
-// -DDSU_FD_FWD_OCC4 (variant build): ask for four waves per SIMD (<= 128 VGPRs; the 6-level
-// instantiation needs 135 today, so a few registers spill) — the kernel is gather-latency bound.
-#ifdef DSU_FD_FWD_OCC4
-#define DSU_FD_FWD_BOUNDS __launch_bounds__(256, 4)
-#else
-#define DSU_FD_FWD_BOUNDS __launch_bounds__(256)
-#endif
-__global__ DSU_FD_FWD_BOUNDS void sdf_fd_fwd_kernel(
+__global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
     const __half2* __restrict__ table, GridMeta m, dsu_sdf_mlp mlp,
     const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
     uint32_t active, float* __restrict__ sdf, float* __restrict__ grad,

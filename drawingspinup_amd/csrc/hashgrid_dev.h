@@ -84,15 +84,19 @@ __device__ __forceinline__ __half2 lookup_level(const __half2* __restrict__ tabl
 
 __device__ __forceinline__ float softplus100(float x) {
   // nn.Softplus(beta=100, threshold=20)  (network_utils.py:134-136)
-  // evaluated as max(x,0) + log(1 + exp(-|100x|))/100 on the hardware exp/log units
-  // (v_exp_f32 / v_log_f32): |error| <= ~1e-9 absolute, versus ~100 VALU instructions for
-  // libm log1pf(expf()) — 64 of these per network evaluation dominated the kernel otherwise
-  float bx = x * 100.0f;
-  return bx > 20.0f ? x : fmaxf(x, 0.0f) + __logf(1.0f + __expf(-fabsf(bx))) * 0.01f;
+  // evaluated as max(x,0) + log(1 + exp(-|100x|))/100 with the raw hardware exp2/log2
+  // (v_exp_f32 / v_log_f32: the arguments stay in (-inf, 0] and [1, 2], so the denormal and range
+  // fix-ups of the library forms are not needed): |error| <= ~1e-9 absolute, versus ~100 VALU
+  // instructions for libm log1pf(expf()).  BRANCH-FREE: beyond the threshold (100x > 20) exp() is
+  // below 2.1e-9, 1 + t rounds to 1 and the expression returns x exactly, as the reference's
+  // threshold branch does; the explicit `bx > 20 ? x : ...` form compiled to one exec-mask branch
+  // region per hidden unit (32 per lane per evaluation: 3x the instruction stream of the layer).
+  const float t = __builtin_amdgcn_exp2f(fabsf(x) * -144.26950408889634f);   // exp(-|100 x|)
+  return fmaxf(x, 0.0f) + __builtin_amdgcn_logf(1.0f + t) * 0.0069314718055994531f;  // ln2 / 100
 }
 __device__ __forceinline__ float softplus100_grad(float x) {
-  float bx = x * 100.0f;
-  return bx > 20.0f ? 1.0f : __frcp_rn(1.0f + __expf(-bx));
+  // sigmoid(100 x) = 1 / (1 + exp(-100 x)); exp2(+large) = inf -> rcp(inf) = 0
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * -144.26950408889634f));
 }
 
 __device__ __forceinline__ float contract(float p, float radius) {

@@ -31,6 +31,19 @@ using namespace dsu_hg;
 #define DSU_ABL(bits) ((ablate & (bits)) != 0)
 #endif
 
+// -DDSU_BWD_PROF (variant build only): per-phase shader-clock totals of the backward kernel,
+// accumulated by every wave into dsu_bwd_prof[] and read back with dsu_debug_bwd_prof().
+#ifdef DSU_BWD_PROF
+__device__ unsigned long long dsu_bwd_prof[16];
+#define DSU_PROF_DECL unsigned long long pt__[16] = {0}; unsigned long long pc__ = __builtin_readcyclecounter();
+#define DSU_PROF(i) { const unsigned long long n__ = __builtin_readcyclecounter(); pt__[i] += n__ - pc__; pc__ = n__; }
+#define DSU_PROF_END if ((threadIdx.x & 63) == 0) { for (int i__ = 0; i__ < 16; ++i__) atomicAdd(&dsu_bwd_prof[i__], pt__[i__]); }
+#else
+#define DSU_PROF_DECL
+#define DSU_PROF(i)
+#define DSU_PROF_END
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -449,6 +462,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) gw1c0[T][r] = 0.0f;
 
+  DSU_PROF_DECL
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t bbase = blockIdx.x * (int64_t)blockDim.x; bbase < n; bbase += stride) {
     const int64_t i = bbase + threadIdx.x;
@@ -488,6 +502,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
       } else {
         encode_input_p<NL>(table, m, active, cx, cy, cz, in);
       }
+      DSU_PROF(0)   // positions + feature-cache row
       // upstream gradient on this evaluation's outputs (own point)
       float dout[NOUT];
 #pragma unroll
@@ -512,6 +527,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
       // partner's position (for the scatter of the other point half)
       const float pcx = __shfl_xor(cx, 32), pcy = __shfl_xor(cy, 32), pcz = __shfl_xor(cz, 32);
 
+      DSU_PROF(1)   // upstream gradient loads
 #pragma unroll 1
       for (int half = 0; half < 2; ++half) {
         // gradient on the outputs of the points of this half: own if this lane owns the half
@@ -522,8 +538,10 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
           if (o < no) other = __shfl_xor(dout[o], 32);
           d[o] = (h == half) ? dout[o] : other;
         }
+        DSU_PROF(2)   // partner shuffles
         f32x16 Hh[2];
         layer0_mfma_half<NL>(fr, in, active, half, Hh, ablate);
+        DSU_PROF(3)   // layer 0 + softplus
         f32x16 din;
 #pragma unroll
         for (int r = 0; r < 16; ++r) din[r] = 0.0f;
@@ -553,7 +571,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             // softplus'(pre) = sigmoid(100 pre) = 1 - exp(-100 softplus(pre))
-            dpre[r] *= 1.0f - __expf(-100.0f * Hh[T][r]);
+            dpre[r] *= 1.0f - __builtin_amdgcn_exp2f(Hh[T][r] * -144.26950408889634f);
             din = __builtin_amdgcn_mfma_f32_32x32x2f32(w0t[T][r], dpre[r], din, 0, 0, 0);
           }
           // dPre of this half's points -> LDS rows [point][hidden] for the W0 gradient GEMM
@@ -562,6 +580,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
             *reinterpret_cast<float4*>(&sd[l31 * SD_ROW + 32 * T + 8 * qd + 4 * h]) =
                 make_float4(dpre[4 * qd], dpre[4 * qd + 1], dpre[4 * qd + 2], dpre[4 * qd + 3]);
         }
+        DSU_PROF(4)   // dPre, sigmoid, dIn MFMAs, dPre staging
         if (h == half) {
 #pragma unroll
           for (int k4 = 0; k4 < 8; ++k4) {
@@ -584,6 +603,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
           }
         }
         __builtin_amdgcn_wave_barrier();
+        DSU_PROF(5)   // input / dOut staging
         // gW0[feat][k'] += sum_points dPre[point][feat] * In'[point][k']
         if (!DSU_ABL(2))
 #pragma unroll 4
@@ -594,6 +614,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
           gw0[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + 32 + l31], b, gw0[1], 0, 0, 0);
         }
         __builtin_amdgcn_wave_barrier();
+        DSU_PROF(6)   // gW0 GEMM
         if (e == 0) {
           // hidden activations of this half's points -> LDS, then gW1[feat][o'] += H^T . dOut
 #pragma unroll
@@ -619,17 +640,19 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) gw1c0[T][r] = fmaf(Hh[T][r], d[0], gw1c0[T][r]);
         }
+        DSU_PROF(7)   // gW1 GEMM / column
         // scatter dIn rows held by this lane: input row i = (r&3) + 8(r>>2) + 4h, levels (i>>1)
         if (SPLIT) {
           // dIn of this half's points -> dinbuf: lane (l31, h) holds the feature pairs of levels
           // {0,1,4,5,8,9} (h = 0) or {2,3,6,7} (h = 1) of point (half, l31)
+          // layout [evaluation][level][point]: the 32 lanes of a half write 256 contiguous bytes
           const int64_t pi = bbase + wave * 64 + half * 32 + l31;
           if (pi < n) {
-            float2* row = dinbuf + ((size_t)e * n + pi) * active;
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
               const int lev = ((r & 3) + 8 * (r >> 2)) / 2 + 2 * h;
-              if (lev < NL && (uint32_t)lev < active) row[lev] = make_float2(din[r], din[r + 1]);
+              if (lev < NL && (uint32_t)lev < active)
+                dinbuf[((size_t)e * active + lev) * n + pi] = make_float2(din[r], din[r + 1]);
             }
           }
         } else if (!DSU_ABL(1)) {
@@ -708,11 +731,6 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
                 v[2 * c] = w * d0;
                 v[2 * c + 1] = w * d1;
               }
-#ifdef DSU_BWD_NOSCAN
-              // variant build for A/B runs: no merge, every valid lane emits its own 8 corners
-              // (≈500 fewer VALU instructions per evaluation, 2-4x the queue items)
-              lead = on && !DSU_ABL(4);
-#else
               const int key = (int)(cp.c[0] | (cp.c[1] << 10) | (cp.c[2] << 20));
               const int l15 = lane & 15;
               int e = (l15 == 15 || dpp_i<0x101>(key) != key) ? 1 : 0;   // run ends at this lane
@@ -728,7 +746,6 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
               DSU_SEG_STEP(0x101) DSU_SEG_STEP(0x102) DSU_SEG_STEP(0x104) DSU_SEG_STEP(0x108)
 #undef DSU_SEG_STEP
               lead = (l15 == 0 || dpp_i<0x111>(key) != key) && !DSU_ABL(4);  // first of its run
-#endif
             }
             const unsigned long long bal = __ballot(lead);
             if (lead) {
@@ -755,6 +772,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
           }
           drain();
         }
+        DSU_PROF(8)   // dIn write-out or scatter
       }
     }
     // flush the gradient cache: one global atomic pair per touched entry, then reset
@@ -773,7 +791,10 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
       }
     }
     __syncthreads();
+    DSU_PROF(9)     // cache flush
   }
+  DSU_PROF(10)
+  DSU_PROF_END
 
   // ---- workgroup reduction of the parameter-gradient tiles -> one partial vector per workgroup
   __syncthreads();
@@ -875,7 +896,7 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
         const float cx = contract(q[0], radius), cy = contract(q[1], radius),
                     cz = contract(q[2], radius);
         float2 d = make_float2(0.0f, 0.0f);
-        if (valid) d = dinbuf[((size_t)e * n + i) * active + lev];
+        if (valid) d = dinbuf[((size_t)e * active + lev) * n + i];
         const CellPos cp = cell_of(l_scale, cx, cy, cz);
         float v[16];
 #pragma unroll
@@ -998,12 +1019,14 @@ extern "C" int64_t dsu_sdf_fd_bwd_workspace_bytes_valu(const dsu_hashgrid_cfg*, 
 //   forward:  VALU 0.22 ms vs MFMA 0.30 ms  -> VALU (gather-latency bound; 2 waves/SIMD help)
 //   backward: VALU 2.31 ms vs MFMA 1.60 ms  -> MFMA
 // DSU_SDF_IMPL=valu|mfma forces one implementation for everything (A/B runs, tests).
-// DSU_BWD_SPLIT=1: MLP backward and table scatter as two kernels (see sdf_fd_bwd_mfma_kernel)
+// Default (measured round 2, N = 262 144 ray-ordered samples at the training step size, 4/5/6 levels):
+//   fused 0.60 / 0.72 / 0.85 ms, two kernels 0.54 / 0.61 / 0.71 ms -> two kernels.
+// DSU_BWD_SPLIT=0 selects the fused kernel.
 static bool bwd_split() {
   static int v = -1;
   if (v < 0) {
     const char* e = getenv("DSU_BWD_SPLIT");
-    v = (e && atoi(e) != 0) ? 1 : 0;
+    v = (e && atoi(e) == 0) ? 0 : 1;
   }
   return v == 1;
 }
@@ -1113,6 +1136,9 @@ int dsu_sdf_fd_bwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16, co
   GridMeta m;
   int rc = make_meta(cfg, &m);
   if (rc) return rc;
+  // the same-cell run merge packs a cell's coordinates into 10 bits each
+  for (uint32_t l = 0; l < active_levels; ++l)
+    if (m.res[l] + 1u > 1024u) return DSU_EUNSUP;
   if (n == 0) return DSU_OK;
   const int64_t need = dsu_sdf_fd_bwd_workspace_bytes(cfg, n);
   if (need < 0) return (int)need;
@@ -1173,5 +1199,17 @@ int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu
                                d_grad, d_feature, d_laplace, grad_table, g_w0, g_b0, g_w1, g_b1,
                                workspace, workspace_bytes, nullptr, stream);
 }
+
+#ifdef DSU_BWD_PROF
+int dsu_debug_bwd_prof(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(dsu_bwd_prof), 16 * sizeof(unsigned long long)) != hipSuccess)
+    return DSU_ELAUNCH;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(dsu_bwd_prof), z, sizeof(z)) != hipSuccess) return DSU_ELAUNCH;
+  }
+  return DSU_OK;
+}
+#endif
 
 }  // extern "C"

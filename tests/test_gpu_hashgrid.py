@@ -219,3 +219,33 @@ def test_fused_sdf_matches_reference_volume_sdf_fixture(dev):
         np.testing.assert_allclose(lap.cpu().numpy(), gold[k + "laplace"], rtol=0, atol=2e-5 / eps ** 2)
         s1 = ops.sdf_fwd(CFG, tab, mlp, pts, 1.0, level, 1)[:, 0]
         np.testing.assert_allclose(s1.cpu().numpy(), gold[k + "forward_level"], rtol=0, atol=5e-6)
+
+
+def test_sdf_fd_bwd_fused_form_in_subprocess():
+    """The single-kernel form of the backward (DSU_BWD_SPLIT=0; the default is the two-kernel form)
+    is selected once per process, so it is checked in a child process."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DSU_BWD_SPLIT="0", PYTHONPATH=root)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-m", "gpu",
+                        os.path.join(root, "tests", "test_gpu_hashgrid.py") + "::test_sdf_fd_bwd",
+                        os.path.join(root, "tests", "test_gpu_hashgrid.py")
+                        + "::test_sdf_fd_feature_cache_round_trip"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_sdf_fd_bwd_rejects_resolutions_beyond_the_cell_key(dev):
+    """The same-cell run merge packs cell coordinates into 10 bits each: a grid whose active levels
+    exceed 1023 cells per axis must be refused, not silently aliased."""
+    cfg = ops.HashGridConfig(n_levels=12, base_resolution=64)
+    n = 64
+    tab = torch.zeros(cfg.n_entries, 2, dtype=torch.float16, device=dev)
+    mlp = [torch.zeros(64, 27), torch.zeros(64), torch.zeros(13, 64), torch.zeros(13)]
+    mlp = [m.to(dev) for m in mlp]
+    pts = _pts(n, 3, -1.0, 1.0).to(dev)
+    d = [torch.zeros(n, device=dev), torch.zeros(n, 3, device=dev), torch.zeros(n, 13, device=dev),
+         torch.zeros(n, device=dev)]
+    ops.sdf_fd_bwd(cfg, tab, mlp, pts, 1.0, 0.01, 10, *d)          # level 9: 64 * s^9 = 776 cells
+    with pytest.raises(Exception):
+        ops.sdf_fd_bwd(cfg, tab, mlp, pts, 1.0, 0.01, 12, *d)      # level 11: 1353 cells
