@@ -48,7 +48,10 @@ def run(stage, argv=None):
     if stage == 2:
         ap.add_argument("--no_edge", action="store_true")
     ap.add_argument("--config", default=None, help="a configs/config_stageN.yaml of the reference")
-    ap.add_argument("--vgg", default=None, help="vgg19 state_dict (torchvision layout)")
+    ap.add_argument("--vgg", default=None, help="vgg19 state_dict (torchvision layout); default: "
+                                                "DSU_VGG19_WEIGHTS or the torch hub cache")
+    ap.add_argument("--random_vgg", action="store_true",
+                    help="train against RANDOM vgg19 features (no ImageNet file available)")
     args = ap.parse_args(argv)
 
     if args.config:
@@ -86,6 +89,8 @@ def run(stage, argv=None):
     perc_args = dict(config["perception_loss"]["perception_model"]["args"])
     if args.vgg:
         perc_args["path"] = args.vgg
+    if args.random_vgg:
+        perc_args["random_init"] = True
     perception_loss_model = build_model(config["perception_loss"]["perception_model"]["type"],
                                         perc_args, device)
 

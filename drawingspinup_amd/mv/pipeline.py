@@ -62,6 +62,7 @@ class DDIMScheduler:
         self.num_inference_steps = num_inference_steps
         step_ratio = self.num_train_timesteps // num_inference_steps
         ts = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.int64)
+        self.timesteps_host = [int(v) for v in ts + self.steps_offset]   # no device read-back per step
         self.timesteps = torch.from_numpy(ts + self.steps_offset).to(device)
 
     def scale_model_input(self, sample, t):
@@ -329,7 +330,9 @@ class MVDiffusionImagePipeline:
             model_in = torch.cat([latents, image_latents], dim=1)
             noise_pred = self._unet_step(model_in, t, image_embeddings, cam)
             vn = None if step_noise is None else step_noise[i].to(dev, dt)
-            latents = self.scheduler.step(noise_pred, t, latents, eta=eta, generator=generator,
+            # the host copy of the schedule: int(device tensor) was one blocking read-back per step
+            t_host = self.scheduler.timesteps_host[i] if hasattr(self.scheduler, "timesteps_host") else t
+            latents = self.scheduler.step(noise_pred, t_host, latents, eta=eta, generator=generator,
                                           variance_noise=vn)
             if callback is not None:
                 callback(i, t, latents)

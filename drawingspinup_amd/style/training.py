@@ -123,6 +123,20 @@ def _vgg19_features():
     return nn.Sequential(*layers)
 
 
+def find_vgg19_weights():
+    """DSU_VGG19_WEIGHTS, else ~/.cache/torch/hub/checkpoints/vgg19-*.pth (where
+    torchvision's models.vgg19(pretrained=True) leaves the file)."""
+    import glob
+    cand = [os.environ.get("DSU_VGG19_WEIGHTS")]
+    hub = os.path.join(os.environ.get("TORCH_HOME", os.path.expanduser("~/.cache/torch")), "hub",
+                       "checkpoints")
+    cand += sorted(glob.glob(os.path.join(hub, "vgg19-*.pth")))
+    for c in cand:
+        if c and os.path.isfile(c):
+            return c
+    return None
+
+
 class _VGG(nn.Module):
     def __init__(self):
         super().__init__()
@@ -133,12 +147,22 @@ class PerceptualVGG19(nn.Module):
     """models.py:480-549.  Holds torchvision's vgg19 `features` stack under the same keys
     (`model.features.N.weight`); only layers up to max(feature_layers) are ever evaluated.
     `path`: a vgg19 state_dict file (torchvision layout; classifier entries are ignored).
-    Without a path the reference downloads the ImageNet weights — there is no network here, so
-    the weights stay at their initialisation unless load_state_dict is called."""
+    Without a path the reference downloads the ImageNet weights (models.vgg19(pretrained=True),
+    models.py:497).  There is no network here: the file is looked up in DSU_VGG19_WEIGHTS and the
+    torch hub cache, and a missing file is an ERROR unless `random_init=True` is passed — the
+    perceptual term carries the largest weight of the three (6.0) and random features would train
+    a different model without any sign of it."""
 
-    def __init__(self, feature_layers, use_normalization=True, path=None):
+    def __init__(self, feature_layers, use_normalization=True, path=None, random_init=False):
         super().__init__()
         self.model = _VGG()
+        if path is None and not random_init:
+            path = find_vgg19_weights()
+            if path is None:
+                raise FileNotFoundError(
+                    "PerceptualVGG19: no ImageNet vgg19 weights (pass path=..., set "
+                    "DSU_VGG19_WEIGHTS, put vgg19-*.pth in the torch hub cache, or pass "
+                    "random_init=True to train against random features knowingly)")
         if path is not None:
             sd = torch.load(path, map_location="cpu")
             self.model.load_state_dict({k: v for k, v in sd.items() if k.startswith("features.")})

@@ -12,8 +12,10 @@ xformers==0.0.17 are absent and not installable), so this file restates:
     FeedForward/GEGLU, ResnetBlock2D, Downsample2D/Upsample2D, Timesteps/TimestepEmbedding),
     from their published definitions.
 PARITY UNPINNED: the reference ships no tests/golden vectors for this path and its
-third-party pieces cannot be executed here; KATs are hand-derived (tests/test_oracle_mv.py).
-Everything is float64 on the CPU.
+third-party pieces cannot be executed here; KATs are hand-derived (tests/test_oracle_mv.py,
+run on the CPU).
+Everything is float64 on the CPU (parameters are widened on use, so a full-width 910 M-parameter
+state_dict stays in its f16 storage).
 """
 import math
 
@@ -23,9 +25,15 @@ from einops import rearrange, repeat
 
 
 def memory_efficient_attention(q, k, v):
-    """xformers semantics on (B*H, M, d): softmax(q k^T * d^-0.5) v."""
-    s = torch.einsum("bmd,bnd->bmn", q, k) * (q.shape[-1] ** -0.5)
-    return torch.einsum("bmn,bnd->bmd", torch.softmax(s, dim=-1), v)
+    """xformers semantics on (B*H, M, d): softmax(q k^T * d^-0.5) v.  Evaluated in slices of the
+    batch axis so that the BASELINE shape (96 x 1024 x 6144 scores) stays under 1 GB."""
+    out = []
+    step = max(1, int(2 ** 27 // max(q.shape[1] * k.shape[1], 1)))
+    for b0 in range(0, q.shape[0], step):
+        sl = slice(b0, b0 + step)
+        s = torch.einsum("bmd,bnd->bmn", q[sl], k[sl]) * (q.shape[-1] ** -0.5)
+        out.append(torch.einsum("bmn,bnd->bmd", torch.softmax(s, dim=-1), v[sl]))
+    return torch.cat(out, 0)
 
 
 def head_to_batch_dim(t, heads):          # diffusers Attention.head_to_batch_dim
@@ -81,13 +89,13 @@ def timestep_embedding(t, dim, flip_sin_to_cos=True, shift=0):
 class UNetRef:
     def __init__(self, sd, block_out_channels, down_types, up_types, layers_per_block=2, heads=8,
                  groups=32, eps=1e-5, num_views=6, cd_attention_mid=True):
-        self.sd = {k: v.double() for k, v in sd.items()}
+        self.sd = dict(sd)               # widened to float64 on use (p())
         self.boc, self.down_types, self.up_types = block_out_channels, down_types, up_types
         self.lpb, self.heads, self.groups, self.eps = layers_per_block, heads, groups, eps
         self.num_views, self.cd_mid = num_views, cd_attention_mid
 
     def p(self, name):
-        return self.sd[name]
+        return self.sd[name].double()
 
     def lin(self, pre, x, bias=True):
         return F.linear(x, self.p(pre + ".weight"), self.p(pre + ".bias") if bias else None)
@@ -176,3 +184,61 @@ class UNetRef:
                 x = self.conv(f"up_blocks.{i}.upsamplers.0.conv", x)
         x = F.silu(self.gn("conv_norm_out", x, self.eps))
         return self.conv("conv_out", x)
+
+
+# ----------------------------------------------------------------------------------------------
+# diffusers 0.19.3 DDIMScheduler (schedulers/scheduling_ddim.py: __init__, set_timesteps with
+# timestep_spacing="leading", step) and the denoising loop of
+# mvdiffusion/pipelines/pipeline_mvdiffusion_image.py:463-486, in float64 with injected noise.
+# ----------------------------------------------------------------------------------------------
+def ddim_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
+    """beta_schedule="scaled_linear": linspace in sqrt(beta), float32 as diffusers builds it."""
+    betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps,
+                           dtype=torch.float32) ** 2
+    return torch.cumprod(1.0 - betas, dim=0).double()
+
+
+def ddim_timesteps(num_inference_steps, num_train_timesteps=1000, steps_offset=1):
+    ratio = num_train_timesteps // num_inference_steps
+    return [int(round(i * ratio)) + steps_offset for i in range(num_inference_steps)][::-1]
+
+
+def ddim_step(model_output, t, sample, num_inference_steps, eta, variance_noise, acp=None,
+              num_train_timesteps=1000, set_alpha_to_one=False):
+    """One DDIMScheduler.step (epsilon prediction, clip_sample False, use_clipped False): formulas
+    (12) and (16) of Song et al. as diffusers writes them."""
+    acp = ddim_alphas_cumprod(num_train_timesteps) if acp is None else acp
+    prev_t = t - num_train_timesteps // num_inference_steps
+    a_t = acp[t]
+    a_prev = acp[prev_t] if prev_t >= 0 else (torch.tensor(1.0, dtype=torch.float64)
+                                              if set_alpha_to_one else acp[0])
+    b_t = 1 - a_t
+    x, eps = sample.double(), model_output.double()
+    x0 = (x - b_t ** 0.5 * eps) / a_t ** 0.5
+    variance = (1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)
+    std = eta * variance ** 0.5
+    prev = a_prev ** 0.5 * x0 + (1 - a_prev - std ** 2) ** 0.5 * eps
+    if eta > 0:
+        prev = prev + std * variance_noise.double()
+    return prev
+
+
+def denoise_loop(unet, latents, image_latents, image_embeddings, camera_embeddings,
+                 num_inference_steps, step_noise, eta=1.0, run_steps=None, round_dtype=None):
+    """pipeline_mvdiffusion_image.py:463-486 without classifier-free guidance (mv.py:81):
+    cat(latents, image_latents) -> UNet -> scheduler.step.  `round_dtype` (torch.float16) rounds
+    the latents after every step as the reference's f16 pipeline does (prev_sample keeps the
+    sample dtype); returns the list of latents after each step."""
+    acp = ddim_alphas_cumprod()
+    out = []
+    lat = latents.double()
+    for i, t in enumerate(ddim_timesteps(num_inference_steps)[:run_steps]):
+        model_in = torch.cat([lat, image_latents.double()], 1)
+        eps = unet(model_in, torch.tensor([t]), image_embeddings, camera_embeddings)
+        if round_dtype is not None:
+            eps = eps.to(round_dtype).double()
+        lat = ddim_step(eps, t, lat, num_inference_steps, eta, step_noise[i], acp)
+        if round_dtype is not None:
+            lat = lat.to(round_dtype).double()
+        out.append(lat)
+    return out

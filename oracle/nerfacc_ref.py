@@ -9,7 +9,7 @@ and anchors on the reference's call sites:
   neus.py:119-129   ray_marching(o, d, scene_aabb, grid, step, stratified, cone_angle=0)
   neus.py:147-152   render_weight_from_alpha / accumulate_along_rays
 PARITY UNPINNED: the reference holds no tests or golden vectors for these ops; the
-known-answer tests in tests/test_oracle_nerfacc.py are hand-derived.
+known-answer tests in tests/test_oracle_nsr.py::test_nerfacc_kats are hand-derived.
 All float arithmetic is done in numpy float32 scalar ops to mirror the f32 device code.
 """
 import numpy as np

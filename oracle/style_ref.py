@@ -89,3 +89,42 @@ def conv_bn_act(x, weight, bias, stride, padding, bn=None, act=None, residual=No
     if residual is not None:
         y = y + residual.to(dt)
     return y
+
+
+def seeded_state_dict(template, seed):
+    """Deterministic parameters for a generator from a SEED (fixtures store the seed, not 13 MB of
+    weights): every tensor of `template` (a state_dict, any module tree) is filled from its own
+    generator keyed by crc32(name) + seed — convolution weights N(0, 1 / fan_in) (the last
+    1x1 convolution N(0, 3 / fan_in): output spread ~0.3, tanh not saturated), BatchNorm
+    weight/var in [0.5, 1.5], bias/mean N(0, 0.1^2), integer buffers kept."""
+    import zlib
+    out = {}
+    for name in sorted(template):
+        t = template[name]
+        if not t.dtype.is_floating_point:
+            out[name] = t.clone()
+            continue
+        g = torch.Generator().manual_seed((zlib.crc32(name.encode()) + 7919 * seed) % (2 ** 31))
+        if t.dim() > 1:
+            fan_in = t[0].numel()
+            gain = 3.0 if (t.dim() == 4 and t.shape[0] == 3) else 1.0     # the RGB head
+            v = torch.randn(t.shape, generator=g) * (gain / fan_in) ** 0.5
+        elif name.endswith("running_var") or name.endswith("weight"):
+            v = torch.rand(t.shape, generator=g) + 0.5
+        else:
+            v = torch.randn(t.shape, generator=g) * 0.1
+        out[name] = v.to(t.dtype)
+    return out
+
+
+# shared by tests/golden/make_style_fullsize_golden.py and the GPU test that reads its fixture
+FULLSIZE_ARGS = dict(use_bias=False, tanh=True, append_smoothers=True, resnet_blocks=7,
+                     filters=[32, 64, 128, 128, 128, 64], input_channels=6)   # config_stage{1,2}.yaml
+
+
+def fullsize_frame(seed):
+    """(1,6,512,512) in [-1,1]: smooth random field + 5 % noise (a frame-like input from a seed)."""
+    g = torch.Generator().manual_seed(seed)
+    low = torch.rand(1, 6, 64, 64, generator=g) * 2 - 1
+    x = F.interpolate(low, size=(512, 512), mode="bilinear", align_corners=False)
+    return (x + 0.05 * torch.randn(1, 6, 512, 512, generator=g)).clamp(-1, 1)

@@ -133,3 +133,24 @@ def test_generator_full_size_runs(dev, name):
         y2 = net(x)
     assert y1.shape == (1, 3, 512, 512) and torch.isfinite(y1).all()
     assert float(y1.abs().max()) <= 1.0 and torch.equal(y1, y2)
+
+
+@pytest.mark.parametrize("name", ["GeneratorJ", "GeneratorJ_RIC"])
+def test_generator_shipped_config_512_matches_reference_fixture(dev, name):
+    """BASELINE size: the reference's own class at the shipped widths on one 512x512 frame
+    (tests/golden/make_style_fullsize_golden.py; weights and input rebuilt from the stored seeds).
+    Same bar as the reduced fixture: 2e-4 absolute on the float output (stride-3 lattice stored),
+    <= 1/255 on >= 99.9 % of the full-resolution uint8 image."""
+    from oracle import style_ref
+    FULL_ARGS, frame = style_ref.FULLSIZE_ARGS, style_ref.fullsize_frame
+    gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "style_fullsize_reference.npz"))
+    seed, stride = int(gold[name + ".seed"]), int(gold["stride"])
+    net = G.build_model(name, FULL_ARGS)
+    net.load_state_dict(style_ref.seeded_state_dict(net.state_dict(), seed))
+    net = net.to(dev).eval()
+    with torch.no_grad():
+        y = net(frame(seed + 1).to(dev))[0].cpu().numpy()
+    assert y.shape == (3, 512, 512)
+    np.testing.assert_allclose(y[:, ::stride, ::stride], gold[name + ".f32"], rtol=0, atol=2e-4)
+    q, qr = _to_image_space(y).astype(int), gold[name + ".u8"].astype(int)
+    assert (np.abs(q - qr) <= 1).mean() >= 0.999

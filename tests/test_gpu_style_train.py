@@ -183,7 +183,7 @@ def _setup(name, dev):
     disc.load_state_dict({k[len(pre) + 3:]: torch.from_numpy(GOLD[k]) for k in GOLD.files
                           if k.startswith(pre + "d0.")})
     perc = T.build_model("PerceptualVGG19", dict(feature_layers=[0, 3, 5],
-                                                 use_normalization=False), dev)
+                                                 use_normalization=False, random_init=True), dev)
     sd = perc.state_dict()
     for f in (0, 2, 5):
         sd[f"model.features.{f}.weight"] = torch.from_numpy(GOLD[f"vgg.features.{f}.weight"])

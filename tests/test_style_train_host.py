@@ -124,7 +124,7 @@ def test_module_layouts_match_reference():
             if k.startswith("GeneratorJ.d0.")}
     got = {k: tuple(v.shape) for k, v in d.state_dict().items()}
     assert got == want
-    v = T.PerceptualVGG19(feature_layers=[0, 3, 5], use_normalization=False)
+    v = T.PerceptualVGG19(feature_layers=[0, 3, 5], use_normalization=False, random_init=True)
     keys = set(v.state_dict().keys())
     for f in (0, 2, 5):
         assert f"model.features.{f}.weight" in keys
@@ -143,7 +143,7 @@ def test_no_cpu_fallback():
     d = T.DiscriminatorN_IN(num_filters=4, n_layers=2)
     with pytest.raises(RuntimeError):
         d(torch.zeros(1, 3, 32, 32))
-    v = T.PerceptualVGG19(feature_layers=[0, 3, 5], use_normalization=False)
+    v = T.PerceptualVGG19(feature_layers=[0, 3, 5], use_normalization=False, random_init=True)
     with pytest.raises(RuntimeError):
         v(torch.zeros(1, 3, 32, 32))
     g = T.build_model("GeneratorJ", dict(resnet_blocks=1, input_channels=6), "cpu").train()
@@ -198,7 +198,7 @@ def _setup(name):
     disc.load_state_dict({k[len(pre) + 3:]: torch.from_numpy(GOLD[k]) for k in GOLD.files
                           if k.startswith(pre + "d0.")})
     perc = T.build_model("PerceptualVGG19", dict(feature_layers=[0, 3, 5],
-                                                 use_normalization=False), "cpu")
+                                                 use_normalization=False, random_init=True), "cpu")
     sd = perc.state_dict()
     for f in (0, 2, 5):
         sd[f"model.features.{f}.weight"] = torch.from_numpy(GOLD[f"vgg.features.{f}.weight"])
@@ -284,3 +284,22 @@ def test_eval_after_training_refolds_batchnorm():
     want = bn.weight / torch.sqrt(bn.running_var + bn.eps)
     assert torch.allclose(scale1, want) and not torch.allclose(scale1, scale0)
     assert torch.allclose(shift1, bn.bias - bn.running_mean * want)
+
+
+def test_perceptual_vgg_refuses_to_run_on_random_features_silently(tmp_path, monkeypatch):
+    """models.py:497 loads the ImageNet weights; without a weights file the product must fail
+    loudly unless random features are asked for by name."""
+    import pytest
+    monkeypatch.delenv("DSU_VGG19_WEIGHTS", raising=False)
+    monkeypatch.setenv("TORCH_HOME", str(tmp_path))
+    with pytest.raises(FileNotFoundError):
+        T.PerceptualVGG19(feature_layers=[0, 3, 5])
+    v = T.PerceptualVGG19(feature_layers=[0, 3, 5], random_init=True)
+    # a weights file in the torchvision layout is picked up from DSU_VGG19_WEIGHTS
+    sd = {"features." + k: t for k, t in v.model.features.state_dict().items()}
+    sd["classifier.0.weight"] = torch.zeros(1)
+    path = tmp_path / "vgg19-test.pth"
+    torch.save(sd, path)
+    monkeypatch.setenv("DSU_VGG19_WEIGHTS", str(path))
+    w = T.PerceptualVGG19(feature_layers=[0, 3, 5])
+    assert torch.equal(w.model.features[0].weight, v.model.features[0].weight)

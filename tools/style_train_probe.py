@@ -41,7 +41,7 @@ def main():
     job["generator"]["args"]["input_channels"] += 3
     gen = T.build_model(job["generator"]["type"], job["generator"]["args"], dev)
     disc = T.build_model("DiscriminatorN_IN", job["discriminator"]["args"], dev)
-    perc = T.build_model("PerceptualVGG19", job["perception_loss"]["perception_model"]["args"], dev)
+    perc = T.build_model("PerceptualVGG19", dict(job["perception_loss"]["perception_model"]["args"], random_init=True), dev)
     ds = synthetic_dataset(dev)
     tr = T.Trainer(None, dict(job["trainer"]), T.build_optimizer("Adam", disc, job["opt_discriminator"]["args"]),
                    T.build_optimizer("Adam", gen, job["opt_generator"]["args"]), None, perc,
