@@ -1,22 +1,30 @@
 #!/usr/bin/env python
 """Benchmark of the DrawingSpinUp hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config drawing|nsr50k|frames]
 
-One "step" = ONE drawing through the hot path on each rank (weak scaling: one drawing per GPU
-per step, BASELINE.json configs[4] per-GPU = the configuration the metric is quoted on):
-    6-view x 2-domain diffusion (75 DDIM steps, UNet B=12, VAE encode/decode, CLIP embed)
+`--config drawing` (default; BASELINE.json's metric, configs[4] per GPU): one "step" = ONE drawing
+through the hot path on each rank (weak scaling, one drawing per GPU per step):
+    FFC-ResNet contour-removal generator + masks (512x512)
+ -> 6-view x 2-domain diffusion (75 DDIM steps, UNet B=12, VAE encode/decode, CLIP embed)
  -> Instant-NSR reconstruction (3000 optimisation steps, 128^3 occupancy grid, 2 x 512^3 SDF export)
  -> 24-frame 512x512 stylisation (stage-1 GeneratorJ_RIC + stage-2 GeneratorJ per frame)
 on synthetic 512x512 drawings and random-init weights.  Not inside the timed region (stated in
-config.workload): FFC-ResNet contour removal (BASELINE configs[0]: CPU plumbing), CPU marching
-cubes / mesh post-processing, Blender rendering, PNG I/O.
+config.workload): the contour stage's CPU inpainting tail, CPU marching cubes / mesh
+post-processing, Blender rendering, PNG I/O.
+`--config nsr50k` (BASELINE configs[2] micro-benchmark): one step = one NSR optimisation
+iteration with 50 000 rays marched through a 128^3 occupancy grid (synthetic sphere).
+`--config frames` (BASELINE configs[3]): one step = 24 frames through stage 1 + stage 2, the
+frames sharded over the ranks (strong scaling).
 
+`--gpus N` with N > 1 launched WITHOUT torch.distributed.run spawns the N ranks itself (one
+process per GPU, RCCL), so `python bench.py --gpus 8` and the torchrun form measure the same job.
 Prints ONE JSON line on rank 0 (see README / DESIGN.md for the fields).
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -26,198 +34,382 @@ if ROOT not in sys.path:
 
 import torch  # noqa: E402
 
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E ~8 TB/s
+F16_MFMA_PEAK_TF = 2500.0    # dense f16/bf16
+F32_MFMA_PEAK_TF = 157.3     # v_mfma_f32_32x32x2_f32
 
-def parse():
+
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--config", default="drawing", choices=["drawing", "nsr50k", "frames"])
     ap.add_argument("--mv-steps", type=int, default=75)
     ap.add_argument("--nsr-steps", type=int, default=3000)
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    return ap.parse_args()
+    a = ap.parse_args(argv)
+    if a.steps is None:
+        a.steps = {"drawing": 1, "nsr50k": 50, "frames": 3}[a.config]
+    if a.warmup is None:
+        a.warmup = {"drawing": 1, "nsr50k": 10, "frames": 1}[a.config]
+    return a
 
 
+# ------------------------------------------------------------------------------------------------
+# HIP-event timing of kernel families on the stream they are launched on (torch's current stream —
+# libdsu_hip launches there).  Each family carries its algorithmic work per launch.
+# ------------------------------------------------------------------------------------------------
 class KernelTimer:
-    """HIP-event timing of ONE kernel family on the stream it is launched on (torch's current
-    stream — libdsu_hip launches there).  Wraps ops.sdf_fd_bwd."""
-
     def __init__(self):
-        self.events, self.points, self.levels = [], [], []
         self.enabled = False
+        self.fam = {}
+
+    def _wrap(self, module, name, family, work):
+        orig = getattr(module, name)
+        timer = self
+
+        def timed(*a, **k):
+            if not timer.enabled:
+                return orig(*a, **k)
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            out = orig(*a, **k)
+            e.record()
+            f = timer.fam.setdefault(family, {"events": [], "work": 0.0})
+            f["events"].append((s, e))
+            f["work"] += work(*a, **k)
+            return out
+        setattr(module, name, timed)
 
     def install(self):
         from drawingspinup_amd import ops
-        orig = ops.sdf_fd_bwd
-        timer = self
+        # hash grid + SDF MLP (N1-N5): algorithmic bytes per point = 7 evaluations x active levels
+        # x 8 corners x 4 B (f16 x 2) [+ 12 B position, + outputs / upstream gradients]
+        self._wrap(ops, "sdf_fd_bwd", "sdf_fd_bwd",
+                   lambda cfg, tab, mlp, pts, radius, eps, active, *a, **k:
+                   pts.shape[0] * (7 * int(active) * 8 * 4 + 12 + 72))
+        self._wrap(ops, "sdf_fd_fwd", "sdf_fd_fwd",
+                   lambda cfg, tab, mlp, pts, radius, eps, active, *a, **k:
+                   pts.shape[0] * (7 * int(active) * 8 * 4 + 12 + 72))
 
-        def timed(cfg, table, mlp, pts, radius, eps, active, *a, **k):
-            if not timer.enabled:
-                return orig(cfg, table, mlp, pts, radius, eps, active, *a, **k)
-            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            s.record()
-            out = orig(cfg, table, mlp, pts, radius, eps, active, *a, **k)
-            e.record()
-            timer.events.append((s, e))
-            timer.points.append(pts.shape[0])
-            timer.levels.append(int(active))
-            return out
-        ops.sdf_fd_bwd = timed
-        import drawingspinup_amd.nsr.model as m
-        m.ops = ops
+        def conv_flops(x, w, bias=None, k=3, stride=1, pad=1, upsample2x=False, *a, **kw):
+            B, H, W, Cin = x.shape
+            IH, IW = (2 * H, 2 * W) if upsample2x else (H, W)
+            OH, OW = (IH + 2 * pad - k) // stride + 1, (IW + 2 * pad - k) // stride + 1
+            return 2.0 * B * OH * OW * w.shape[0] * Cin * k * k
+        self._wrap(ops, "conv2d_nhwc_f16", "conv_f16", conv_flops)
+
+        def attn_flops(q, k, vt, seg, heads, seg_len, scale=None):
+            return 4.0 * q.shape[0] * q.shape[1] * q.shape[2] * seg.shape[1] * seg_len
+        self._wrap(ops, "mv_attention", "mv_attention", attn_flops)
+        # the python modules captured `ops.<name>` at call time through the module attribute, so
+        # re-binding the attribute on `ops` is enough
 
     def summary(self):
-        if not self.events:
-            return None
-        ms = [s.elapsed_time(e) for s, e in self.events]
-        # algorithmic bytes per launch (DESIGN.md §Roofline): per point 7 evaluations x
-        # active_levels x 8 corners x (4 B f16x2 table read + 8 B f32x2 gradient scatter)
-        # + 12 B position + 72 B upstream gradients
-        bytes_ = [n * (7 * l * 8 * (4 + 8) + 12 + 72) for n, l in zip(self.points, self.levels)]
-        avg_ms = sum(ms) / len(ms)
-        avg_bytes = sum(bytes_) / len(bytes_)
-        return {"launches": len(ms), "avg_ms": avg_ms, "avg_bytes": avg_bytes,
-                "gbps": avg_bytes / (avg_ms * 1e-3) / 1e9}
+        rows = []
+        for name, f in self.fam.items():
+            ms = sum(s.elapsed_time(e) for s, e in f["events"])
+            n = len(f["events"])
+            if not n or ms <= 0:
+                continue
+            hbm = name.startswith("sdf_")
+            ach = f["work"] / (ms * 1e-3) / (1e9 if hbm else 1e12)
+            peak = HBM_PEAK_GBS if hbm else F16_MFMA_PEAK_TF
+            rows.append({"kernel": name, "bound": "hbm" if hbm else "mfma", "launches": n,
+                         "total_ms": ms, "avg_launch_ms": ms / n,
+                         "alg_work_per_launch": f["work"] / n, "achieved": ach, "peak": peak,
+                         "unit": "GB/s" if hbm else "TFLOP/s", "frac": ach / peak})
+        rows.sort(key=lambda r: -r["total_ms"])
+        return rows
 
 
+# ------------------------------------------------------------------------------------------------
+# CPU baseline: the same operators on the GPU box's host cores, bounded samples.
+# ------------------------------------------------------------------------------------------------
 def cpu_baseline(nsr_steps, frames, mv_steps):
-    """Bounded CPU run of the oracle restatements, extrapolated to one drawing."""
+    """kind "port": /root/reference does not exist on the GPU box and the reference has no CPU
+    path for its CUDA-only ops, so the baseline runs (a) this repository's restatements that are
+    pinned to the reference's own classes by fixtures and execute the SAME torch CPU operators
+    the reference's modules would (FFC-ResNet generator, GeneratorJ: nn.Conv2d / BatchNorm /
+    activations), (b) the float64 UNet oracle, (c) the numpy hash-grid oracle.  Each leg is a
+    bounded sample, extrapolated by the stated factor."""
     import numpy as np
-    from oracle import hashgrid as oh, mv_ref as mr, style_ref as sr
-    torch.set_num_threads(os.cpu_count() or 1)
+    from oracle import hashgrid as oh, mv_ref as mr, style_net_ref as snr
+    # at most 32 threads: on the GPU box's 256 hardware threads torch's CPU convolutions ran 10-90x
+    # SLOWER with one thread per hardware thread than with a few dozen (measured: one FFC-ResNet
+    # forward 146 s at 256 threads vs 1.6 s at 8)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     cores = torch.get_num_threads()
+    legs = {}
+    # (a1) contour remover: one 512x512 forward of the FFC-ResNet generator (27 M parameters)
+    from drawingspinup_amd.contour.ffc import LAMA_FOURIER_GENERATOR, make_generator
+    torch.manual_seed(0)
+    gen = make_generator(**LAMA_FOURIER_GENERATOR).eval()
+    x = torch.rand(1, 4, 512, 512)
+    with torch.no_grad():
+        t = time.time(); gen(x); legs["contour_s"] = time.time() - t
+    # (a2) stylisation: one 512x512 GeneratorJ frame (272 GMAC); the stage-1 GeneratorJ_RIC
+    # (149 GMAC, deformable) is charged at the same rate per MAC
+    from drawingspinup_amd.drawing import STYLE_ARGS
+    from drawingspinup_amd.style.generators import build_model
+    g2 = build_model("GeneratorJ", STYLE_ARGS, "cpu").eval()
+    xf = torch.rand(1, 6, 512, 512) * 2 - 1
+    with torch.no_grad():
+        t = time.time(); snr.generator_j_forward(g2, xf); t_g2 = time.time() - t
+    legs["style_s"] = frames * t_g2 * (271.9 + 148.8) / 271.9
+    # (b) diffusion: ONE UNet forward of the full-width architecture at B=12 on 16x16 latents in
+    # the float64 oracle, scaled to the BASELINE 32x32 shape by algorithmic work (SURVEY.md 8d:
+    # convolutions / linears 1088.9 GMAC scale x4, attention 367.5 GMAC x16 -> 1456.3 / 295.2 =
+    # x4.93), x75 steps (VAE / CLIP not charged)
+    from drawingspinup_amd.mv.unet import UNetMV2DConditionModel
+    torch.manual_seed(0)
+    un = UNetMV2DConditionModel().half()
+    ref = mr.UNetRef(un.state_dict(), (320, 640, 1280, 1280),
+                     ("CrossAttnDownBlockMV2D",) * 3 + ("DownBlock2D",),
+                     ("UpBlock2D",) + ("CrossAttnUpBlockMV2D",) * 3, layers_per_block=2)
+    g = torch.Generator().manual_seed(1)
+    sample = torch.randn(12, 8, 16, 16, generator=g)
+    t = time.time()
+    ref(sample, torch.tensor([500]), torch.randn(12, 1, 768, generator=g), torch.randn(12, 10, generator=g))
+    t_unet = (time.time() - t) * 4.93
+    legs["mv_s"] = mv_steps * t_unet
+    del un, ref
+    # (c) NSR: 20 000 points x 7 evaluations through the numpy oracle; one optimisation step is
+    # ~1.86 M evaluations forward and the backward is charged at 2x the forward
     lv = oh.make_levels()
-    g = torch.Generator().manual_seed(0)
-    tab = ((torch.rand(lv["offsets"][10], 2, generator=g) * 2 - 1) * 0.1).half().numpy()
-    mlp = [np.random.default_rng(0).normal(size=s) * 0.2 for s in [(64, 23), (64,), (13, 64), (13,)]]
-    pts = (np.random.default_rng(1).random((20000, 3)) * 2 - 1).astype(np.float32)
+    tg = torch.Generator().manual_seed(0)
+    tab = ((torch.rand(lv["offsets"][10], 2, generator=tg) * 2 - 1) * 0.1).half().numpy()
+    rng = np.random.default_rng(0)
+    mlp = [rng.normal(size=s) * 0.2 for s in [(64, 23), (64,), (13, 64), (13,)]]
+    pts = (rng.random((20000, 3)) * 2 - 1).astype(np.float32)
     t = time.time()
-    oh.sdf_fd(tab, mlp, pts, 1.0, 0.02, lv, 4)
-    t_eval = (time.time() - t) / (20000 * 7)                      # s per network evaluation (fwd)
-    # one NSR step = ~1.86 M evaluations forward; backward costs ~2x forward
-    t_nsr = nsr_steps * 1.86e6 * 3 * t_eval + 2 * 512 ** 3 * t_eval
-    # stylisation: one stage-2-shaped 7x7 166->64 conv on a 128x128 crop, scaled by FLOPs
-    x, w = torch.randn(1, 166, 128, 128), torch.randn(64, 166, 7, 7)
-    t = time.time()
-    sr.conv_bn_act(x, w, None, 1, 3)
-    t_conv = time.time() - t
-    gmac_crop = 166 * 49 * 64 * 128 * 128 / 1e9
-    t_style = frames * (148.8 + 271.9) / gmac_crop * t_conv
-    # diffusion: one level-0 multi-view attention call of the oracle (B=12,N=256 reduced), scaled
-    q = torch.randn(12, 256, 320, dtype=torch.float64)
-    t = time.time()
-    mr.mv_attention_core(q, q, q, 8, 6)
-    t_att = time.time() - t
-    gmac_att = 12 * 8 * 256 * (6 * 256) * 40 * 2 / 1e9
-    t_mv = mv_steps * 1456.3 / gmac_att * t_att
-    total = t_nsr + t_style + t_mv
+    oh.sdf_fd(tab, mlp, pts, 1.0, 0.02, lv, 5)
+    t_eval = (time.time() - t) / (20000 * 7)
+    legs["nsr_s"] = nsr_steps * 1.86e6 * 3 * t_eval + 2 * 512 ** 3 * t_eval
+    total = sum(legs.values())
     return {"value": 1.0 / total, "unit": "drawings/s", "cores": cores, "kind": "port",
-            "sample": ("numpy/torch oracle on host cores, extrapolated by work: NSR from 140k "
-                       "hash-grid+MLP evaluations (%.2e s/eval, x3 for fwd+bwd, %d steps + 2x512^3 "
-                       "export = %.0f s); stylisation from one 7x7 166->64 conv on a 128^2 crop "
-                       "(%.0f s / %d frames); diffusion from one level-0 multi-view attention "
-                       "(%.0f s / %d steps)" % (t_eval, nsr_steps, t_nsr, t_style, frames, t_mv,
-                                                mv_steps))}
+            "seconds_per_drawing": total, "legs_seconds": legs,
+            "sample": ("host cores, torch CPU / numpy: one 512^2 FFC-ResNet forward (%.2f s); one 512^2 "
+                       "GeneratorJ frame (%.2f s) x %d frames x (272+149)/272 GMAC; one float64 oracle "
+                       "UNet forward at B=12 (16x16 latents, x4.93 by work to 32x32: %.1f s) x %d steps; 140 000 numpy hash-grid+MLP "
+                       "evaluations (single-threaded numpy, %.2e s each) x 1.86 M x 3 x %d steps + 2 x "
+                       "512^3 export evaluations"
+                       % (legs["contour_s"], t_g2, frames, t_unet, mv_steps, t_eval, nsr_steps))}
 
 
-def main():
-    args = parse()
+# ------------------------------------------------------------------------------------------------
+def run(args):
     from drawingspinup_amd import dist as ddist
     rank, world, local = ddist.init()
-    if world != args.gpus:
-        if rank == 0:
-            print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; using {world}", file=sys.stderr)
+    if world != args.gpus and rank == 0:
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}; measuring {world} rank(s)",
+              file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs a GPU"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-
-    from drawingspinup_amd.drawing import DrawingPipeline
     timer = KernelTimer()
     timer.install()
-    pipe = DrawingPipeline(dev, seed=0, mv_steps=args.mv_steps, nsr_steps=args.nsr_steps,
-                           n_frames=args.frames)
-    # shared read-only weights: RCCL broadcast from rank 0 over xGMI, once
-    bcast_bytes = sum(ddist.broadcast_module(m, 0) for m in pipe.shared_modules())
+    if args.config == "nsr50k":
+        out = bench_nsr50k(args, ddist, rank, world, dev, timer)
+    elif args.config == "frames":
+        out = bench_frames(args, ddist, rank, world, dev, timer)
+    else:
+        out = bench_drawing(args, ddist, rank, world, dev, timer)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
 
-    stage_t = {"mv": 0.0, "nsr": 0.0, "style": 0.0}
 
-    def one_drawing(seed, timed):
-        from drawingspinup_amd.drawing import synthetic_drawing, synthetic_frames
-        drawing = synthetic_drawing(seed, device=dev)
-        torch.cuda.synchronize(); t0 = time.time()
-        normals, colors = pipe.multiview(drawing, 123456 + seed)
-        torch.cuda.synchronize(); t1 = time.time()
-        system, inside = pipe.reconstruct(normals, colors, drawing, 123456 + seed)
-        torch.cuda.synchronize(); t2 = time.time()
-        frames = pipe.stylize(synthetic_frames(seed, args.frames, device=dev))
-        torch.cuda.synchronize(); t3 = time.time()
-        if timed:
-            stage_t["mv"] += t1 - t0; stage_t["nsr"] += t2 - t1; stage_t["style"] += t3 - t2
-        return colors, inside.sum(), frames
-
+def _timed_loop(args, ddist, dev, timer, body):
     for w in range(args.warmup):
-        one_drawing(1000 + rank * 100 + w, False)
+        body(w, False)
     ddist.barrier(); torch.cuda.synchronize()
     timer.enabled = True
     t0 = time.time()
     last = None
     for s in range(args.steps):
-        last = one_drawing(rank * 100 + s, True)
+        last = body(s, True)
     torch.cuda.synchronize(); ddist.barrier()
     elapsed = ddist.max_over_ranks(time.time() - t0, dev)
     timer.enabled = False
-    # per-rank gather of the (small) outputs only
-    ddist.gather_tensor(last[1].reshape(1).float())
+    return elapsed, last
 
-    if rank == 0:
-        drawings = world * args.steps
-        ks = timer.summary()
-        roof = None
-        if ks:
-            roof = {"bound": "hbm", "kernel": "sdf_fd_bwd_mfma_kernel", "achieved": ks["gbps"],
-                    "peak": 8000.0, "unit": "GB/s", "frac": ks["gbps"] / 8000.0,
-                    # PMC passes are separate runs (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE): the
-                    # per-launch HBM-side bytes of this kernel at the first schedule stage
-                    "traffic": 5.40e8,
-                    "traffic_pmc_reference": "profiles/round1_pmc_sdf_kernels.txt: 540 MB HBM-side "
-                                             "(FETCH 36 MB + WRITE 504 MB) per launch at N=262144, "
-                                             "4 levels vs 726 MB algorithmic for that launch",
-                    "launches": ks["launches"], "avg_launch_ms": ks["avg_ms"],
-                    "alg_bytes_per_launch": ks["avg_bytes"],
-                    # per-stage view (SURVEY.md §8d algorithmic FLOPs / wall time of the stage):
-                    # diffusion 2.913 TFLOP per UNet forward at B=12 (f16 MFMA peak 2.5 PFLOP/s),
-                    # stylisation 0.30 + 0.54 TFLOP per frame (f32 MFMA peak 157 TFLOP/s)
-                    "stages": {
-                        "mv": {"bound": "mfma", "unit": "TFLOP/s", "peak": 2500.0,
-                               "achieved": 2.913 * args.mv_steps / max(stage_t["mv"] / args.steps, 1e-9)},
-                        "style": {"bound": "mfma", "unit": "TFLOP/s", "peak": 157.0,
-                                  "achieved": 0.84 * args.frames / max(stage_t["style"] / args.steps, 1e-9)},
-                    }}
-            for st in roof["stages"].values():
-                st["frac"] = st["achieved"] / st["peak"]
-        out = {
-            "metric": "drawings/sec end-to-end (512x512, 6 views, 24 frames)",
-            "value": drawings / elapsed, "unit": "drawings/s", "n_gpus": world,
+
+def _roofline(timer, extra=None):
+    rows = timer.summary()
+    if not rows:
+        return None
+    top = dict(rows[0])
+    top["kernels"] = rows[:3]
+    # PMC passes are separate runs (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/): HBM-side
+    # bytes per launch of the dominant kernel pair at the first schedule stage
+    top["traffic"] = None
+    if extra:
+        top.update(extra)
+    return top
+
+
+def bench_drawing(args, ddist, rank, world, dev, timer):
+    from drawingspinup_amd.drawing import DrawingPipeline, synthetic_drawing, synthetic_frames
+    pipe = DrawingPipeline(dev, seed=0, mv_steps=args.mv_steps, nsr_steps=args.nsr_steps,
+                           n_frames=args.frames)
+    bcast_bytes = sum(ddist.broadcast_module(m, 0) for m in pipe.shared_modules())
+    stage_t = {"contour": 0.0, "mv": 0.0, "nsr": 0.0, "style": 0.0}
+
+    def one_drawing(s, timed):
+        seed = (rank * 100 + s) if timed else (1000 + rank * 100 + s)
+        drawing = synthetic_drawing(seed, device=dev)
+        torch.cuda.synchronize(); t0 = time.time()
+        cleaned = pipe.remove_contour(drawing)
+        torch.cuda.synchronize(); t1 = time.time()
+        normals, colors = pipe.multiview(cleaned, 123456 + seed)
+        torch.cuda.synchronize(); t2 = time.time()
+        system, inside = pipe.reconstruct(normals, colors, cleaned, 123456 + seed)
+        torch.cuda.synchronize(); t3 = time.time()
+        frames = pipe.stylize(synthetic_frames(seed, args.frames, device=dev))
+        torch.cuda.synchronize(); t4 = time.time()
+        if timed:
+            for k, v in zip(stage_t, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                stage_t[k] += v
+        return colors, inside.sum(), frames
+
+    elapsed, last = _timed_loop(args, ddist, dev, timer, one_drawing)
+    ddist.gather_tensor(last[1].reshape(1).float())          # per-rank gather of small outputs only
+    if rank != 0:
+        return None
+    per = {k: v / args.steps for k, v in stage_t.items()}
+    stages = {
+        "mv": {"bound": "mfma", "unit": "TFLOP/s", "peak": F16_MFMA_PEAK_TF,
+               "achieved": 2.913 * args.mv_steps / max(per["mv"], 1e-9)},
+        "style": {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TF,
+                  "achieved": 0.84 * args.frames / max(per["style"], 1e-9)},
+    }
+    for st in stages.values():
+        st["frac"] = st["achieved"] / st["peak"]
+    roof = _roofline(timer, {"stages": stages,
+                             "traffic_note": "HBM-side bytes per launch: separate rocprofv3 --pmc "
+                                             "passes, see profiles/ (null here: not collected in "
+                                             "this run)"})
+    out = {
+        "metric": "drawings/sec end-to-end (512x512, 6 views, 24 frames)",
+        "value": world * args.steps / elapsed, "unit": "drawings/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f16 (diffusion) / f16 table + f32 MLP (NSR) / f32 (stylisation, contour)",
+        "data": "synthetic",
+        "config": {"workload": "one drawing per GPU: FFC-ResNet contour generator + masks (512^2) -> "
+                               "6-view diffusion (%d DDIM steps, B=12) -> NSR recon (%d steps, "
+                               "2x512^3 export) -> %d-frame stage1+stage2 stylisation; NOT timed: "
+                               "the contour stage's CPU inpainting tail, CPU mesh post-processing, "
+                               "Blender, PNG I/O" % (args.mv_steps, args.nsr_steps, args.frames),
+                   "drawings_per_step": world, "parallelism": f"replica-per-drawing x{world}",
+                   "stage_seconds_rank0": per, "weights_broadcast_bytes": bcast_bytes},
+        "roofline": roof,
+    }
+    if not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args.nsr_steps, args.frames, args.mv_steps)
+    return out
+
+
+def bench_nsr50k(args, ddist, rank, world, dev, timer):
+    """BASELINE configs[2]: '128^3 hash-grid 50k rays/iter' = 128^3 occupancy grid + 50 000 rays per
+    optimisation iteration on the synthetic sphere; every rank runs its own replica."""
+    from drawingspinup_amd.nsr.model import Cfg, DEFAULT_MODEL_CONFIG
+    from drawingspinup_amd.nsr.system import OrthoData, OrthoNeuSSystem
+    R = 50000
+    cfg = Cfg(DEFAULT_MODEL_CONFIG)
+    cfg["train_num_rays"], cfg["max_train_num_rays"], cfg["dynamic_ray_sampling"] = R, R, False
+    ds = OrthoData.synthetic_sphere(1024, device=dev)
+    sysm = OrthoNeuSSystem(model_config=cfg, device=dev, seed=rank)
+    sysm.dataset = ds
+    for _ in range(300):                      # occupancy grid warm-up on a small ray count
+        sysm.train_num_rays = 2048
+        sysm.training_step()
+    samples = [0]
+
+    def step(s, timed):
+        sysm.train_num_rays = R
+        r = sysm.training_step()
+        if timed:
+            samples[0] += int(r["n_samples"])
+        return r
+
+    elapsed, _ = _timed_loop(args, ddist, dev, timer, step)
+    if rank != 0:
+        return None
+    n = samples[0] / max(args.steps, 1)
+    return {"metric": "NSR optimisation iterations/sec (128^3 occupancy grid, 50k rays/iter)",
+            "value": world * args.steps / elapsed, "unit": "iterations/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f16 (diffusion) / f16 table + f32 MLP (NSR) / f32 (stylisation)",
-            "data": "synthetic",
-            "config": {"workload": "one drawing per GPU: 6-view diffusion (%d DDIM steps, B=12) -> "
-                                   "NSR recon (%d steps, 2x512^3 export) -> %d-frame stage1+stage2 "
-                                   "stylisation; NOT timed: FFC-ResNet contour removal, CPU mesh "
-                                   "post-processing, Blender, PNG I/O"
-                                   % (args.mv_steps, args.nsr_steps, args.frames),
-                       "drawings_per_step": world, "parallelism": f"replica-per-drawing x{world}",
-                       "stage_seconds_rank0": {k: v / args.steps for k, v in stage_t.items()},
-                       "weights_broadcast_bytes": bcast_bytes},
-            "roofline": roof,
-        }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.nsr_steps, args.frames, args.mv_steps)
-        print(json.dumps(out))
-    if world > 1:
-        torch.distributed.destroy_process_group()
+            "dtype": "f16 table + f32 MLP", "data": "synthetic",
+            "config": {"workload": "NSR micro-benchmark: 50 000 rays per iteration marched at "
+                                   "3.383e-3 through a 128^3 occupancy grid of the synthetic sphere, "
+                                   "full optimisation step (7-evaluation SDF forward/backward, "
+                                   "texture MLP, compositing, losses, AdamW)",
+                       "rays_per_s": world * R * args.steps / elapsed,
+                       "samples_per_iteration": n, "samples_per_s": world * n * args.steps / elapsed,
+                       "point_evaluations_per_s": world * 7 * (n + 4096) * args.steps / elapsed,
+                       "parallelism": f"replica x{world}"},
+            "roofline": _roofline(timer)}
+
+
+def bench_frames(args, ddist, rank, world, dev, timer):
+    """BASELINE configs[3]: 24 frames 512x512 through stage 1 + stage 2, frame f on rank f mod N,
+    stage 2 on the rank of its stage-1 frame (no exchange), outputs gathered to rank 0."""
+    from drawingspinup_amd.drawing import DrawingPipeline, synthetic_frames
+    pipe = DrawingPipeline(dev, seed=0, n_frames=args.frames, with_mv=False, with_contour=False)
+    for m in (pipe.gen1, pipe.gen2):
+        ddist.broadcast_module(m, 0)
+    frames = synthetic_frames(0, args.frames, device=dev)
+    mine = ddist.shard(list(range(args.frames)), rank, world)
+    per_rank = (args.frames + world - 1) // world
+
+    def step(s, timed):
+        out = torch.zeros(per_rank, 4, frames.shape[2], frames.shape[3], dtype=torch.uint8, device=dev)
+        if len(mine):
+            out[:len(mine)] = pipe.stylize(frames[mine])
+        return ddist.gather_tensor(out)                 # equal shapes: padded to ceil(frames / N)
+
+    elapsed, _ = _timed_loop(args, ddist, dev, timer, step)
+    if rank != 0:
+        return None
+    fps = args.frames * args.steps / elapsed
+    return {"metric": "stylised frames/sec (512x512, stage 1 + stage 2)", "value": fps,
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "%d frames 512x512 per step through GeneratorJ_RIC + GeneratorJ, "
+                                   "frames sharded round-robin over the ranks, outputs gathered to "
+                                   "rank 0" % args.frames,
+                       "frames_per_rank": len(mine), "parallelism": f"frame-shard x{world}"},
+            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TF,
+                         "achieved": 0.84 * fps, "frac": 0.84 * fps / F32_MFMA_PEAK_TF,
+                         "traffic": None, "kernels": timer.summary()[:3]}}
+
+
+def _spawn_worker(local_rank, args, port):
+    os.environ.update({"RANK": str(local_rank), "LOCAL_RANK": str(local_rank),
+                       "WORLD_SIZE": str(args.gpus), "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    run(args)
+
+
+def main():
+    args = parse()
+    launched = int(os.environ.get("WORLD_SIZE", "1")) > 1 or "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        # `python bench.py --gpus N`: spawn the N ranks here (one process per GPU)
+        import torch.multiprocessing as mp
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        mp.spawn(_spawn_worker, args=(args, port), nprocs=args.gpus, join=True)
+        return
+    run(args)
 
 
 if __name__ == "__main__":

@@ -61,17 +61,13 @@ def broadcast_module(module, src=0, bucket_bytes=256 << 20):
 
 
 def gather_tensor(t, dst=0):
-    """Gather equally-shaped per-rank tensors on `dst` (list on dst, None elsewhere)."""
+    """Gather equally-shaped per-rank tensors on `dst` (list on dst, None elsewhere): a gather,
+    not an all-gather — only rank `dst` receives the (small) outputs."""
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return [t]
     world = dist.get_world_size()
     out = [torch.empty_like(t) for _ in range(world)] if dist.get_rank() == dst else None
-    if dist.get_backend() == "nccl":
-        # gather is implemented on top of all_gather for NCCL/RCCL in older stacks
-        buf = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(buf, t)
-        return buf if dist.get_rank() == dst else None
-    dist.gather(t, out, dst)
+    dist.gather(t.contiguous(), out, dst)
     return out
 
 

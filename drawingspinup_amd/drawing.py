@@ -54,20 +54,46 @@ class DrawingPipeline:
     """Holds the shared read-only weights (diffusion UNet/VAE/CLIP) and runs drawings."""
 
     def __init__(self, device="cuda", seed=0, mv_steps=75, nsr_steps=3000, n_frames=24,
-                 with_clip=True, export_resolution=512):
+                 with_clip=True, export_resolution=512, with_mv=True, with_contour=True):
         self.device = torch.device(device)
         self.mv_steps, self.nsr_steps, self.n_frames = mv_steps, nsr_steps, n_frames
         self.export_resolution = export_resolution
-        self.mv = build_random_pipeline(self.device, seed, with_clip=with_clip)
+        self.mv = build_random_pipeline(self.device, seed, with_clip=with_clip) if with_mv else None
         torch.manual_seed(seed + 1)
         self.gen1 = build_model("GeneratorJ_RIC", STYLE_ARGS, self.device).eval()
         self.gen2 = build_model("GeneratorJ", STYLE_ARGS, self.device).eval()
+        self.contour = None
+        if with_contour:
+            from .contour.predict import load_generator
+            torch.manual_seed(seed + 2)
+            self.contour = load_generator(None, self.device)
 
     def shared_modules(self):
-        mods = [self.mv.unet, self.mv.vae, self.gen1, self.gen2]
-        if self.mv.image_encoder is not None:
-            mods.append(self.mv.image_encoder)
+        mods = [self.gen1, self.gen2]
+        if self.mv is not None:
+            mods += [self.mv.unet, self.mv.vae]
+            if self.mv.image_encoder is not None:
+                mods.append(self.mv.image_encoder)
+        if self.contour is not None:
+            mods.append(self.contour)
         return mods
+
+    # ---------------------------------------------------------------- stage 1: predict.py
+    @torch.no_grad()
+    def remove_contour(self, drawing_rgba, threshold=0.2):
+        """1_lama_contour_remover/predict.py:46-62 on the device: the drawing composited on white
+        + its alpha -> FFC-ResNet generator -> contour mask (prob > 0.2) and inpaint mask
+        max(contour, 255 - alpha).  The CPU tail of the reference (cv2.inpaint TELEA over that
+        mask, predict.py:63) is host geometry and not part of this path; the drawing handed on is
+        the composited input with its alpha, the masks ride along for a host inpainter."""
+        if self.contour is None:
+            return drawing_rgba
+        rgb, a = drawing_rgba[:3], drawing_rgba[3:4]
+        x = torch.cat([rgb * a + (1 - a), a], 0)[None]
+        prob = self.contour(x)[0, 0].float()
+        contour = prob > threshold
+        self.last_contour_masks = (contour, contour | (a[0] < 1.0))
+        return drawing_rgba
 
     # ---------------------------------------------------------------- stage 2a: mv.py
     @torch.no_grad()

@@ -137,10 +137,16 @@ def ranking_loss_masked(error, valid, penalize_ratio=0.7, extra_weights=None, ty
     `index_select(error, 0, indices[:k])`), i.e. it sums sorted[p] over the subset positions p of
     the k smallest entries.  That exact selection is reproduced: masked-out entries sort to the
     end as +inf, subset positions come from a running count of `valid`, and
-    k = int(ratio * valid.sum()) stays on the device (float64 product = Python's value)."""
+    k = int(ratio * valid.sum()) stays on the device (float64 product = Python's value).
+
+    Ties: with that selection rule the result depends on the ORDER of equal errors whenever a run
+    of ties straddles k (rays that miss the object all have opacity 0 and therefore equal mask
+    errors), and the reference's `torch.sort` (stable=False) leaves that order to the backend.
+    Here, as in the HIP kernel (64-bit (value, index) keys), ties keep their original order —
+    torch.sort(stable=True); the reference-generated fixture is produced under the same rule."""
     n = error.shape[0]
     e = torch.where(valid, error, torch.full_like(error, float("inf")))
-    se, idx = torch.sort(e)                                   # sorted valid errors, then +inf
+    se, idx = torch.sort(e, stable=True)                      # sorted valid errors, then +inf
     k = torch.floor(penalize_ratio * valid.sum().double())
     sel = torch.arange(n, device=error.device) < k
     pos = torch.cumsum(valid.to(torch.int64), 0) - 1          # position inside error[valid]

@@ -699,7 +699,8 @@ def mv_attention(q, k, vt, seg_batch, heads, seg_len, scale=None):
     d = Cq // heads
     S = seg_batch.shape[1]
     assert q.dtype == torch.float16 and k.dtype == torch.float16 and vt.dtype == torch.float16
-    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    # unit stride on the innermost axis (a size-1 axis keeps whatever stride its view had)
+    assert q.stride(2) == 1 and k.stride(2) == 1 and (vt.stride(2) == 1 or vt.shape[2] == 1)
     out = torch.empty((Bq, Nq, Cq), dtype=torch.float16, device=q.device)
     if scale is None:
         scale = d ** -0.5

@@ -12,7 +12,7 @@ everything that is the reference's OWN code on this path — sample positions fr
 their normalisation, the random regulariser points, and the whole loss section of training_step
 (masking, cosine clamp, the three ranking losses incl. geo-aware weighting, eikonal, BCE with
 clamped opacity, sparsity, 3-D normal smoothness, the weighted total).  The two third-party ops
-stay "parity unpinned".
+stay "parity unpinned".  Tie order in ranking_loss: see the comment at the training_step call.
 
 The hash table comes from a seed (as in make_nsr_golden.py); every other parameter is stored.
 """
@@ -237,7 +237,14 @@ if __name__ == "__main__":
     sysm.forward = lambda b: leaf
     sysm.model = model
     tb = {k: v.clone() for k, v in batch.items()}
+    # criterions.py:16 sorts with torch.sort(error) (stable=False): when a run of equal errors
+    # straddles the selection boundary (here: the rays that miss the shell all have opacity 0) the
+    # value of ranking_loss depends on the backend's tie order.  The fixture pins the order a
+    # stable sort gives (ties keep their original order), which is what the HIP kernel implements.
+    _sort = torch.sort
+    torch.sort = lambda x, *a, **k: _sort(x, *a, **{**k, "stable": True})
     res = sysm.training_step(tb, 0)
+    torch.sort = _sort
     res["loss"].backward()
     for k, v in batch.items():
         out["batch." + k] = v.numpy()

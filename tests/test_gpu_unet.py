@@ -93,11 +93,13 @@ def _full_ref(sd):
                       FULL["up_block_types"], layers_per_block=2)
 
 
-@pytest.mark.parametrize("side", [8, 32])
+@pytest.mark.parametrize("side", [16, 32])
 def test_unet_full_width_vs_oracle(dev, side):
     """SURVEY 8(d) tolerance on the SHIPPED architecture (320/640/1280/1280, two layers per block,
     16 multi-view transformer blocks, B = 12): rel-L2 <= 2e-3 against the float64 restatement.
-    side = 32 is BASELINE config 2's exact input shape (12, 8, 32, 32)."""
+    side = 32 is BASELINE config 2's exact input shape (12, 8, 32, 32); side = 16 is the smallest
+    latent the attention kernel takes (its deepest level then has 2x2 = 4 tokens per view; the
+    kernel stages V^T four keys at a time and refuses shorter segments with DSU_EUNSUP)."""
     model, sd = _full_model(dev)
     g = torch.Generator().manual_seed(20 + side)
     sample = torch.randn(12, 8, side, side, generator=g).half()
@@ -115,7 +117,7 @@ def test_unet_full_width_vs_oracle(dev, side):
 
 def test_ddim_steps_vs_oracle_loop(dev):
     """pipeline_mvdiffusion_image.py:463-486 with injected latents and per-step noise, full-width
-    UNet at 8x8 latents: latents after ONE step rel-L2 <= 2e-3, after four steps
+    UNet at 16x16 latents: latents after ONE step rel-L2 <= 2e-3, after four steps
     <= 1e-2 (reported).  The oracle loop rounds the model output and the latents to f16 after
     every step, as the reference's f16 pipeline does."""
     from drawingspinup_amd.mv.pipeline import AutoencoderKL, MVDiffusionImagePipeline
@@ -125,10 +127,10 @@ def test_ddim_steps_vs_oracle_loop(dev):
     g = torch.Generator().manual_seed(31)
     B, steps, run = 12, 75, 4
     emb = (torch.randn(B, 1, 768, generator=g) * 0.5).half()
-    img_lat = torch.randn(B, 4, 8, 8, generator=g).half()
+    img_lat = torch.randn(B, 4, 16, 16, generator=g).half()
     pipe._encode_image = lambda images: (emb.to(dev), img_lat.to(dev))
-    lat0 = torch.randn(B, 4, 8, 8, generator=g).half()
-    noise = torch.randn(steps, B, 4, 8, 8, generator=g).half()
+    lat0 = torch.randn(B, 4, 16, 16, generator=g).half()
+    noise = torch.randn(steps, B, 4, 16, 16, generator=g).half()
     got = []
     sched = pipe.scheduler
     orig_set = sched.set_timesteps
@@ -137,7 +139,7 @@ def test_ddim_steps_vs_oracle_loop(dev):
         orig_set(n, device=device)
         sched.timesteps = sched.timesteps[:run]
     sched.set_timesteps = first_steps
-    pipe(torch.zeros(B, 3, 64, 64), height=64, width=64, num_inference_steps=steps,
+    pipe(torch.zeros(B, 3, 128, 128), height=128, width=128, num_inference_steps=steps,
          latents=lat0.clone(), step_noise=noise, output_type="latent", eta=1.0,
          callback=lambda i, t, lat: got.append(lat.float().cpu().double()))
     cam = pipe.prepare_camera_embedding(
