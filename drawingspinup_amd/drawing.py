@@ -113,7 +113,7 @@ class DrawingPipeline:
     def reconstruct(self, normals, colors, drawing_rgba, seed):
         """OrthoDatasetBase from in-memory mv outputs (ortho.py:54-97: 1024^2 images, normals
         from the normal maps rotated to the front camera's world frame, masks), then the NSR
-        optimisation and the 2 x 512^3 SDF export."""
+        optimisation and the export (2 x 512^3 SDF volumes -> smoothing -> marching cubes)."""
         dev = self.device
         size = 1024
         up = lambda t: F.interpolate(t.float(), size=(size, size), mode="bicubic",
@@ -131,8 +131,12 @@ class DrawingPipeline:
         data = OrthoData(col, masks, n_world, poses, dev)
         system = OrthoNeuSSystem(device=dev, seed=seed)
         system.fit(data, max_steps=self.nsr_steps)
-        coarse, fine, vmin, vmax = system.export_levels(self.export_resolution)
-        return system, (fine <= 0)
+        # export (neus_ortho.py:183-200): smoothed binary volumes, front-mask cutting with the
+        # drawing's own alpha (char/mask.png, rotated as ortho.py:155-156), marching cubes, colours
+        front = (F.interpolate(drawing_rgba[3:4][None], size=(size, size), mode="nearest")[0, 0] * 255).to(torch.uint8)
+        mesh = system.export_mesh(torch.rot90(front, k=-1, dims=(0, 1)).contiguous(), self.export_resolution)
+        self.last_mesh = mesh
+        return system, mesh["binary"]
 
     # ---------------------------------------------------------------- stage 3: test_stage1/2.py
     @torch.no_grad()

@@ -1,7 +1,9 @@
 """`python recon.py --uid U [--all]` of the reference (2_charactor_reconstructor/recon.py:44-62):
-3000 optimisation steps, then the 2 x 512^3 SDF export.  The SDF volumes are saved as
-<uid>/mesh/it3000-sdf512_{coarse,fine}.npy; marching cubes / mesh post-processing are CPU geometry
-outside this path."""
+3000 optimisation steps, then the export (neus_ortho.py:183-200): 2 x 512^3 SDF volumes, constrained
+smoothing, front-mask cutting (char/mask.png rotated as ortho.py:155-156), marching cubes, vertex
+colours, written as <uid>/mesh/it3000-mc512-f50000_c.obj.  The CPU geometry steps of save_mesh
+(quadric decimation, thinning, Laplacian smoothing, colour back-projection, shear) are outside this
+path, hence no _r_s_cbp suffix."""
 import argparse
 import json
 import os
@@ -31,13 +33,18 @@ def main(argv=None):
         ds = D.load_mv_prediction(os.path.join(args.data_root, uid, "mv"), dev, args.pose_dir)
         system = OrthoNeuSSystem(device=dev, seed=args.seed)
         system.fit(ds, max_steps=args.max_steps, log_every=500)
-        coarse, fine, vmin, vmax = system.export_levels()
+        front = None
+        fm_path = os.path.join(args.data_root, uid, "char", "mask.png")
+        if os.path.isfile(fm_path):
+            from PIL import Image
+            fm = np.array(Image.open(fm_path).convert("L"))
+            front = torch.from_numpy(np.ascontiguousarray(np.rot90(fm, k=-1))).to(dev)   # cv2.ROTATE_90_CLOCKWISE
+        mesh = system.export_mesh(front)
         out = os.path.join(args.data_root, uid, "mesh")
         os.makedirs(out, exist_ok=True)
-        np.save(os.path.join(out, f"it{system.global_step}-sdf512_coarse.npy"), coarse.cpu().numpy())
-        np.save(os.path.join(out, f"it{system.global_step}-sdf512_fine.npy"), fine.cpu().numpy())
-        np.save(os.path.join(out, f"it{system.global_step}-sdf512_fine_bbox.npy"),
-                torch.stack([vmin, vmax]).cpu().numpy())
+        from ..nsr.mesh import save_obj
+        save_obj(os.path.join(out, system.export_name(front is not None) + ".obj"), mesh["verts"],
+                 mesh["faces"], mesh["vert_colors"])
         torch.save(system.model.state_dict(), os.path.join(out, f"it{system.global_step}.ckpt"))
         print(uid, flush=True)
 

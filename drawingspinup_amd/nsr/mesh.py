@@ -1,0 +1,527 @@
+"""Iso-surface extraction of the NSR export on the device:
+
+    MarchingCubeHelper.forward            instant_nsr/models/geometry.py:50-69
+        binary = (level <= 0) * (front_mask > 127)   ->  mcubes.smooth  ->  mcubes.marching_cubes
+        ->  verts / (resolution - 1)
+    BaseImplicitGeometry.isosurface(_)    geometry.py:83-117   (coarse box -> padded bbox of the
+        coarse mesh's vertices -> fine pass with the front mask)
+    save_mesh (axis convention, scale, OBJ)    instant_nsr/utils/mesh_utils.py:25-73
+
+The reference does this on the host with PyMCubes 0.1.4 and OpenCV (both absent here, sources not
+in the snapshot: PARITY UNPINNED for those two packages).  What is restated, and how:
+
+  * `mcubes.smooth(binary)` -> `smooth_constrained` (the method PyMCubes picks for arrays of at most
+    512^3 voxels): the constrained higher-order smoothing of Lempitsky, "Surface extraction from
+    binary volumes with higher-order smoothness" (CVPR 2010), as PyMCubes implements it: signed
+    Euclidean distance transform (+-0.5 at the boundary voxels), variables = the band |d| < 4,
+    energy |F x|^2 with F the stacked 1-D second differences along the three axes (a neighbour
+    outside the band folds onto the diagonal), weighted-Jacobi iterations (weight 0.5) with the
+    projection x >= lower, x <= upper that keeps every voxel on its side of the surface, energy
+    test every 10 iterations (relative improvement), float64.
+  * `mcubes.marching_cubes(volume, iso)`: x-major / y / z-minor sweep over the cubes, a corner is
+    "below" when value < iso, every grid edge owns ONE vertex (created by the first cube of the
+    sweep that touches it: edges 6, 5, 10 of a cube, the remaining nine only on the low faces of
+    the volume), vertices numbered in creation order, position by linear interpolation along the
+    edge in float64, triangles cube by cube in table order.  Vertex numbering therefore depends
+    only on the volume; the per-cube triangulation table is GENERATED here (see `_build_tables`)
+    because no copy of the classic 256-row table exists in this image: same vertices, same
+    numbering, same surface, but triangle order / fan inside a cube need not equal PyMCubes'.
+  * `cv2.resize(front_mask, (res, res), INTER_CUBIC)`: OpenCV's bicubic kernel (a = -0.75),
+    half-pixel centres, replicated border, rounded and saturated to uint8.
+
+Everything runs as tensor programs on the device (prefix sums over the sweep order instead of the
+serial vertex list); the integer outputs are checked bit for bit against a serial restatement
+(oracle/mcubes_ref.py).  Not here: trimesh quadric decimation (`remesh`, geometry.py:63-64) and
+the thinning / Laplacian smoothing / colour back-projection / shear / uv steps of save_mesh
+(trimesh, igl, mesh_raycast: CPU geometry).
+"""
+import functools
+import math
+import os
+
+import numpy as np
+import torch
+
+# cube corners (Bourke / PyMCubes numbering) and the two corners of each of the 12 edges
+CORNERS = ((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1))
+EDGES = ((0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7))
+# faces as cyclic corner lists
+FACES = ((0, 1, 2, 3), (4, 5, 6, 7), (0, 1, 5, 4), (3, 2, 6, 7), (0, 3, 7, 4), (1, 2, 6, 5))
+# creation order of a cube's vertices in the sweep and the condition under which THIS cube is the
+# first to touch the edge (i, j, k = cube coordinates): edges 6, 5, 10 always, the others only on
+# the low faces of the volume
+CREATE_ORDER = (6, 5, 10, 0, 1, 2, 3, 4, 7, 8, 9, 11)
+# edge -> (axis, (di, dj, dk) of the edge's low corner relative to the cube)
+EDGE_AXIS_OFF = {0: (0, (0, 0, 0)), 2: (0, (0, 1, 0)), 4: (0, (0, 0, 1)), 6: (0, (0, 1, 1)),
+                 3: (1, (0, 0, 0)), 1: (1, (1, 0, 0)), 7: (1, (0, 0, 1)), 5: (1, (1, 0, 1)),
+                 8: (2, (0, 0, 0)), 9: (2, (1, 0, 0)), 11: (2, (0, 1, 0)), 10: (2, (1, 1, 0))}
+
+
+def _edge_of(a, b):
+    for e, (p, q) in enumerate(EDGES):
+        if {p, q} == {a, b}:
+            return e
+    raise KeyError((a, b))
+
+
+def _coplanar(e0, e1):
+    """Do the two cube edges lie on a common cube face (a chord between them runs inside it)?"""
+    s0, s1 = set(EDGES[e0]), set(EDGES[e1])
+    return any(s0 <= set(f) and s1 <= set(f) for f in FACES)
+
+
+def _triangulate(loop):
+    """Triangles (same orientation as `loop`) of a polygon through cube edges.  Of all
+    triangulations, in a fixed enumeration order, the first whose chords avoid the cube's faces:
+    a chord inside a face of an ambiguous configuration could coincide with the chord the
+    neighbouring cube draws there (an edge shared by four triangles)."""
+    n = len(loop)
+    best = None
+
+    def rec(i, j):                       # triangulations of the sub-polygon loop[i..j]
+        if j - i < 2:
+            yield []
+            return
+        for k in range(i + 1, j):
+            for left in rec(i, k):
+                for right in rec(k, j):
+                    yield left + [(i, k, j)] + right
+
+    for tri in rec(0, n - 1):
+        bad = 0
+        for a, b, c in tri:
+            for p, q in ((a, b), (b, c), (a, c)):
+                if (q - p) % n not in (1, n - 1) and _coplanar(loop[p], loop[q]):
+                    bad += 1
+        if best is None or bad < best[0]:
+            best = (bad, tri)
+        if bad == 0:
+            break
+    out = []
+    for a, b, c in best[1]:
+        out += [loop[a], loop[b], loop[c]]
+    return out
+
+
+@functools.lru_cache(maxsize=None)
+def _build_tables():
+    """(edge_table (256,) int32 bit masks, tri_table (256, 3*T) int8 padded with -1).
+
+    For every corner configuration (bit m set = corner m below the iso value) the surface inside the
+    cube is the set of closed polygons through the crossed edges: each cube face contributes one
+    segment between its two crossed edges, or — on a face whose diagonal corners are below — two
+    segments that cut the two below-corners off separately (the choice depends on that face's four
+    corner states only, so the two cubes sharing the face agree: no cracks).  Polygons are walked
+    from their smallest edge, oriented so that the normal points to the below side, and
+    triangulated by `_triangulate`."""
+    pos = np.array(CORNERS, np.float64)
+    mid = np.array([(pos[a] + pos[b]) / 2 for a, b in EDGES])
+    edge_table = np.zeros(256, np.int32)
+    tris = []
+    for c in range(256):
+        below = [(c >> m) & 1 for m in range(8)]
+        mask = 0
+        for e, (a, b) in enumerate(EDGES):
+            if below[a] != below[b]:
+                mask |= 1 << e
+        edge_table[c] = mask
+        adj = {e: [] for e in range(12) if mask >> e & 1}
+        for f in FACES:
+            fe = [_edge_of(f[i], f[(i + 1) % 4]) for i in range(4)]
+            cross = [e for e in fe if mask >> e & 1]
+            if len(cross) == 2:
+                adj[cross[0]].append(cross[1]); adj[cross[1]].append(cross[0])
+            elif len(cross) == 4:
+                for i in range(4):
+                    if below[f[i]]:                      # cut this below-corner off
+                        e0, e1 = fe[i - 1], fe[i]        # its two face edges
+                        adj[e0].append(e1); adj[e1].append(e0)
+        seen, out = set(), []
+        for start in sorted(adj):
+            if start in seen:
+                continue
+            assert len(adj[start]) == 2
+            loop, prev, cur = [start], start, min(adj[start])
+            while cur != start:
+                loop.append(cur)
+                a, b = adj[cur]
+                prev, cur = cur, (b if a == prev else a)
+            seen.update(loop)
+            p = mid[loop]
+            normal = np.zeros(3)
+            for i in range(len(loop)):                   # Newell
+                a, b = p[i], p[(i + 1) % len(loop)]
+                normal += np.cross(a, b)
+            ref = np.zeros(3)
+            for e in loop:
+                a, b = EDGES[e]
+                ref += (pos[a] - pos[b]) if below[a] else (pos[b] - pos[a])
+            if normal @ ref < 0:
+                loop = [loop[0]] + loop[:0:-1]
+            out += _triangulate(loop)
+        tris.append(out)
+    width = max(len(t) for t in tris)
+    tri_table = np.full((256, width), -1, np.int8)
+    for c, t in enumerate(tris):
+        tri_table[c, :len(t)] = t
+    return edge_table, tri_table
+
+
+def tables():
+    return _build_tables()
+
+
+# ------------------------------------------------------------------------------------------------
+# mcubes.marching_cubes
+# ------------------------------------------------------------------------------------------------
+@torch.no_grad()
+def marching_cubes(volume, isovalue=0.0):
+    """volume (X,Y,Z) float on the device -> (verts (N,3) float64 in index units, faces (M,3) int64).
+    Vertex and face ORDER follow the serial x-major sweep (see the module docstring)."""
+    dev = volume.device
+    v = volume.to(torch.float64)
+    X, Y, Z = v.shape
+    assert min(X, Y, Z) >= 2
+    et, tt = tables()
+    edge_table = torch.from_numpy(et).to(dev)
+    tri_table = torch.from_numpy(tt.astype(np.int64)).to(dev)
+    below = v < isovalue
+    cube = torch.zeros((X - 1, Y - 1, Z - 1), dtype=torch.int64, device=dev)
+    for m, (dx, dy, dz) in enumerate(CORNERS):
+        cube += below[dx:X - 1 + dx, dy:Y - 1 + dy, dz:Z - 1 + dz].to(torch.int64) << m
+    active = torch.nonzero((cube != 0) & (cube != 255))           # lexicographic = sweep order
+    na = active.shape[0]
+    if na == 0:
+        return (torch.zeros((0, 3), dtype=torch.float64, device=dev),
+                torch.zeros((0, 3), dtype=torch.int64, device=dev))
+    ci, cj, ck = active[:, 0], active[:, 1], active[:, 2]
+    cidx = cube[ci, cj, ck]
+    emask = edge_table[cidx].to(torch.int64)
+    # which of its 12 edges does each active cube CREATE (first cube of the sweep on that edge)?
+    own = {6: None, 5: None, 10: None,
+           0: (cj == 0) & (ck == 0), 1: ck == 0, 2: ck == 0, 3: (ci == 0) & (ck == 0),
+           4: cj == 0, 7: ci == 0, 8: (ci == 0) & (cj == 0), 9: cj == 0, 11: ci == 0}
+    created = torch.zeros((na, 12), dtype=torch.bool, device=dev)
+    for e in range(12):
+        flag = (emask >> e & 1).bool()
+        created[:, e] = flag if own[e] is None else (flag & own[e])
+    order = torch.tensor(CREATE_ORDER, device=dev)
+    created_o = created[:, order]                                  # columns in creation order
+    rank_o = torch.cumsum(created_o.to(torch.int64), 1) - created_o.to(torch.int64)
+    n_created = created_o.sum(1)
+    vbase = torch.cumsum(n_created, 0) - n_created
+    vid_o = vbase[:, None] + rank_o                                # vertex id per (cube, slot)
+    n_verts = int(n_created.sum())
+    # vertex positions
+    verts = torch.empty((n_verts, 3), dtype=torch.float64, device=dev)
+    for slot, e in enumerate(CREATE_ORDER):
+        sel = created_o[:, slot]
+        if not bool(sel.any()):
+            continue
+        a, b = EDGES[e]
+        base = active[sel]
+        pa = base + torch.tensor(CORNERS[a], device=dev)
+        pb = base + torch.tensor(CORNERS[b], device=dev)
+        fa, fb = v[pa[:, 0], pa[:, 1], pa[:, 2]], v[pb[:, 0], pb[:, 1], pb[:, 2]]
+        pa, pb = pa.to(torch.float64), pb.to(torch.float64)
+        t = (isovalue - fa) / (fb - fa)
+        p = (pb - pa) * t[:, None] + pa                            # (x2 - x1) * (iso - f1) / (f2 - f1) + x1
+        p = torch.where((fa == fb)[:, None], (pa + pb) / 2, p)
+        verts[vid_o[sel, slot]] = p
+    # per grid edge: the id of its vertex (three dense id volumes, one per axis)
+    eid = [torch.full((X, Y, Z), -1, dtype=torch.int64, device=dev) for _ in range(3)]
+    for slot, e in enumerate(CREATE_ORDER):
+        sel = created_o[:, slot]
+        if not bool(sel.any()):
+            continue
+        axis, off = EDGE_AXIS_OFF[e]
+        b = active[sel] + torch.tensor(off, device=dev)
+        eid[axis][b[:, 0], b[:, 1], b[:, 2]] = vid_o[sel, slot]
+    # triangles: cube by cube, table order
+    tri = tri_table[cidx]                                          # (na, 3T), -1 padded
+    ntri = (tri >= 0).sum(1) // 3
+    fbase = torch.cumsum(ntri, 0) - ntri
+    n_faces = int(ntri.sum())
+    faces = torch.empty((n_faces, 3), dtype=torch.int64, device=dev)
+    T = tri.shape[1] // 3
+    cube_vid = torch.full((na, 12), -1, dtype=torch.int64, device=dev)
+    for e in range(12):
+        axis, off = EDGE_AXIS_OFF[e]
+        b = active + torch.tensor(off, device=dev)
+        cube_vid[:, e] = eid[axis][b[:, 0], b[:, 1], b[:, 2]]
+    for t in range(T):
+        sel = ntri > t
+        if not bool(sel.any()):
+            break
+        e3 = tri[sel][:, 3 * t:3 * t + 3]
+        faces[fbase[sel] + t] = torch.gather(cube_vid[sel], 1, e3)
+    return verts, faces
+
+
+# ------------------------------------------------------------------------------------------------
+# mcubes.smooth (constrained)
+# ------------------------------------------------------------------------------------------------
+def _line_distance(other, axis, cap):
+    """Per voxel, the distance ALONG `axis` to the nearest voxel where `other` is True (int32,
+    capped at `cap`): two running-maximum sweeps over the index of the last such voxel."""
+    n = other.shape[axis]
+    shape = [1, 1, 1]
+    shape[axis] = n
+    idx = torch.arange(n, device=other.device, dtype=torch.int32).view(shape)
+    far = -(cap + n)
+    last = torch.cummax(torch.where(other, idx, torch.full_like(idx, far).expand_as(other)), axis).values
+    d_fwd = idx - last
+    ridx = (n - 1) - idx
+    nxt = torch.cummax(torch.where(other, ridx, torch.full_like(idx, far).expand_as(other)).flip(axis),
+                       axis).values.flip(axis)
+    d_bwd = ridx - nxt
+    return torch.minimum(d_fwd, d_bwd).clamp(max=cap)
+
+
+def _min_plus_pass(d2, axis, radius):
+    """out[i] = min_{|s| <= radius} d2[i + s] + s^2 along `axis` (one sweep of the separable exact
+    Euclidean transform, restricted to the radius that matters)."""
+    out = d2.clone()
+    n = d2.shape[axis]
+    for s_ in range(1, radius + 1):
+        if s_ >= n:
+            break
+        for sgn in (1, -1):
+            sh = sgn * s_
+            src = [slice(None)] * 3
+            dst = [slice(None)] * 3
+            if sh > 0:
+                src[axis], dst[axis] = slice(sh, n), slice(0, n - sh)
+            else:
+                src[axis], dst[axis] = slice(0, n + sh), slice(-sh, n)
+            tgt = out[tuple(dst)]
+            tgt.copy_(torch.minimum(tgt, d2[tuple(src)] + s_ * s_))
+    return out
+
+
+@torch.no_grad()
+def signed_distance_band(binary, radius=5.0):
+    """scipy.ndimage.distance_transform_edt on both classes, exact wherever the other class is
+    within `radius` voxels: d = +(distance to the nearest False voxel) - 0.5 inside,
+    -(distance to the nearest True voxel) + 0.5 outside; farther voxels get +-(radius + 0.5).
+    Separable squared-distance transform in integers: nearest other-class voxel along z, then
+    min-plus sweeps over |dy| <= R and |dx| <= R (a nearest voxel within R has every coordinate
+    offset within R)."""
+    b = binary.bool()
+    R = int(math.ceil(radius))
+    cap2 = (R + 1) * (R + 1)
+
+    def dist2_to(other):
+        dz = _line_distance(other, 2, R + 1)
+        d2 = (dz * dz).clamp(max=cap2)
+        d2 = _min_plus_pass(d2, 1, R).clamp(max=cap2)
+        return _min_plus_pass(d2, 0, R).clamp(max=cap2)
+
+    d_in = torch.sqrt(dist2_to(~b).to(torch.float64))          # True voxels: nearest False
+    d_out = torch.sqrt(dist2_to(b).to(torch.float64))          # False voxels: nearest True
+    big = float(radius) + 1.0
+    d_in = torch.where(d_in > radius, torch.full_like(d_in, big), d_in)
+    d_out = torch.where(d_out > radius, torch.full_like(d_out, big), d_out)
+    return torch.where(b, d_in - 0.5, -(d_out - 0.5))
+
+
+@torch.no_grad()
+def smooth_constrained(binary, max_iters=250, rel_tol=1e-6, band_radius=4.0, weight=0.5):
+    """mcubes.smooth for volumes of at most 512^3 voxels (see the module docstring).  Returns the
+    float64 volume PyMCubes returns — the signed distance with the band replaced by the solution —
+    except that distances beyond the band are capped at +-(band_radius + 1.5): they never reach the
+    zero level set, and an exact far-field transform of 2 x 512^3 voxels would cost more than
+    everything else in the export.
+
+    The unknowns are the band voxels only (a few million of the 134 M), compacted in x-major
+    order with six neighbour-slot arrays; F and F^T are gathers over them."""
+    b = binary.bool()
+    dev = b.device
+    dist = signed_distance_band(b, band_radius + 1.0)
+    band = dist.abs() < band_radius
+    pos = torch.nonzero(band)
+    nv = pos.shape[0]
+    if nv == 0:
+        return dist
+    slot = torch.full(b.shape, -1, dtype=torch.int64, device=dev)
+    slot[band] = torch.arange(nv, device=dev)
+    shape = torch.tensor(b.shape, device=dev)
+    nbr, has = [], []                       # [axis][0: -1, 1: +1]
+    for a in range(3):
+        na_, ha_ = [], []
+        for sgn in (-1, 1):
+            q = pos.clone()
+            q[:, a] += sgn
+            ok = (q[:, a] >= 0) & (q[:, a] < shape[a])
+            q[:, a].clamp_(0, int(shape[a]) - 1)
+            n = slot[q[:, 0], q[:, 1], q[:, 2]]
+            ok = ok & (n >= 0)
+            na_.append(n.clamp(min=0))
+            ha_.append(ok.to(torch.float64))
+        nbr.append(na_); has.append(ha_)
+    cdiag = [-2.0 + (1 - has[a][0]) + (1 - has[a][1]) for a in range(3)]
+    x = dist[band]
+    inside = b[band]
+    ninf, pinf = float("-inf"), float("inf")
+    lower = torch.where(inside, torch.zeros_like(x), torch.full_like(x, ninf))
+    upper = torch.where(inside, torch.full_like(x, pinf), torch.zeros_like(x))
+
+    def apply_q(v):
+        out = torch.zeros_like(v)
+        for a in range(3):
+            y = cdiag[a] * v + v[nbr[a][0]] * has[a][0] + v[nbr[a][1]] * has[a][1]        # F rows
+            out += cdiag[a] * y + y[nbr[a][0]] * has[a][0] + y[nbr[a][1]] * has[a][1]    # F^T
+        return out
+
+    diag = torch.zeros_like(x)
+    for a in range(3):
+        diag += cdiag[a] ** 2 + has[a][0] + has[a][1]
+    inv_d = 1.0 / diag
+    check_each = 10
+    cum_rel_tol = 1 - (1 - rel_tol) ** check_each
+    energy_now = float((x * apply_q(x)).sum()) / 2
+    for i in range(max_iters):
+        x1 = -inv_d * (apply_q(x) - diag * x)               # -D^-1 R x
+        x = weight * x1 + (1 - weight) * x
+        x = torch.minimum(torch.maximum(x, lower), upper)
+        if (i + 1) % check_each == 0:
+            energy_before = energy_now
+            energy_now = float((x * apply_q(x)).sum()) / 2
+            if energy_before <= 0 or (energy_before - energy_now) / energy_before < cum_rel_tol:
+                break
+    out = dist.clone()
+    out[band] = x
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# cv2.resize(..., interpolation=cv2.INTER_CUBIC) for a uint8 single-channel image
+# ------------------------------------------------------------------------------------------------
+def resize_cubic_u8(img, out_hw):
+    """OpenCV bicubic (A = -0.75): source coordinate (dst + 0.5) * scale - 0.5, 4 taps per axis,
+    replicated border, result rounded and saturated to uint8.  img (H,W) uint8 tensor."""
+    A = -0.75
+
+    def weights(t):
+        w0 = ((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A
+        w1 = ((A + 2) * t - (A + 3)) * t * t + 1
+        w2 = ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1
+        return torch.stack([w0, w1, w2, 1.0 - w0 - w1 - w2], -1)
+
+    def axis_tables(n_in, n_out, dev):
+        s = n_in / n_out
+        f = (torch.arange(n_out, dtype=torch.float64, device=dev) + 0.5) * s - 0.5
+        i0 = torch.floor(f)
+        idx = (i0[:, None] + torch.arange(-1, 3, device=dev)).clamp(0, n_in - 1).long()
+        return idx, weights(f - i0)
+
+    x = img.to(torch.float64)
+    H, W = x.shape
+    oh, ow = out_hw
+    iy, wy = axis_tables(H, oh, x.device)
+    ix, wx = axis_tables(W, ow, x.device)
+    rows = (x[iy] * wy[:, :, None]).sum(1)                    # (oh, W)
+    out = (rows[:, ix] * wx[None]).sum(-1)                    # (oh, ow)
+    return torch.floor(out + 0.5).clamp(0, 255).to(torch.uint8)
+
+
+# ------------------------------------------------------------------------------------------------
+# MarchingCubeHelper / isosurface / export
+# ------------------------------------------------------------------------------------------------
+class MarchingCubeHelper:
+    """geometry.py:33-69 (remeshing = trimesh quadric decimation is not part of this path)."""
+
+    def __init__(self, resolution):
+        self.resolution = int(resolution)
+
+    @torch.no_grad()
+    def __call__(self, level, threshold=0.0, front_mask=None):
+        res = self.resolution
+        level = level.float().view(res, res, res)
+        binary = level <= 0
+        if front_mask is not None:
+            fm = resize_cubic_u8(front_mask.to(level.device), (res, res))
+            binary = binary & (fm[:, None, :].expand(res, res, res) > 127)       # np.tile(front_mask[:, None, :])
+        value = smooth_constrained(binary)
+        verts, faces = marching_cubes(value, threshold)
+        return {"verts": verts / (res - 1.0), "faces": faces, "binary": binary}
+
+
+def scale_anything(x, src, dst):                    # instant_nsr/models/utils.py:101-106
+    return (x - src[0]) / (src[1] - src[0]) * (dst[1] - dst[0]) + dst[0]
+
+
+def crop_front_mask(front_mask, vmin, vmax):
+    """geometry.py:93-98: the fine pass crops the (rotated) front mask to the fine box in x and z."""
+    size = front_mask.shape[0] / 2
+    x_min, x_max = int(math.floor(vmin[0] * size + size)), int(math.ceil(vmax[0] * size + size))
+    z_min, z_max = int(math.floor(vmin[2] * size + size)), int(math.ceil(vmax[2] * size + size))
+    return front_mask[x_min:x_max, z_min:z_max]
+
+
+@torch.no_grad()
+def isosurface(model, front_mask=None, resolution=None):
+    """BaseImplicitGeometry.isosurface (geometry.py:108-117) on the device: coarse pass over the
+    whole box, bounding box of the coarse MESH's vertices padded by 10 % and clamped, fine pass in
+    it with the front mask.  Returns the fine mesh {verts (N,3) f64 world, faces (M,3) i64} plus
+    the two level volumes."""
+    r = float(model.config.radius)
+    res = resolution or model.config.geometry.isosurface.resolution
+    thr = float(model.config.geometry.isosurface.threshold)
+    helper = MarchingCubeHelper(res)
+
+    def one(vmin, vmax, fm):
+        level = model.isosurface_levels(vmin, vmax, res)
+        mesh = helper(level, thr, fm)
+        v = mesh["verts"]
+        mesh["verts"] = torch.stack([scale_anything(v[:, a], (0, 1), (vmin[a], vmax[a])) for a in range(3)], -1)
+        mesh["level"] = level
+        return mesh
+
+    coarse = one((-r, -r, -r), (r, r, r), None)
+    if coarse["verts"].shape[0] == 0:
+        return coarse, coarse
+    vmin, vmax = coarse["verts"].amin(0), coarse["verts"].amax(0)
+    vmin_ = (vmin - (vmax - vmin) * 0.1).clamp(-r, r).tolist()
+    vmax_ = (vmax + (vmax - vmin) * 0.1).clamp(-r, r).tolist()
+    fm = None if front_mask is None else crop_front_mask(front_mask, vmin_, vmax_)
+    fine = one(vmin_, vmax_, fm)
+    fine["vmin"], fine["vmax"] = vmin_, vmax_
+    return fine, coarse
+
+
+@torch.no_grad()
+def vertex_colors(model, verts, chunk=2097152):
+    """NeuSModel.export's colour pass (neus.py:222-236): texture(feature, -normal, normal)."""
+    import torch.nn.functional as F
+    out = []
+    for i in range(0, verts.shape[0], chunk):
+        p = verts[i:i + chunk].float()
+        _, grad, feat = model.geometry(p, with_grad=True, with_feature=True)
+        normal = F.normalize(grad, p=2, dim=-1)
+        out.append(model.texture(feat, -normal, normal))
+    return torch.cat(out, 0) if out else torch.zeros((0, 3), device=verts.device)
+
+
+def save_obj(path, verts, faces, colors=None, ortho_scale=1.35):
+    """save_mesh (mesh_utils.py:25-73) with its geometry switches off (thinning, smoothing, colour
+    back-projection, shearing are CPU steps outside this path): halve, swap to the front-facing
+    convention (x right, y up, z front), apply ortho_scale, write an OBJ with per-vertex colours
+    (trimesh's OBJ export of `vertex_colors`: `v x y z r g b`, faces 1-based)."""
+    v = verts.detach().cpu().numpy().astype(np.float64) * 0.5
+    out = np.zeros_like(v)
+    out[:, 0], out[:, 1], out[:, 2] = v[:, 0], v[:, 2], -v[:, 1]
+    out *= ortho_scale
+    f = faces.detach().cpu().numpy().astype(np.int64) + 1
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "w") as fh:
+        if colors is not None:
+            c = colors.detach().float().cpu().numpy()
+            for p, q in zip(out, c):
+                fh.write("v %.8f %.8f %.8f %.6f %.6f %.6f\n" % (p[0], p[1], p[2], q[0], q[1], q[2]))
+        else:
+            for p in out:
+                fh.write("v %.8f %.8f %.8f\n" % (p[0], p[1], p[2]))
+        for t in f:
+            fh.write("f %d %d %d\n" % (t[0], t[1], t[2]))
+    return path

@@ -635,26 +635,37 @@ class OrthoNeuSSystem:
                 print(f"[nsr] step {self.global_step} loss {float(r['loss']):.4f} "
                       f"rays {r['n_rays']} samples {r['n_samples']}", flush=True)
 
-    # ----------------------------------------------------------------- export (SDF volumes)
+    # ----------------------------------------------------------------- export
     @torch.no_grad()
-    def export_levels(self, resolution=None):
-        """model.export's device work (geometry.py:108-117): coarse 512^3 SDF over the whole
-        box, bounding box of the inside region padded by 10 %, fine 512^3 SDF in it.  Returns
-        (coarse, fine, vmin, vmax).  Marching cubes / mesh post-processing stay on the host
-        (not part of this path)."""
+    def export_mesh(self, front_mask=None, resolution=None, with_colors=True):
+        """OrthoNeuSSystem.export -> model.export (neus_ortho.py:183-200, neus.py:220-238,
+        geometry.py:108-117) on the device: coarse 512^3 pass, iso-surface of the smoothed coarse
+        binary volume, fine box = the coarse MESH's bounding box padded by 10 %, fine pass with
+        the front mask, marching cubes, vertex colours from the texture network at the surface
+        normal.  `front_mask`: (H,W) uint8 tensor, already rotated as ortho.py:155-156 does.
+        Returns {verts (N,3) f64, faces (M,3) i64, vert_colors (N,3) or None, level, ...}."""
+        from . import mesh as M
         self.model.eval()
+        fine, coarse = M.isosurface(self.model, front_mask, resolution)
+        fine["coarse_level"] = coarse["level"]
+        fine["vert_colors"] = M.vertex_colors(self.model, fine["verts"].to(self.device)) \
+            if with_colors and fine["verts"].shape[0] else None
+        return fine
+
+    def export_name(self, front_cutting=True):
+        """save name of neus_ortho.py:184-196 for the switches applied here (resolution, face
+        count label, front cutting; remeshing / thinning / smoothing / colour back-projection are
+        CPU steps outside this path and leave no suffix)."""
+        iso = self.model.config.geometry.isosurface
+        name = f"it{self.global_step}-{iso.method}{iso.resolution}-f50000"
+        return name + ("_c" if front_cutting else "")
+
+    def export_levels(self, resolution=None):
+        """The two level volumes of the export and the fine box: (coarse, fine, vmin, vmax), the
+        fine box derived from the coarse mesh as the reference does (geometry.py:111-114)."""
+        m = self.export_mesh(None, resolution, with_colors=False)
+        dev = m["level"].device
         r = self.model.config.radius
-        coarse = self.model.isosurface_levels((-r, -r, -r), (r, r, r), resolution)
-        res = coarse.shape[0]
-        inside = coarse <= 0
-        if bool(inside.any()):
-            idx = torch.nonzero(inside)
-            lo = idx.min(0).values.float() / (res - 1) * 2 * r - r
-            hi = idx.max(0).values.float() / (res - 1) * 2 * r - r
-        else:
-            lo = torch.full((3,), -r, device=coarse.device)
-            hi = torch.full((3,), r, device=coarse.device)
-        vmin = (lo - (hi - lo) * 0.1).clamp(-r, r)
-        vmax = (hi + (hi - lo) * 0.1).clamp(-r, r)
-        fine = self.model.isosurface_levels(vmin.tolist(), vmax.tolist(), resolution)
-        return coarse, fine, vmin, vmax
+        vmin = torch.tensor(m.get("vmin", [-r] * 3), device=dev)
+        vmax = torch.tensor(m.get("vmax", [r] * 3), device=dev)
+        return m["coarse_level"], m["level"], vmin, vmax

@@ -1,0 +1,171 @@
+"""CPU restatement of the PyMCubes==0.1.4 calls on the NSR export path.  TEST INFRASTRUCTURE ONLY.
+
+PyMCubes is an un-vendored dependency (requirements.txt:16: pymcubes==0.1.4; call sites
+2_charactor_reconstructor/instant_nsr/models/geometry.py:56-61); its source is not under
+/root/reference and the package is not installable here.  PARITY UNPINNED: the reference holds no
+tests or golden meshes.  Restated from the published implementation (mcubes/src/marchingcubes.h:
+serial x-major sweep, `shared_indices` de-duplication, vertex creation order 6, 5, 10 then the
+boundary edges, `mc_isovalue_interpolation`; mcubes/smoothing.py: `signed_distance_function`,
+`_buildq3d`, `_jacobi`, `smooth_constrained`) as serial Python / scipy code, independent of the
+tensor formulation in drawingspinup_amd/nsr/mesh.py.  The per-cube triangulation table is an INPUT
+(the classic 256-row table is not available in this image; the product generates one, and
+tests/test_mesh_host.py checks its topological properties before using it here).
+"""
+import numpy as np
+
+CORNERS = ((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1))
+EDGES = ((0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7))
+
+
+def _interp(iso, f1, f2, x1, x2):
+    if f2 == f1:
+        return (x2 + x1) / 2
+    return (x2 - x1) * (iso - f1) / (f2 - f1) + x1
+
+
+def marching_cubes(volume, iso, edge_table, tri_table):
+    """Serial sweep: for i, for j, for k (k fastest).  Returns (verts (N,3) f64, faces (M,3) i64)."""
+    f = np.asarray(volume, np.float64)
+    X, Y, Z = f.shape
+    verts, faces = [], []
+    # id of the vertex on the grid edge that starts at (x, y, z) and runs along `axis`
+    shared = {}
+
+    def vertex(a_pt, b_pt):
+        fa, fb = f[a_pt], f[b_pt]
+        verts.append(tuple(_interp(iso, fa, fb, float(a_pt[d]), float(b_pt[d])) for d in range(3)))
+        return len(verts) - 1
+
+    def key(a_pt, b_pt):
+        lo = tuple(min(p, q) for p, q in zip(a_pt, b_pt))
+        axis = [d for d in range(3) if a_pt[d] != b_pt[d]][0]
+        return lo + (axis,)
+
+    for i in range(X - 1):
+        for j in range(Y - 1):
+            for k in range(Z - 1):
+                pts = [(i + dx, j + dy, k + dz) for dx, dy, dz in CORNERS]
+                cubeindex = 0
+                for m in range(8):
+                    if f[pts[m]] < iso:
+                        cubeindex |= 1 << m
+                edges = int(edge_table[cubeindex])
+                if edges == 0:
+                    continue
+                idx = [-1] * 12
+                # the three edges no earlier cube has seen, then the rest (created on the low faces
+                # of the volume, looked up otherwise)
+                for e in (6, 5, 10, 0, 1, 2, 3, 4, 7, 8, 9, 11):
+                    if not edges >> e & 1:
+                        continue
+                    a, b = EDGES[e]
+                    kk = key(pts[a], pts[b])
+                    if kk not in shared:
+                        shared[kk] = vertex(pts[a], pts[b])
+                    idx[e] = shared[kk]
+                row = tri_table[cubeindex]
+                m = 0
+                while m < len(row) and row[m] != -1:
+                    faces.append((idx[row[m]], idx[row[m + 1]], idx[row[m + 2]]))
+                    m += 3
+    return (np.asarray(verts, np.float64).reshape(-1, 3), np.asarray(faces, np.int64).reshape(-1, 3))
+
+
+# ------------------------------------------------------------------------------------------------
+def signed_distance_function(binary):
+    from scipy import ndimage as ndi
+    b = np.asarray(binary) > 0
+    return np.where(b, ndi.distance_transform_edt(b) - 0.5, -ndi.distance_transform_edt(~b) + 0.5)
+
+
+def _buildq3d(variable_indices):
+    from scipy import sparse
+    num = variable_indices.max() + 1
+    F = sparse.lil_matrix((3 * num, num))
+    vi = np.pad(variable_indices, [(0, 1)] * 3, mode="constant", constant_values=-1)
+    coords = np.nonzero(vi >= 0)
+    for count, (i, j, k) in enumerate(zip(*coords)):
+        assert vi[i, j, k] == count
+        for row, (di, dj, dk) in enumerate(((1, 0, 0), (0, 1, 0), (0, 0, 1))):
+            r = 3 * count + row
+            F[r, count] = -2
+            for s in (-1, 1):
+                n = vi[i + s * di, j + s * dj, k + s * dk]      # index -1 wraps onto the -1 padding
+                if n >= 0:
+                    F[r, n] = 1
+                else:
+                    F[r, count] += 1
+    F = F.tocsr()
+    return F.T.dot(F)
+
+
+def _jacobi(Q, x0, lower, upper, max_iters=10, rel_tol=1e-6, weight=0.5):
+    from scipy import sparse
+    d = Q.diagonal()
+    R = sparse.lil_matrix(Q)
+    R.setdiag(0)
+    R = R.tocsr()
+    inv_d = 1.0 / d
+    x = x0
+    check_each = 10
+    cum_rel_tol = 1 - (1 - rel_tol) ** check_each
+    energy_now = np.dot(x, Q.dot(x)) / 2
+    for i in range(max_iters):
+        x1 = -inv_d * R.dot(x)
+        x = weight * x1 + (1 - weight) * x
+        x = np.maximum(x, lower)
+        x = np.minimum(x, upper)
+        if (i + 1) % check_each == 0:
+            energy_before = energy_now
+            energy_now = np.dot(x, Q.dot(x)) / 2
+            if energy_before <= 0 or (energy_before - energy_now) / energy_before < cum_rel_tol:
+                break
+    return x
+
+
+def smooth_constrained(binary, max_iters=250, rel_tol=1e-6, band_radius=4.0):
+    b = np.asarray(binary) > 0
+    dist = signed_distance_function(b)
+    band = np.abs(dist) < band_radius
+    vi = np.full(b.shape, -1, np.int64)
+    vi[band] = np.arange(int(band.sum()))
+    Q = _buildq3d(vi)
+    x0 = dist[band]
+    lower = np.where(b[band], 0.0, -np.inf)
+    upper = np.where(b[band], np.inf, 0.0)
+    x = _jacobi(Q, x0, lower, upper, max_iters, rel_tol)
+    out = dist.copy()
+    out[band] = x
+    return out
+
+
+def resize_cubic_u8(img, out_hw):
+    """cv2.resize INTER_CUBIC on a single-channel uint8 image, pixel by pixel (A = -0.75)."""
+    A = -0.75
+    img = np.asarray(img, np.float64)
+    H, W = img.shape
+    oh, ow = out_hw
+
+    def w4(t):
+        w0 = ((A * (t + 1) - 5 * A) * (t + 1) + 8 * A) * (t + 1) - 4 * A
+        w1 = ((A + 2) * t - (A + 3)) * t * t + 1
+        w2 = ((A + 2) * (1 - t) - (A + 3)) * (1 - t) * (1 - t) + 1
+        return (w0, w1, w2, 1.0 - w0 - w1 - w2)
+
+    out = np.zeros((oh, ow), np.uint8)
+    for y in range(oh):
+        fy = (y + 0.5) * H / oh - 0.5
+        y0 = int(np.floor(fy)); wy = w4(fy - y0)
+        for x in range(ow):
+            fx = (x + 0.5) * W / ow - 0.5
+            x0 = int(np.floor(fx)); wx = w4(fx - x0)
+            acc = 0.0
+            for a in range(4):
+                yy = min(max(y0 - 1 + a, 0), H - 1)
+                row = 0.0
+                for c in range(4):
+                    xx = min(max(x0 - 1 + c, 0), W - 1)
+                    row += img[yy, xx] * wx[c]
+                acc += row * wy[a]
+            out[y, x] = int(min(max(np.floor(acc + 0.5), 0), 255))
+    return out

@@ -29,9 +29,15 @@ def test_entry_points_chain(dev, tmp_path):
         files = sorted(os.listdir(os.path.join(root, uid, "mv", sub)))
         assert files == sorted(f"{v}.png" for v in ("front", "front_right", "right", "back", "left", "front_left"))
     assert Image.open(os.path.join(root, uid, "mv", "color", "front.png")).size == (1024, 1024)
+    _drawing().split()[-1].save(os.path.join(root, uid, "char", "mask.png"))     # front mask (ortho.py:153-156)
     recon.main(["--uid", uid, "--data_root", root, "--max_steps", "20"])
-    fine = np.load(os.path.join(root, uid, "mesh", "it20-sdf512_fine.npy"))
-    assert fine.shape == (512, 512, 512) and np.isfinite(fine).all()
+    # recon.py's product: the mesh file, named as neus_ortho.py:184-196 names it
+    obj = open(os.path.join(root, uid, "mesh", "it20-mc512-f50000_c.obj")).read().splitlines()
+    nv, nf = sum(l.startswith("v ") for l in obj), sum(l.startswith("f ") for l in obj)
+    assert nv > 1000 and nf > 2000
+    assert len(obj[0].split()) == 7                                   # v x y z r g b
+    idx = np.array([[int(t) for t in l.split()[1:]] for l in obj if l.startswith("f ")])
+    assert idx.min() == 1 and idx.max() == nv                         # 1-based, every vertex used
     sd = torch.load(os.path.join(root, uid, "mesh", "it20.ckpt"), map_location="cpu")
     assert "geometry.encoding.encoding.encoding.params" in sd and "variance.variance" in sd
     # stage 3 inputs: 2 synthetic frames (colour / pos / edge) in the blender_render layout

@@ -1,0 +1,153 @@
+"""NSR export tail (drawingspinup_amd/nsr/mesh.py: tensor programs, device-agnostic) against the
+serial restatement of PyMCubes (oracle/mcubes_ref.py) on the CPU: integer outputs bit-exact."""
+import numpy as np
+import pytest
+import torch
+
+from drawingspinup_amd.nsr import mesh as M
+from oracle import mcubes_ref as R
+
+
+def test_generated_tables_are_a_valid_crack_free_triangulation():
+    et, tt = M.tables()
+    assert et[0] == 0 and et[255] == 0 and tt.shape[0] == 256
+    for c in range(256):
+        row = [int(v) for v in tt[c] if v >= 0]
+        assert len(row) % 3 == 0
+        used = set(row)
+        crossed = {e for e in range(12) if et[c] >> e & 1}
+        assert used == crossed                                   # every crossed edge carries the surface
+        # inside the cube each polygon edge that is NOT on a cube face is shared by two triangles;
+        # segments on cube faces appear once (they are matched by the neighbouring cube)
+        seg = {}
+        for t in range(0, len(row), 3):
+            tri = row[t:t + 3]
+            assert len(set(tri)) == 3
+            for a, b in ((tri[0], tri[1]), (tri[1], tri[2]), (tri[2], tri[0])):
+                seg[(a, b)] = seg.get((a, b), 0) + 1
+        for (a, b), n in seg.items():
+            assert n == 1                                         # consistent orientation: no directed edge twice
+        # complement symmetry of the edge masks
+        assert et[c] == et[255 - c]
+
+
+def _closed_and_oriented(faces):
+    d = {}
+    for f in faces:
+        for a, b in ((f[0], f[1]), (f[1], f[2]), (f[2], f[0])):
+            d[(a, b)] = d.get((a, b), 0) + 1
+    return all(n == 1 for n in d.values()) and all((b, a) in d for (a, b) in d)
+
+
+@pytest.mark.parametrize("seed,shape", [(0, (9, 8, 10)), (1, (12, 12, 12)), (2, (6, 14, 7))])
+def test_marching_cubes_matches_serial_sweep_bit_exactly(seed, shape):
+    g = torch.Generator().manual_seed(seed)
+    vol = torch.randn(*shape, generator=g, dtype=torch.float64)
+    vol = torch.nn.functional.avg_pool3d(vol[None, None], 3, 1, 1)[0, 0]       # some structure
+    shell = torch.ones_like(vol, dtype=torch.bool)
+    shell[1:-1, 1:-1, 1:-1] = False
+    vol = torch.where(shell, vol.abs() + 0.1, vol)                  # nothing below iso on the shell
+    et, tt = M.tables()
+    v, f = M.marching_cubes(vol, 0.02)
+    rv, rf = R.marching_cubes(vol.numpy(), 0.02, et, tt)
+    assert np.array_equal(f.numpy(), rf)                            # INT: face index arrays
+    assert np.array_equal(v.numpy(), rv)                            # same float64 interpolation
+    assert _closed_and_oriented(rf.tolist())                        # positive shell: a closed surface
+
+
+def test_marching_cubes_open_boundary_and_degenerate_values():
+    """Surfaces that leave the volume (boundary-created vertices on the low faces) and equal corner
+    values (the (x1+x2)/2 branch is unreachable for a crossed edge; exact-iso corners count as
+    not below)."""
+    g = torch.Generator().manual_seed(5)
+    vol = torch.randn(7, 6, 8, generator=g, dtype=torch.float64)
+    vol[2, 3, 4] = 0.0
+    et, tt = M.tables()
+    v, f = M.marching_cubes(vol, 0.0)
+    rv, rf = R.marching_cubes(vol.numpy(), 0.0, et, tt)
+    assert np.array_equal(f.numpy(), rf) and np.array_equal(v.numpy(), rv)
+    empty_v, empty_f = M.marching_cubes(torch.ones(4, 4, 4), 0.0)
+    assert empty_v.shape == (0, 3) and empty_f.shape == (0, 3)
+
+
+def test_sphere_mesh_is_closed_and_lattice_order_is_x_major():
+    n = 24
+    c = torch.linspace(-1, 1, n, dtype=torch.float64)
+    x, y, z = torch.meshgrid(c, c, c, indexing="ij")
+    vol = 0.6 - torch.sqrt(x * x + y * y + z * z)                    # positive inside
+    v, f = M.marching_cubes(vol, 0.0)
+    assert _closed_and_oriented(f.tolist())
+    r = torch.sqrt((((v / (n - 1)) * 2 - 1) ** 2).sum(-1))
+    assert float((r - 0.6).abs().max()) < 0.02
+    # outward normals (toward the below side = outside for a positive-inside field)
+    p = (v / (n - 1)) * 2 - 1
+    a, b, cc = p[f[:, 0]], p[f[:, 1]], p[f[:, 2]]
+    nrm = torch.cross(b - a, cc - a, dim=-1)
+    assert float(((nrm * (a + b + cc)).sum(-1) > 0).double().mean()) == 1.0
+    # vertex numbering follows the x-major sweep: first vertex has the smallest x cell
+    assert float(v[0, 0]) <= float(v[:, 0].min()) + 1.0
+
+
+def test_signed_distance_band_matches_scipy_edt():
+    g = torch.Generator().manual_seed(3)
+    b = torch.nn.functional.avg_pool3d(torch.rand(1, 1, 20, 18, 22, generator=g), 5, 1, 2)[0, 0] > 0.5
+    d = M.signed_distance_band(b, 5.0).numpy()
+    ref = R.signed_distance_function(b.numpy())
+    near = np.abs(ref) <= 4.5                      # exact where the other class is within the radius
+    assert near.sum() > 1000
+    np.testing.assert_allclose(d[near], ref[near], rtol=0, atol=1e-12)
+    assert np.all(np.abs(d[~near]) > 4.5 - 1e-12)
+
+
+def test_smooth_constrained_matches_scipy_restatement():
+    n = 20
+    c = torch.linspace(-1, 1, n)
+    x, y, z = torch.meshgrid(c, c, c, indexing="ij")
+    b = ((x / 0.7) ** 2 + (y / 0.5) ** 2 + (z / 0.6) ** 2 <= 1.0) | ((x - 0.3).abs() + y.abs() + z.abs() < 0.35)
+    got = M.smooth_constrained(b, max_iters=60).numpy()
+    ref = R.smooth_constrained(b.numpy(), max_iters=60)
+    near = np.abs(R.signed_distance_function(b.numpy())) <= 4.5
+    np.testing.assert_allclose(got[near], ref[near], rtol=0, atol=1e-9)
+    # beyond the band the product caps the distance (the zero level set never sees those values)
+    assert np.array_equal(np.sign(got[~near]), np.sign(ref[~near])) and np.all(np.abs(got[~near]) > 4.5)
+    # the constraint: every voxel stays on its side of the surface
+    assert np.all(got[b.numpy()] >= 0) and np.all(got[~b.numpy()] <= 0)
+    # and the mesh of the smoothed field, faces bit-exact vs the serial sweep on the oracle's field
+    et, tt = M.tables()
+    v, f = M.marching_cubes(torch.from_numpy(got), 0.0)
+    rv, rf = R.marching_cubes(ref, 0.0, et, tt)
+    assert np.array_equal(f.numpy(), rf)
+    np.testing.assert_allclose(v.numpy(), rv, rtol=0, atol=1e-7)
+
+
+def test_resize_cubic_matches_pixel_loop():
+    g = torch.Generator().manual_seed(4)
+    img = (torch.rand(13, 17, generator=g) * 255).to(torch.uint8)
+    for out_hw in ((24, 24), (7, 9), (13, 17)):
+        got = M.resize_cubic_u8(img, out_hw).numpy()
+        ref = R.resize_cubic_u8(img.numpy(), out_hw)
+        assert np.array_equal(got, ref)
+    assert np.array_equal(M.resize_cubic_u8(img, (13, 17)).numpy(), img.numpy())   # identity at scale 1
+
+
+def test_helper_and_obj_writer(tmp_path):
+    res = 16
+    c = torch.linspace(0, 1, res)
+    x, y, z = torch.meshgrid(c, c, c, indexing="ij")
+    level = torch.sqrt((x - 0.5) ** 2 + (y - 0.5) ** 2 + (z - 0.5) ** 2) - 0.3     # SDF: negative inside
+    helper = M.MarchingCubeHelper(res)
+    mesh = helper(level.reshape(-1), 0.0)
+    assert mesh["verts"].shape[1] == 3 and float(mesh["verts"].min()) >= 0 and float(mesh["verts"].max()) <= 1
+    front = torch.zeros(32, 32, dtype=torch.uint8)
+    front[:, :16] = 255                                            # keeps z < 0.5 (columns -> z)
+    cut = helper(level.reshape(-1), 0.0, front)
+    assert float(cut["verts"][:, 2].max()) < 0.56 and cut["faces"].shape[0] > 0
+    assert int(cut["binary"].sum()) < int(mesh["binary"].sum())
+    path = M.save_obj(str(tmp_path / "mesh" / "m.obj"), mesh["verts"] * 2 - 1, mesh["faces"],
+                      torch.rand(mesh["verts"].shape[0], 3))
+    lines = open(path).read().splitlines()
+    nv = sum(l.startswith("v ") for l in lines)
+    nf = sum(l.startswith("f ") for l in lines)
+    assert nv == mesh["verts"].shape[0] and nf == mesh["faces"].shape[0]
+    first_face = [int(t) for t in [l for l in lines if l.startswith("f ")][0].split()[1:]]
+    assert first_face == (mesh["faces"][0] + 1).tolist()
