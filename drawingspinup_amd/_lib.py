@@ -105,6 +105,10 @@ _PROTOS = {
                                    c_i32, P, P, P, c_i32, P, c_i64, P],
     "dsu_conv2d_nhwc_f16_split_k": [c_i32] * 9,
     "dsu_conv2d_nhwc_f16_workspace_bytes": [c_i32] * 9,
+    "dsu_gemm_f16_split_k": [c_i64, c_i32, c_i32],
+    "dsu_gemm_f16_workspace_bytes": [c_i64, c_i32, c_i32],
+    "dsu_gemm_f16_fwd": [P, P, P, c_i64, c_i32, c_i32, P, P, c_i32, c_i32, P, c_i64, P],
+    "dsu_gemm_geglu_fwd": [P, P, P, c_i64, c_i32, c_i32, P, P],
     "dsu_groupnorm_nhwc_f16": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_f32, c_i32, P, P, P],
     "dsu_layernorm_f16": [P, P, P, c_i64, c_i32, c_f32, P, P],
     "dsu_geglu_f16": [P, c_i64, c_i32, P, P],

@@ -16,6 +16,17 @@
 // MFMAs run; they are written to LDS after the MFMAs).
 // Fusions: nearest x2 upsample folded into the gather (Upsample2D), stride 2 (Downsample2D),
 // bias, per-(image, channel) vector add (ResnetBlock2D's time-embedding projection), residual.
+//
+// The same kernel is the GEMM of the UNet's linear layers (a 1x1 "convolution" over M rows):
+// dsu_gemm_f16_fwd (to_q / to_k / to_out, FeedForward output, proj_in / proj_out, the embedding
+// MLPs; mvdiffusion/models/transformer_mv2d.py:447-483, unet_mv2d_condition.py:313-319,374),
+// with two extra epilogues selected by the MODE template parameter:
+//   MODE 1  GEGLU (diffusers FeedForward's first layer): the 128 weight rows of a tile are 2 x 32
+//           value rows + 2 x 32 gate rows per wave pair, so a lane holds value and gate of the
+//           SAME (row, channel) in matching accumulator registers and the epilogue writes
+//           (value + b_v) * gelu(gate + b_g): the (M, 8C) intermediate never exists.
+//   transposed output (to_v): out[(image, channel, token)] so that the attention kernel reads V^T
+//           rows directly.
 #include "common.h"
 
 namespace {
@@ -41,16 +52,19 @@ struct CArgs {
   int Ktot;             // KS*KS*C
   int split_k;          // > 1: blockIdx.z owns a contiguous range of K chunks, f32 partials -> ws
   float* ws;            // (split_k, npix, O) f32 when split_k > 1
+  int out_t;            // 1: out[(n * O + o) * (OH*OW) + pixel-in-image]  (V^T for the attention kernel)
 };
 
-template <int DUMMY>
+template <int MODE>
 __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
+  constexpr bool GEGLU = MODE == 1;
   __shared__ __attribute__((aligned(16))) f16 sA[2][TM * ROW];
   __shared__ __attribute__((aligned(16))) f16 sB[2][TN * ROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;      // 2x2 waves, 64x64 each
-  const int o0 = blockIdx.y * TM;
+  // GEGLU: a tile covers 64 output channels (value rows + gate rows of the 2*O-row weight)
+  const int o0 = blockIdx.y * (GEGLU ? TM / 2 : TM);
   const int64_t npix = (int64_t)a.B * a.OH * a.OW;
   const int64_t p0 = (int64_t)blockIdx.x * TN;
   const int C8 = a.C >> 3;                      // 8-channel groups per tap
@@ -74,9 +88,16 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
     const int idx = tid + 256 * i;
     a_row[i] = idx >> 3;
     b_row[i] = idx >> 3;
-    const int o = o0 + a_row[i];
+    int o = o0 + a_row[i];
+    int wrow = o;
+    if (GEGLU) {
+      // tile row r = wm*64 + i*32 + l: i = 0 value rows, i = 1 gate rows of channel o0 + wm*32 + l
+      const int r = a_row[i];
+      o = o0 + (r >> 6) * 32 + (r & 31);
+      wrow = ((r >> 5) & 1) ? a.O + o : o;
+    }
     a_ok[i] = o < a.O;
-    w_off[i] = (uint32_t)(a_ok[i] ? o : 0) * (uint32_t)a.Ktot + (uint32_t)kofs;
+    w_off[i] = (uint32_t)(a_ok[i] ? wrow : 0) * (uint32_t)a.Ktot + (uint32_t)kofs;
     const int64_t p = p0 + b_row[i];
     b_ok[i] = p < npix;
     const int64_t pp = b_ok[i] ? p : 0;
@@ -191,6 +212,50 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
           } else {
             for (int e = 0; e < 4 && o + e < a.O; ++e) ws[(size_t)p * a.O + o + e] = acc[i][j][4 * r4 + e];
           }
+        }
+    }
+    return;
+  }
+  if (GEGLU) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t p = p0 + wn * 64 + j * 32 + l31;
+      if (p >= npix) continue;
+#pragma unroll
+      for (int r4 = 0; r4 < 4; ++r4) {
+        const int o = o0 + wm * 32 + 8 * r4 + 4 * hh;
+        if (o >= a.O) continue;                                  // O % 4 == 0 (checked by the host)
+        f16x4 ov;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float val = acc[0][j][4 * r4 + e], gate = acc[1][j][4 * r4 + e];
+          if (a.bias) { val += (float)a.bias[o + e]; gate += (float)a.bias[a.O + o + e]; }
+          // the f16 rounding of the projection the unfused path stored is kept
+          val = (float)(f16)val; gate = (float)(f16)gate;
+          ov[e] = (f16)(val * (0.5f * gate * (1.0f + erff(gate * 0.70710678118654752f))));
+        }
+        *reinterpret_cast<f16x4*>(a.out + (size_t)p * a.O + o) = ov;
+      }
+    }
+    return;
+  }
+  if (a.out_t) {
+    const int hw = a.OH * a.OW;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int64_t p = p0 + wn * 64 + j * 32 + l31;
+      if (p >= npix) continue;
+      const int n = (int)(p / hw);
+      const int t = (int)(p - (int64_t)n * hw);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int o = o0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+          if (o >= a.O) continue;
+          float v = acc[i][j][r];
+          if (a.bias) v += (float)a.bias[o];
+          a.out[((size_t)n * a.O + o) * hw + t] = (f16)v;        // 32 lanes = 32 consecutive tokens
         }
     }
     return;
@@ -324,6 +389,7 @@ int dsu_conv2d_nhwc_f16_fwd_ws(const void* input, const void* weight_okc, const 
   a.addvec = (const f16*)addvec; a.residual = (const f16*)residual; a.out = (f16*)out;
   a.B = B; a.H = H; a.W = W; a.C = C; a.O = O; a.KS = k; a.stride = stride; a.pad = pad;
   a.up2 = upsample2x ? 1 : 0;
+  a.out_t = 0;
   const int IH = a.up2 ? 2 * H : H, IW = a.up2 ? 2 * W : W;
   a.OH = (IH + 2 * pad - k) / stride + 1;
   a.OW = (IW + 2 * pad - k) / stride + 1;
@@ -349,6 +415,78 @@ int dsu_conv2d_nhwc_f16_fwd_ws(const void* input, const void* weight_okc, const 
     conv_f16_reduce_kernel<<<dsu_capped_blocks(total, 256, 2048), 256, 0, (hipStream_t)stream>>>(
         a, npix);
   }
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+// ---- GEMM entry points (the UNet's linear layers): x (M, K) f16 row-major, w (N, K) f16 (the
+// nn.Linear layout), f32 accumulation.
+static int gemm_args(CArgs& a, const void* x, const void* w, const void* bias, int64_t M, int32_t K,
+                     int32_t N, const void* residual, void* out) {
+  if (!x || !w || !out) return DSU_EINVAL;
+  if (M <= 0 || K <= 0 || N <= 0) return DSU_EINVAL;
+  if (K % 8 != 0) return DSU_EUNSUP;
+  if (M * (int64_t)K >= (int64_t)1 << 31 || (int64_t)N * K >= (int64_t)1 << 30 ||
+      M * (int64_t)N >= (int64_t)1 << 31)
+    return DSU_EUNSUP;
+  a.in = (const f16*)x; a.w = (const f16*)w; a.bias = (const f16*)bias; a.addvec = nullptr;
+  a.residual = (const f16*)residual; a.out = (f16*)out;
+  a.B = 1; a.H = (int)M; a.W = 1; a.C = K; a.O = N; a.OH = (int)M; a.OW = 1;
+  a.KS = 1; a.stride = 1; a.pad = 0; a.up2 = 0; a.Ktot = K; a.split_k = 1; a.ws = nullptr;
+  a.out_t = 0;
+  return DSU_OK;
+}
+
+int32_t dsu_gemm_f16_split_k(int64_t M, int32_t K, int32_t N) {
+  if (M <= 0 || M >= ((int64_t)1 << 31) || K <= 0 || N <= 0) return 1;
+  return dsu_conv2d_nhwc_f16_split_k(1, (int32_t)M, 1, K, N, 1, 1, 0, 0);
+}
+
+int64_t dsu_gemm_f16_workspace_bytes(int64_t M, int32_t N, int32_t split_k) {
+  return split_k <= 1 ? 0 : (int64_t)split_k * M * N * (int64_t)sizeof(float);
+}
+
+/* out (M, N) = x w^T (+ bias) (+ residual (M, N)).  tokens_per_image > 0: the output is written
+ * TRANSPOSED per image, out[(m / tokens) * N * tokens + n * tokens + m % tokens]  (to_v -> V^T). */
+int dsu_gemm_f16_fwd(const void* x, const void* w, const void* bias, int64_t M, int32_t K, int32_t N,
+                     const void* residual, void* out, int32_t tokens_per_image, int32_t split_k,
+                     void* workspace, int64_t workspace_bytes, void* stream) {
+  CArgs a;
+  int rc = gemm_args(a, x, w, bias, M, K, N, residual, out);
+  if (rc) return rc;
+  if (tokens_per_image > 0) {
+    if (M % tokens_per_image != 0 || residual || split_k > 1) return DSU_EINVAL;
+    a.out_t = 1;
+    a.B = (int)(M / tokens_per_image); a.H = tokens_per_image; a.OH = tokens_per_image;
+  }
+  const int chunks = (K + BK - 1) / BK;
+  if (split_k < 1 || split_k > 64) return DSU_EINVAL;
+  if (split_k > chunks) split_k = chunks;
+  while (split_k > 1 && (split_k - 1) * ((chunks + split_k - 1) / split_k) >= chunks) --split_k;
+  a.split_k = split_k;
+  a.ws = (float*)workspace;
+  if (split_k > 1 && (!workspace || workspace_bytes < (int64_t)split_k * M * N * (int64_t)sizeof(float)))
+    return DSU_EINVAL;
+  dim3 grid((unsigned)((M + TN - 1) / TN), (unsigned)((N + TM - 1) / TM), (unsigned)split_k);
+  conv_f16_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  if (split_k > 1) {
+    const int64_t total = M * ((N + 3) / 4);
+    conv_f16_reduce_kernel<<<dsu_capped_blocks(total, 256, 2048), 256, 0, (hipStream_t)stream>>>(a, M);
+  }
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+/* diffusers FeedForward first layer + GEGLU in one pass: w (2N, K), bias (2N) or null;
+ * out (M, N) = (x w[:N]^T + b[:N]) * gelu(x w[N:]^T + b[N:])   (exact erf GELU). */
+int dsu_gemm_geglu_fwd(const void* x, const void* w, const void* bias, int64_t M, int32_t K,
+                       int32_t N, void* out, void* stream) {
+  CArgs a;
+  int rc = gemm_args(a, x, w, bias, M, K, N, nullptr, out);
+  if (rc) return rc;
+  if (N % 4 != 0 || (int64_t)2 * N * K >= (int64_t)1 << 31) return DSU_EUNSUP;
+  dim3 grid((unsigned)((M + TN - 1) / TN), (unsigned)((N + TM / 2 - 1) / (TM / 2)), 1);
+  conv_f16_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }

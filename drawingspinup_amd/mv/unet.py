@@ -69,7 +69,18 @@ class TimestepEmbedding(nn.Module):
         self.linear_2 = nn.Linear(time_embed_dim, time_embed_dim)
 
     def forward(self, sample):
-        return self.linear_2(self.act(self.linear_1(sample)))
+        """Both layers on the MFMA GEMM (inputs narrower than a 16-byte K group — the 10-wide
+        class embedding — are zero-padded to 16 once, weight columns alike)."""
+        w1 = self.linear_1.weight
+        if w1.shape[1] % 8:
+            pad = (-w1.shape[1]) % 16
+            c = getattr(self, "_dsu_w1p", None)
+            if c is None or c[0] != w1._version or c[1].device != w1.device:
+                self._dsu_w1p = (w1._version, F.pad(w1.detach(), (0, pad)).contiguous())
+                c = self._dsu_w1p
+            sample, w1 = F.pad(sample, (0, pad)), c[1]
+        h = ops.linear_f16(sample.contiguous(), w1, self.linear_1.bias)
+        return ops.linear_f16(self.act(h), self.linear_2.weight, self.linear_2.bias)
 
 
 class ResnetBlock2D(nn.Module):
@@ -88,8 +99,8 @@ class ResnetBlock2D(nn.Module):
     def forward(self, x, temb_act):
         """x NHWC f16; temb_act = silu(emb) (B, temb_channels) computed once per UNet call."""
         h = group_norm(self.norm1, x, silu=True)
-        t = F.linear(temb_act, self.time_emb_proj.weight, self.time_emb_proj.bias)
-        h = conv_nhwc(self.conv1, h, addvec=t.contiguous())
+        t = ops.linear_f16(temb_act, self.time_emb_proj.weight, self.time_emb_proj.bias)
+        h = conv_nhwc(self.conv1, h, addvec=t)
         h = group_norm(self.norm2, h, silu=True)
         sc = x if self.conv_shortcut is None else conv_nhwc(self.conv_shortcut, x)
         return conv_nhwc(self.conv2, h, residual=sc)       # output_scale_factor == 1
@@ -140,11 +151,10 @@ class FeedForward(nn.Module):
                                   nn.Linear(dim * mult, dim)])
 
     def forward(self, x, residual):
-        h = F.linear(x, self.net[0].proj.weight, self.net[0].proj.bias)
-        h = ops.geglu_f16(h)
-        return torch.addmm(residual.reshape(-1, residual.shape[-1]),
-                           h.reshape(-1, h.shape[-1]), self.net[2].weight.t(),
-                           ).add_(self.net[2].bias).view_as(residual)
+        # proj + GEGLU in one launch (the (M, 8C) projection is never written), then the output
+        # layer with bias and residual in its epilogue
+        h = ops.linear_geglu_f16(x, self.net[0].proj.weight, self.net[0].proj.bias)
+        return ops.linear_f16(h, self.net[2].weight, self.net[2].bias, residual=residual)
 
 
 _SEG_CACHE = {}
@@ -164,13 +174,11 @@ def _seg_table(kind, B, num_views, device):
 
 def _self_attention(attn, x, residual, table):
     """x (B,N,C) normalised input; returns to_out(attention) + residual."""
-    q = F.linear(x, attn.to_q.weight)
-    k = F.linear(x, attn.to_k.weight)
-    vt = torch.matmul(attn.to_v.weight, x.transpose(1, 2))          # (B, C, N): V^T per head
-    o = ops.mv_attention(q, k, vt.contiguous(), table, attn.heads, x.shape[1])
-    C = residual.shape[-1]
-    return torch.addmm(residual.reshape(-1, C), o.reshape(-1, o.shape[-1]),
-                       attn.to_out[0].weight.t()).add_(attn.to_out[0].bias).view_as(residual)
+    q = ops.linear_f16(x, attn.to_q.weight)
+    k = ops.linear_f16(x, attn.to_k.weight)
+    vt = ops.linear_f16(x, attn.to_v.weight, transposed_tokens=x.shape[1])   # (B, C, N): V^T per head
+    o = ops.mv_attention(q, k, vt, table, attn.heads, x.shape[1])
+    return ops.linear_f16(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=residual)
 
 
 class BasicMVTransformerBlock(nn.Module):
@@ -212,8 +220,8 @@ class BasicMVTransformerBlock(nn.Module):
         ctx = encoder_hidden_states
         if ctx.shape[1] != 1:
             raise NotImplementedError("cross-attention context with more than one token")
-        v = F.linear(ctx[:, 0], self.attn2.to_v.weight)
-        o = F.linear(v, self.attn2.to_out[0].weight, self.attn2.to_out[0].bias)
+        v = ops.linear_f16(ctx[:, 0].contiguous(), self.attn2.to_v.weight)
+        o = ops.linear_f16(v, self.attn2.to_out[0].weight, self.attn2.to_out[0].bias)
         h = h + o[:, None, :]
         h = self.ff(layer_norm(self.norm3, h), h)
         if self.cd_attention_last:
@@ -235,12 +243,12 @@ class TransformerMV2DModel(nn.Module):
     def forward(self, x, encoder_hidden_states):
         B, H, W, C = x.shape
         h = group_norm(self.norm, x)
-        h = F.linear(h.view(B, H * W, C), self.proj_in.weight.view(-1, C), self.proj_in.bias)
+        h = ops.linear_f16(h.view(B, H * W, C), self.proj_in.weight.view(-1, C), self.proj_in.bias)
         for blk in self.transformer_blocks:
             h = blk(h, encoder_hidden_states)
         inner = h.shape[-1]
-        out = torch.addmm(x.view(-1, C), h.view(-1, inner), self.proj_out.weight.view(C, inner).t())
-        return out.add_(self.proj_out.bias).view(B, H, W, C)
+        return ops.linear_f16(h, self.proj_out.weight.view(C, inner), self.proj_out.bias,
+                              residual=x.view(B, H * W, C)).view(B, H, W, C)
 
 
 class _Block(nn.Module):

@@ -746,6 +746,47 @@ def conv2d_nhwc_f16(x_nhwc, w_okc, bias=None, k=3, stride=1, pad=1, upsample2x=F
     return out
 
 
+def linear_f16(x, weight, bias=None, residual=None, transposed_tokens=0, split_k=None):
+    """nn.Linear on the hand-written MFMA kernel.  x (..., K) f16 contiguous, weight (N, K) f16,
+    residual (..., N) added last.  transposed_tokens = T > 0: x is (B, T, K) and the result is
+    (B, N, T) (V^T for mv_attention).  Returns (..., N) f16."""
+    K = x.shape[-1]
+    N = weight.shape[0]
+    M = x.numel() // K
+    f16 = torch.float16
+    assert x.dtype == f16 and weight.dtype == f16 and x.is_contiguous() and weight.is_contiguous()
+    if transposed_tokens:
+        out = torch.empty((M // transposed_tokens, N, transposed_tokens), dtype=f16, device=x.device)
+        split_k = 1
+    else:
+        out = torch.empty(x.shape[:-1] + (N,), dtype=f16, device=x.device)
+    if split_k is None:
+        split_k = int(lib().dsu_gemm_f16_split_k(M, K, N))
+    ws, wbytes = None, 0
+    if split_k > 1:
+        wbytes = int(lib().dsu_gemm_f16_workspace_bytes(M, N, split_k))
+        ws = torch.empty(wbytes // 4, dtype=torch.float32, device=x.device)
+    if residual is not None:
+        assert residual.is_contiguous() and residual.numel() == M * N
+    check(lib().dsu_gemm_f16_fwd(ptr(x, f16), ptr(weight, f16), ptr(bias, f16), M, K, N,
+                                 ptr(residual, f16), ptr(out), int(transposed_tokens), int(split_k),
+                                 ptr(ws), wbytes, stream()), "dsu_gemm_f16_fwd")
+    return out
+
+
+def linear_geglu_f16(x, weight, bias=None):
+    """FeedForward's first layer + GEGLU: x (..., K), weight (2N, K), bias (2N) -> (..., N)."""
+    K = x.shape[-1]
+    N = weight.shape[0] // 2
+    M = x.numel() // K
+    f16 = torch.float16
+    assert x.dtype == f16 and weight.dtype == f16 and x.is_contiguous() and weight.is_contiguous()
+    out = torch.empty(x.shape[:-1] + (N,), dtype=f16, device=x.device)
+    check(lib().dsu_gemm_geglu_fwd(ptr(x, f16), ptr(weight, f16), ptr(bias, f16), M, K, N, ptr(out),
+                                   stream()), "dsu_gemm_geglu_fwd")
+    return out
+
+
 # ------------------------------------------------------------------ norms / activations (f16)
 def groupnorm_nhwc_f16(x, gamma, beta, groups, eps=1e-5, silu=False):
     """x (B,H,W,C) or (B,HW,C) f16 contiguous."""

@@ -472,6 +472,29 @@ int dsu_conv2d_nhwc_f16_fwd_ws(const void* input, const void* weight_okc, const 
                                int32_t split_k, void* workspace, int64_t workspace_bytes,
                                void* stream);
 
+/* nn.Linear forward of the UNet's transformer blocks and embedding MLPs on the same MFMA kernel
+ * (a 1x1 convolution over M rows): Attention.to_q / to_k / to_out, FeedForward.net.2,
+ * TransformerMV2DModel.proj_in / proj_out, TimestepEmbedding, ResnetBlock2D.time_emb_proj
+ * (transformer_mv2d.py:447-483, 304-370; unet_mv2d_condition.py:313-319,374).
+ *   x (M, K) f16 row-major, w (N, K) f16 = the nn.Linear weight as stored, bias (N) or NULL,
+ *   residual (M, N) or NULL (added last), out (M, N) f16, f32 accumulation.  K % 8 == 0.
+ *   tokens_per_image > 0 (M a multiple of it): out is written TRANSPOSED per image,
+ *   out[(m / tokens) * N * tokens + n * tokens + m % tokens] — Attention.to_v, so that
+ *   dsu_mv_attention_fwd reads V^T rows in place; no residual / split-K in that form.
+ *   split_k / workspace as for dsu_conv2d_nhwc_f16_fwd_ws (dsu_gemm_f16_split_k = the library's
+ *   choice, dsu_gemm_f16_workspace_bytes = f32 scratch). */
+int32_t dsu_gemm_f16_split_k(int64_t M, int32_t K, int32_t N);
+int64_t dsu_gemm_f16_workspace_bytes(int64_t M, int32_t N, int32_t split_k);
+int dsu_gemm_f16_fwd(const void* x, const void* w, const void* bias, int64_t M, int32_t K, int32_t N,
+                     const void* residual, void* out, int32_t tokens_per_image, int32_t split_k,
+                     void* workspace, int64_t workspace_bytes, void* stream);
+/* diffusers FeedForward(activation_fn="geglu") first layer fused with its activation
+ * (transformer_mv2d.py:483 -> GEGLU.forward): w (2N, K), bias (2N) or NULL;
+ * out (M, N) = (x w[:N]^T + b[:N]) * gelu_erf(x w[N:]^T + b[N:]); both halves are rounded to f16
+ * before the product, as the unfused nn.Linear output is.  K % 8 == 0, N % 4 == 0. */
+int dsu_gemm_geglu_fwd(const void* x, const void* w, const void* bias, int64_t M, int32_t K,
+                       int32_t N, void* out, void* stream);
+
 /* nn.GroupNorm(G, C, eps) on NHWC f16 (+ optional fused SiLU): diffusers ResnetBlock2D
  * norm1/norm2 + nonlinearity, TransformerMV2DModel.norm (transformer_mv2d.py:304),
  * conv_norm_out + conv_act (unet_mv2d_condition.py:1046-1048).  x/out (B,HW,C) f16;

@@ -84,3 +84,55 @@ def test_conv_f16_split_k_heuristic():
     assert f(12, 4, 4, 1280, 1280, 3, 1, 1, 0) >= 8          # 2 x 10 tiles, 180 chunks
     assert f(12, 8, 8, 1280, 1280, 3, 1, 1, 0) >= 4
     assert f(12, 4, 4, 64, 1280, 1, 1, 0, 0) == 1            # 1 chunk: nothing to split
+
+
+# ---------------------------------------------------------------------------------------------
+# The UNet's linear layers on the same MFMA kernel (dsu_gemm_f16_fwd / dsu_gemm_geglu_fwd)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N", [(12 * 1024, 320, 320), (12 * 256, 640, 640), (12 * 16, 1280, 1280),
+                                   (12, 768, 1280), (12, 1280, 320), (37, 16, 1280), (12 * 64, 1280, 1280)])
+def test_linear_f16_matches_torch(dev, M, K, N):
+    g = torch.Generator().manual_seed(M + K + N)
+    x = torch.randn(M, K, generator=g).half()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).half()
+    b = (torch.randn(N, generator=g) * 0.1).half()
+    r = torch.randn(M, N, generator=g).half()
+    ref = x.float() @ w.float().t() + b.float() + r.float()
+    got = ops.linear_f16(x.to(dev), w.to(dev), b.to(dev), residual=r.to(dev)).cpu().float()
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=4e-3)
+    got = ops.linear_f16(x.to(dev), w.to(dev)).cpu().float()             # no bias, no residual
+    torch.testing.assert_close(got, x.float() @ w.float().t(), rtol=2e-3, atol=4e-3)
+    for sk in (2, 5):                                                       # explicit split-K
+        if K >= 64 * sk:
+            got = ops.linear_f16(x.to(dev), w.to(dev), b.to(dev), residual=r.to(dev), split_k=sk)
+            torch.testing.assert_close(got.cpu().float(), ref, rtol=2e-3, atol=4e-3)
+
+
+@pytest.mark.parametrize("B,T,K,N", [(12, 1024, 320, 320), (12, 16, 1280, 1280), (3, 100, 640, 648)])
+def test_linear_f16_transposed_output_is_v_transposed(dev, B, T, K, N):
+    g = torch.Generator().manual_seed(B + T + K)
+    x = torch.randn(B, T, K, generator=g).half()
+    w = (torch.randn(N, K, generator=g) * K ** -0.5).half()
+    got = ops.linear_f16(x.to(dev), w.to(dev), transposed_tokens=T).cpu().float()
+    ref = torch.matmul(w.float(), x.float().transpose(1, 2))               # (B, N, T)
+    assert got.shape == (B, N, T)
+    torch.testing.assert_close(got, ref, rtol=2e-3, atol=4e-3)
+
+
+@pytest.mark.parametrize("M,C", [(12 * 1024, 320), (12 * 64, 1280), (19, 640), (130, 328)])
+def test_linear_geglu_matches_unfused_reference(dev, M, C):
+    """diffusers GEGLU: proj -> chunk(2) -> a * gelu(g), the projection rounded to f16 first."""
+    g = torch.Generator().manual_seed(M + C)
+    N = 4 * C
+    x = torch.randn(M, C, generator=g).half()
+    w = (torch.randn(2 * N, C, generator=g) * C ** -0.5).half()
+    b = (torch.randn(2 * N, generator=g) * 0.1).half()
+    proj = (x.float() @ w.float().t() + b.float()).half().float()
+    a, gate = proj.chunk(2, -1)
+    ref = a * torch.nn.functional.gelu(gate)
+    got = ops.linear_geglu_f16(x.to(dev), w.to(dev), b.to(dev)).cpu().float()
+    assert got.shape == (M, N)
+    # one f16 ulp of the projection can flip under a different accumulation order
+    torch.testing.assert_close(got, ref, rtol=4e-3, atol=6e-3)
+    fused_old = ops.geglu_f16((x.to(dev) @ w.to(dev).t() + b.to(dev)).contiguous()).cpu().float()
+    torch.testing.assert_close(got, fused_old, rtol=4e-3, atol=6e-3)
