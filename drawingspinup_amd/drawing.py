@@ -121,7 +121,11 @@ class DrawingPipeline:
         col = up(colors).permute(0, 2, 3, 1)
         nrm = up(normals).permute(0, 2, 3, 1) * 2 - 1                      # img2normal
         alpha = F.interpolate(drawing_rgba[3:4][None], size=(size, size), mode="nearest")[0, 0]
-        masks = torch.stack([alpha, alpha, alpha, alpha.flip(1), alpha, alpha]) > 0.5
+        # front: the drawing's alpha, back: mirrored (mv.py:113-116); side views: matte of the
+        # predicted colour image (distance to the white background, entry/data.py
+        # side_mask_from_prediction — the reference runs a CPU ONNX matting model there)
+        side = (1.0 - col).amax(-1) > 12.0 / 255.0
+        masks = torch.stack([alpha > 0.5, side[1], side[2], alpha.flip(1) > 0.5, side[4], side[5]])
         nrm = nrm * masks[..., None]
         front = torch.from_numpy(inv_rt(rt_opengl2opencv(ideal_w2c("front")))[:3, :3]).float().to(dev)
         n_cv = nrm * torch.tensor([1.0, -1.0, -1.0], device=dev)           # normal_opengl2opencv

@@ -69,24 +69,61 @@ def mv_batch(single_image, pose_dir=None, size=256):
     return imgs, torch.cat([cam, task], -1)
 
 
+ADD_GRAY_UIDS = ("0b39d3ae37ee430dbe721cdcc40e270c", "b2f0411a69b149088282f262b77970a7",
+                 "7d64695e10134f4883cf0f646c21ed30")        # mv.py:59-61
+
+
+def add_gray(img):
+    """mv.py:153-158: darken the colours to 80 % over white, alpha kept."""
+    a = np.array(img, dtype=np.float32)
+    rgb = a[:, :, 0:3] * 0.8
+    mask = a[:, :, 3:4] / 255.0
+    a[:, :, 0:3] = rgb * mask + 255 * (1 - mask)
+    return Image.fromarray(a.astype(np.uint8))
+
+
+def side_mask_from_prediction(image_pil, threshold=12):
+    """Foreground matte of a predicted side view.  The reference runs the isnet-dis ONNX matting
+    network on the predicted colour image (mv.py:105-150, a third-party CPU model whose weights
+    are not in the snapshot); the diffusion model renders its views on a white background, so the
+    stand-in here is the distance to white: 255 where any channel is more than `threshold` grey
+    levels below white.  `write_mv_outputs(..., matting_fn=...)` takes the real matting model."""
+    a = np.array(image_pil.convert("RGB"), np.int16)
+    return Image.fromarray((((255 - a).max(-1) > threshold) * 255).astype(np.uint8), "L")
+
+
 def tensor2pil(t):                      # mv.py:47-49
     nd = t.mul(255).add_(0.5).clamp_(0, 255).permute(1, 2, 0).to("cpu", torch.uint8).numpy()
     return Image.fromarray(nd)
 
 
-def write_mv_outputs(out_dir, normals, colors, single_image, res=(1024, 1024)):
-    """mv.py:105-126 — LANCZOS 1024^2 PNGs; masks: input alpha (front), mirrored (back); the side
-    views' isnet-ONNX matting of the reference is a CPU third-party model outside this path, the
-    input alpha is written for them as well (documented deviation)."""
+NORMAL_MATTE_UIDS = ("01522711d3b642ddbfb506307a007990", "1a2fd47487a24c4c84f2c7d0f7d35147",
+                     "1f1654afb5aa4f8daa5db9a96351c226", "d77b86a6b2024cffa36f010e72c0a2af")   # mv.py:118-122
+
+
+def write_mv_outputs(out_dir, normals, colors, single_image, res=(1024, 1024), uid=None,
+                     matting_fn=None):
+    """mv.py:105-126 — LANCZOS 1024^2 PNGs; masks: the input alpha (front), mirrored (back), and for
+    the four side views a matte of the PREDICTED image (colour, or the normal map for the uids of
+    mv.py:118-122): `matting_fn(pil) -> 'L' image` (the reference's isnet-dis session), default
+    `side_mask_from_prediction`."""
+    matting_fn = matting_fn or side_mask_from_prediction
     for sub in ("normal", "color", "mask"):
         os.makedirs(os.path.join(out_dir, sub), exist_ok=True)
     mask_front = single_image.split()[-1]
     mask_back = ImageOps.mirror(mask_front)
     for j, view in enumerate(VIEWS):
-        tensor2pil(normals[j].float()).resize(res, Image.LANCZOS).save(os.path.join(out_dir, "normal", f"{view}.png"))
-        tensor2pil(colors[j].float()).resize(res, Image.LANCZOS).save(os.path.join(out_dir, "color", f"{view}.png"))
-        m = mask_back if view == "back" else mask_front
-        m.resize(res, Image.NEAREST).save(os.path.join(out_dir, "mask", f"{view}.png"))
+        normal = tensor2pil(normals[j].float()).resize(res, Image.LANCZOS)
+        color = tensor2pil(colors[j].float()).resize(res, Image.LANCZOS)
+        if view == "front":
+            m = mask_front.resize(res, Image.NEAREST)
+        elif view == "back":
+            m = mask_back.resize(res, Image.NEAREST)
+        else:
+            m = matting_fn(normal if uid in NORMAL_MATTE_UIDS else color)
+        normal.save(os.path.join(out_dir, "normal", f"{view}.png"))
+        color.save(os.path.join(out_dir, "color", f"{view}.png"))
+        m.save(os.path.join(out_dir, "mask", f"{view}.png"))
 
 
 # ------------------------------------------------------------------ ortho dataset (recon.py)

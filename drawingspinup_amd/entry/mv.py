@@ -20,15 +20,37 @@ def main(argv=None):
     ap.add_argument("--data_root", default="../dataset/AnimatedDrawings/preprocessed")
     ap.add_argument("--uid_list_file", default="../dataset/AnimatedDrawings/drawings_uids.json")
     ap.add_argument("--pose_dir", default=None, help=".../mvdiffusion/data/fixed_poses/nine_views")
-    ap.add_argument("--unet_state_dict", default=None, help="UNet state_dict (diffusers key names)")
+    ap.add_argument("--pretrained", default=None,
+                    help="local diffusers-layout directory of the Wonder3D checkpoint "
+                         "(unet/, vae/, image_encoder/): what mv.py:29-39 downloads from the hub")
+    ap.add_argument("--unet_state_dict", default=None, help="UNet weights file (diffusers key names)")
+    ap.add_argument("--vae_state_dict", default=None, help="VAE weights file (diffusers key names)")
+    ap.add_argument("--image_encoder", default=None, help="local CLIP vision directory (config + weights)")
+    ap.add_argument("--random_init", action="store_true",
+                    help="run with random weights for whatever was not given (smoke tests only: the "
+                         "outputs are noise)")
     ap.add_argument("--seed", type=int, default=123456)         # configs/mvdiffusion-joint-ortho-6views.yaml:1
     ap.add_argument("--num_inference_steps", type=int, default=75)
     args = ap.parse_args(argv)
     rank, world, local = ddist.init()
     dev = torch.device("cuda", local)
-    pipe = build_random_pipeline(dev, seed=0)
-    if args.unet_state_dict:
-        pipe.unet.load_state_dict(torch.load(args.unet_state_dict, map_location="cpu"))
+    from ..mv import checkpoint as ck
+    if args.pretrained:
+        pipe = ck.load_pipeline(args.pretrained, dev)
+    else:
+        missing = [n for n, v in (("--unet_state_dict", args.unet_state_dict),
+                                  ("--vae_state_dict", args.vae_state_dict),
+                                  ("--image_encoder", args.image_encoder)) if not v]
+        if missing and not args.random_init:
+            raise SystemExit("mv: no weights for " + ", ".join(missing) + " (give --pretrained DIR or "
+                             "the three files; --random_init runs on random weights and produces noise)")
+        pipe = build_random_pipeline(dev, seed=0)
+        if args.unet_state_dict:
+            ck.load_unet(pipe.unet, args.unet_state_dict)
+        if args.vae_state_dict:
+            ck.load_vae(pipe.vae, args.vae_state_dict)
+        if args.image_encoder:
+            pipe.image_encoder = ck.load_image_encoder(args.image_encoder, dev)
     for m in (pipe.unet, pipe.vae, pipe.image_encoder):
         ddist.broadcast_module(m, 0)
     uids = json.load(open(args.uid_list_file)) if args.all else [args.uid]
@@ -36,12 +58,17 @@ def main(argv=None):
         img_fn = os.path.join(args.data_root, uid, args.img_fn)
         if not os.path.exists(img_fn):
             img_fn = os.path.join(args.data_root, uid, "char/texture.png")
-        single = Image.open(img_fn).convert("RGBA")
+        single = Image.open(img_fn)                         # char/*.png are RGBA (mv.py:58)
+        if single.mode != "RGBA":
+            single = single.convert("RGBA")
+        if uid in D.ADD_GRAY_UIDS:                          # mv.py:59-62
+            single = D.add_gray(single)
         imgs, cam = D.mv_batch(single, args.pose_dir)
         g = torch.Generator(device=dev).manual_seed(args.seed)
         out = pipe(imgs.to(dev), cam.to(dev), generator=g, guidance_scale=1.0, output_type="pt",
                    eta=1.0, num_inference_steps=args.num_inference_steps)
-        D.write_mv_outputs(os.path.join(args.data_root, uid, args.save_folder), out[:6], out[6:], single)
+        D.write_mv_outputs(os.path.join(args.data_root, uid, args.save_folder), out[:6], out[6:], single,
+                           uid=uid)
         print(uid, flush=True)
 
 

@@ -24,7 +24,7 @@ def test_entry_points_chain(dev, tmp_path):
     root, uid = str(tmp_path), "uid0"
     os.makedirs(os.path.join(root, uid, "char"))
     _drawing().save(os.path.join(root, uid, "char", "ffc_resnet_inpainted.png"))
-    mv.main(["--uid", uid, "--data_root", root, "--num_inference_steps", "2"])
+    mv.main(["--uid", uid, "--data_root", root, "--num_inference_steps", "2", "--random_init"])
     for sub in ("color", "normal", "mask"):
         files = sorted(os.listdir(os.path.join(root, uid, "mv", sub)))
         assert files == sorted(f"{v}.png" for v in ("front", "front_right", "right", "back", "left", "front_left"))
