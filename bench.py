@@ -258,6 +258,8 @@ def bench_drawing(args, ddist, rank, world, dev, timer):
                            n_frames=args.frames)
     bcast_bytes = sum(ddist.broadcast_module(m, 0) for m in pipe.shared_modules())
     stage_t = {"contour": 0.0, "mv": 0.0, "nsr": 0.0, "style": 0.0}
+    sub_t = {"nsr_fit": 0.0, "nsr_export": 0.0}
+    pipe.time_substages = True               # one extra synchronize between fit and export
 
     def one_drawing(s, timed):
         seed = (rank * 100 + s) if timed else (1000 + rank * 100 + s)
@@ -274,6 +276,8 @@ def bench_drawing(args, ddist, rank, world, dev, timer):
         if timed:
             for k, v in zip(stage_t, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
                 stage_t[k] += v
+            for k in sub_t:
+                sub_t[k] += pipe.substage_seconds.get(k, 0.0)
         return colors, inside.sum(), frames
 
     elapsed, last = _timed_loop(args, ddist, dev, timer, one_drawing)
@@ -281,6 +285,7 @@ def bench_drawing(args, ddist, rank, world, dev, timer):
     if rank != 0:
         return None
     per = {k: v / args.steps for k, v in stage_t.items()}
+    per.update({k: v / args.steps for k, v in sub_t.items()})
     stages = {
         "mv": {"bound": "mfma", "unit": "TFLOP/s", "peak": F16_MFMA_PEAK_TF,
                "achieved": 2.913 * args.mv_steps / max(per["mv"], 1e-9)},

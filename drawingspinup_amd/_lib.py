@@ -69,6 +69,15 @@ _PROTOS = {
     "dsu_sdf_fd_bwd_cached": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, c_i64, c_f32, c_f32,
                               c_u32, P, P, P, P, P, P, P, P, P, P, c_i64, P, P],
     "dsu_sdf_fd_enc_cache_bytes": [c_i64, c_u32],
+    "dsu_sdf_fd_fwd_sorted": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, P, c_i64, c_f32,
+                              c_f32, c_u32, P, P, P, P, P, P],
+    "dsu_sdf_fd_bwd_sorted": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, P, c_i64, c_f32,
+                              c_f32, c_u32, P, P, P, P, P, P, P, P, P, P, c_i64, P, P],
+    "dsu_smooth_iterate": [P, c_i64, P, C.c_double, c_i32, P, P, P],
+    "dsu_smooth_energy": [P, c_i64, P, P, P, P],
+    "dsu_smooth_energy_partials": [],
+    "dsu_spatial_sort": [P, c_i64, c_f32, c_i32, P, P, P, c_i64, P],
+    "dsu_spatial_sort_workspace_bytes": [c_i64, c_i32],
     "dsu_ray_aabb": [P, P, c_i64, P, P, c_f32, P, P, P],
     "dsu_ray_march_count": [P, P, P, P, c_i64, P, P, c_i32, c_f32, P, P],
     "dsu_ray_march_fill": [P, P, P, P, c_i64, P, P, c_i32, c_f32, P, P, P, P, P],

@@ -202,6 +202,67 @@ __device__ __forceinline__ void mlp_stream(const float* lds, const float* in, in
   }
 }
 
+// Same chains with the weights read through the SCALAR cache (constant address space, uniform
+// addresses -> s_load into SGPR operands of the FMAs) instead of LDS broadcasts: a wave-wide
+// ds_read_b128 occupies the CU's one LDS port for 8 clocks whether or not the lanes share the
+// address, 368 of them per evaluation made the LDS port, shared by the four SIMDs, the kernel's
+// bottleneck (-DDSU_FWD_SGPR_W).
+typedef __attribute__((address_space(4))) const float cfloat_t;
+__device__ __forceinline__ const cfloat_t* as_const(const float* p) {
+  return (const cfloat_t*)(uintptr_t)p;
+}
+
+template <int NL, int NO, int LMAX = NL>
+__device__ __forceinline__ void mlp_stream_sgpr(const dsu_sdf_mlp& mlp, const float* in, int kmax,
+                                                float* out /*NO*/) {
+  constexpr int DIN = 3 + 2 * NL;
+  const cfloat_t* w0 = as_const(mlp.w0);
+  const cfloat_t* b0 = as_const(mlp.b0);
+  const cfloat_t* w1 = as_const(mlp.w1);
+  const cfloat_t* b1 = as_const(mlp.b1);
+#pragma unroll
+  for (int o = 0; o < NO; ++o) out[o] = b1[o];
+#pragma unroll 1
+  for (int j = 0; j < HID; j += 4) {
+    float p0 = b0[j], p1 = b0[j + 1], p2 = b0[j + 2], p3 = b0[j + 3];
+#pragma unroll
+    for (int k = 0; k < 3 + 2 * LMAX; ++k) {
+      if (k < kmax) {
+        const float v = in[k];
+        p0 = fmaf(w0[(j + 0) * DIN + k], v, p0);
+        p1 = fmaf(w0[(j + 1) * DIN + k], v, p1);
+        p2 = fmaf(w0[(j + 2) * DIN + k], v, p2);
+        p3 = fmaf(w0[(j + 3) * DIN + k], v, p3);
+      }
+    }
+    p0 = softplus100(p0); p1 = softplus100(p1); p2 = softplus100(p2); p3 = softplus100(p3);
+#pragma unroll
+    for (int o = 0; o < NO; ++o) {
+      float acc = out[o];
+      acc = fmaf(w1[o * HID + j + 0], p0, acc);
+      acc = fmaf(w1[o * HID + j + 1], p1, acc);
+      acc = fmaf(w1[o * HID + j + 2], p2, acc);
+      acc = fmaf(w1[o * HID + j + 3], p3, acc);
+      out[o] = acc;
+    }
+  }
+}
+
+// default: scalar-cache weights (measured on MI355X, 262 144 ray-ordered samples: forward 0.225 ->
+// 0.173 ms at 4 levels, 0.309 -> 0.236 ms at 7; 77 instead of 135-156 VGPRs, no LDS at all).
+// -DDSU_FWD_LDS_W keeps the LDS-broadcast form for A/B runs.
+#ifndef DSU_FWD_LDS_W
+#define DSU_MLP_STREAM(NLv, NOv, LMAXv, lds, mlp, in, kmax, out) \
+  mlp_stream_sgpr<NLv, NOv, LMAXv>(mlp, in, kmax, out)
+#define DSU_FWD_LOAD_MLP(NLv, lds, mlp)
+#define DSU_FWD_LDS_BYTES(NLv) ((size_t)0)
+#else
+#define DSU_MLP_STREAM(NLv, NOv, LMAXv, lds, mlp, in, kmax, out) \
+  mlp_stream<NLv, NOv, LMAXv>(lds, in, kmax, out)
+#define DSU_FWD_LOAD_MLP(NLv, lds, mlp) load_mlp_to_lds<NLv>(lds, mlp.w0, mlp.b0, mlp.w1, mlp.b1)
+#define DSU_FWD_LDS_BYTES(NLv) (MlpLds<NLv>::TOTAL * sizeof(float))
+#endif
+
 template <int NL, int NO>
 __global__ __launch_bounds__(256) void sdf_fwd_kernel(const __half2* __restrict__ table,
                                                       GridMeta m, dsu_sdf_mlp mlp,
@@ -210,7 +271,7 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(const __half2* __restrict_
                                                       float* __restrict__ out) {
   using L = MlpLds<NL>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  load_mlp_to_lds<NL>(lds, mlp.w0, mlp.b0, mlp.w1, mlp.b1);
+  DSU_FWD_LOAD_MLP(NL, lds, mlp);
   const int kmax = 3 + 2 * (int)active;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -220,7 +281,7 @@ __global__ __launch_bounds__(256) void sdf_fwd_kernel(const __half2* __restrict_
     float in[L::DIN];
     encode_input<NL>(table, m, active, x, y, z, in);
     float o_[NO];
-    mlp_stream<NL, NO>(lds, in, kmax, o_);
+    DSU_MLP_STREAM(NL, NO, NL, lds, mlp, in, kmax, o_);
 #pragma unroll
     for (int o = 0; o < NO; ++o) out[i * NO + o] = o_[o];
   }
@@ -234,14 +295,19 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
     const __half2* __restrict__ table, GridMeta m, dsu_sdf_mlp mlp,
     const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
     uint32_t active, float* __restrict__ sdf, float* __restrict__ grad,
-    float* __restrict__ feature, float* __restrict__ laplace, __half2* __restrict__ enc) {
+    float* __restrict__ feature, float* __restrict__ laplace, __half2* __restrict__ enc,
+    const int32_t* __restrict__ perm) {
   using L = MlpLds<NL>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  load_mlp_to_lds<NL>(lds, mlp.w0, mlp.b0, mlp.w1, mlp.b1);
+  DSU_FWD_LOAD_MLP(NL, lds, mlp);
   const int kmax = 3 + 2 * (int)active;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const float p[3] = {pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2]};
+    // spatially sorted evaluation order (spatial_sort.hip): point i of `pts` is point perm[i] of
+    // the caller's order; the per-point outputs go back to the caller's rows, the feature cache
+    // stays in evaluation order (the backward pass walks it in the same order)
+    const int64_t oi = perm ? (int64_t)perm[i] : i;
     float s[7];
 #pragma unroll 1
     for (int e = 0; e < 7; ++e) {
@@ -269,29 +335,29 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
       }
       if (e == 0 && feature != nullptr) {
         float o_[NOUT];
-        mlp_stream<NL, NOUT, LMAX>(lds, in, kmax, o_);
+        DSU_MLP_STREAM(NL, NOUT, LMAX, lds, mlp, in, kmax, o_);
         s[0] = o_[0];
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) feature[i * NOUT + o] = o_[o];
+        for (int o = 0; o < NOUT; ++o) feature[oi * NOUT + o] = o_[o];
       } else {
         float o_[1];
-        mlp_stream<NL, 1, LMAX>(lds, in, kmax, o_);
+        DSU_MLP_STREAM(NL, 1, LMAX, lds, mlp, in, kmax, o_);
         s[e] = o_[0];
       }
     }
-    sdf[i] = s[0];
+    sdf[oi] = s[0];
     if (grad != nullptr) {
       // 0.5 * (sdf(+eps) - sdf(-eps)) / eps   (geometry.py:173)
-      grad[i * 3 + 0] = 0.5f * (s[1] - s[2]) / eps;
-      grad[i * 3 + 1] = 0.5f * (s[3] - s[4]) / eps;
-      grad[i * 3 + 2] = 0.5f * (s[5] - s[6]) / eps;
+      grad[oi * 3 + 0] = 0.5f * (s[1] - s[2]) / eps;
+      grad[oi * 3 + 1] = 0.5f * (s[3] - s[4]) / eps;
+      grad[oi * 3 + 2] = 0.5f * (s[5] - s[6]) / eps;
     }
     if (laplace != nullptr) {
       // (sdf(+)+sdf(-)-2 sdf).sum(-1) / eps^2   (geometry.py:176)
       float t0 = s[1] + s[2] - 2.0f * s[0];
       float t1 = s[3] + s[4] - 2.0f * s[0];
       float t2 = s[5] + s[6] - 2.0f * s[0];
-      laplace[i] = ((t0 + t1) + t2) / eps2;
+      laplace[oi] = ((t0 + t1) + t2) / eps2;
     }
   }
 }
@@ -708,7 +774,7 @@ int dsu_sdf_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, const d
   hipStream_t s = (hipStream_t)stream;
   const int blocks = dsu_capped_blocks(n, 256, 8192);
   DSU_DISPATCH_NL(cfg->n_levels, {
-    const size_t shm = MlpLds<NL>::TOTAL * sizeof(float);
+    const size_t shm = DSU_FWD_LDS_BYTES(NL);
     if (n_out == 1)
       sdf_fwd_kernel<NL, 1><<<dim3(blocks), dim3(256), shm, s>>>(
           (const __half2*)table_f16, m, *mlp, pts, n, radius, active_levels, out);
@@ -723,7 +789,7 @@ int dsu_sdf_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, const d
 int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
                    const float* pts, int64_t n, float radius, float eps,
                    uint32_t active_levels, float* sdf, float* grad, float* feature,
-                   float* laplace, void* enc_cache, void* stream) {
+                   float* laplace, void* enc_cache, const int32_t* perm, void* stream) {
   if (!cfg || !table_f16 || !mlp || (!pts && n) || (!sdf && n) || n < 0) return DSU_EINVAL;
   if (!mlp->w0 || !mlp->b0 || !mlp->w1 || !mlp->b1) return DSU_EINVAL;
   if (active_levels > cfg->n_levels || !(eps > 0.0f)) return DSU_EINVAL;
@@ -735,15 +801,15 @@ int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, cons
   const float eps2 = (float)((double)eps * (double)eps);
   const int blocks = dsu_capped_blocks(n, 256, 8192);
   DSU_DISPATCH_NL(cfg->n_levels, {
-    const size_t shm = MlpLds<NL>::TOTAL * sizeof(float);
+    const size_t shm = DSU_FWD_LDS_BYTES(NL);
     if (active_levels <= 6)
       sdf_fd_fwd_kernel<NL, 6><<<dim3(blocks), dim3(256), shm, s>>>(
           (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, sdf, grad,
-          feature, laplace, (__half2*)enc_cache);
+          feature, laplace, (__half2*)enc_cache, perm);
     else
       sdf_fd_fwd_kernel<NL, NL><<<dim3(blocks), dim3(256), shm, s>>>(
           (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, sdf, grad,
-          feature, laplace, (__half2*)enc_cache);
+          feature, laplace, (__half2*)enc_cache, perm);
   });
   DSU_CHECK_LAUNCH();
   return DSU_OK;

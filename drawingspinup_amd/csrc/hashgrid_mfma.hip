@@ -412,7 +412,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     uint32_t active, const float* __restrict__ d_sdf, const float* __restrict__ d_grad,
     const float* __restrict__ d_feature, const float* __restrict__ d_laplace,
     float* __restrict__ gtable, float* __restrict__ partials, const __half2* __restrict__ enc,
-    float2* __restrict__ dinbuf, int ablate) {
+    float2* __restrict__ dinbuf, const int32_t* __restrict__ perm, int ablate) {
   constexpr int KIN = MC<NL>::KIN;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* w1perm = lds;
@@ -470,10 +470,12 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     const int64_t ii = valid ? i : n - 1;
     const float p[3] = {pts[ii * 3], pts[ii * 3 + 1], pts[ii * 3 + 2]};
     float ds = 0.f, dl = 0.f, dg[3] = {0.f, 0.f, 0.f};
+    // sorted evaluation order: the upstream gradients stay in the caller's row order
+    const int64_t gi = perm ? (int64_t)perm[ii] : ii;
     if (valid) {
-      if (d_sdf) ds = d_sdf[i];
-      if (d_laplace) dl = d_laplace[i];
-      if (d_grad) { dg[0] = d_grad[i * 3]; dg[1] = d_grad[i * 3 + 1]; dg[2] = d_grad[i * 3 + 2]; }
+      if (d_sdf) ds = d_sdf[gi];
+      if (d_laplace) dl = d_laplace[gi];
+      if (d_grad) { dg[0] = d_grad[gi * 3]; dg[1] = d_grad[gi * 3 + 1]; dg[2] = d_grad[gi * 3 + 2]; }
     }
 #pragma unroll 1
     for (int e = 0; e < 7; ++e) {
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
         if (e == 0) {
           if (d_feature) {
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) dout[o] = d_feature[i * NOUT + o];
+            for (int o = 0; o < NOUT; ++o) dout[o] = d_feature[gi * NOUT + o];
           }
           dout[0] += ds - 6.0f * dl / eps2;
         } else {
@@ -733,7 +735,13 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
               }
               const int key = (int)(cp.c[0] | (cp.c[1] << 10) | (cp.c[2] << 20));
               const int l15 = lane & 15;
-              int e = (l15 == 15 || dpp_i<0x101>(key) != key) ? 1 : 0;   // run ends at this lane
+              // The neighbour keys are fetched with ALL lanes active: written as
+              // `l15 == 15 || dpp(key) != key`, the short-circuit put the DPP move under a reduced
+              // EXEC mask, a disabled source lane reads as 0 (bound_ctrl), and lanes 14 / 1 of every
+              // row then always saw "different cell": lane 15's share of a run was dropped and
+              // lane 1's counted twice whenever they shared the cell of their neighbour.
+              const int key_next = dpp_i<0x101>(key), key_prev = dpp_i<0x111>(key);
+              int e = ((l15 == 15) | (key_next != key)) ? 1 : 0;   // run ends at this lane
 #define DSU_SEG_STEP(CTRL)                                              \
               {                                                         \
                 const int eo = dpp_i<CTRL>(e);                          \
@@ -745,7 +753,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
               }
               DSU_SEG_STEP(0x101) DSU_SEG_STEP(0x102) DSU_SEG_STEP(0x104) DSU_SEG_STEP(0x108)
 #undef DSU_SEG_STEP
-              lead = (l15 == 0 || dpp_i<0x111>(key) != key) && !DSU_ABL(4);  // first of its run
+              lead = ((l15 == 0) | (key_prev != key)) && !DSU_ABL(4);  // first of its run
             }
             const unsigned long long bal = __ballot(lead);
             if (lead) {
@@ -907,7 +915,10 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
         }
         const int key = (int)(cp.c[0] | (cp.c[1] << 10) | (cp.c[2] << 20));
         const int l15 = lane & 15;
-        int ee = (l15 == 15 || dpp_i<0x101>(key) != key) ? 1 : 0;   // run ends at this lane
+        // neighbour keys with all lanes active (see the fused kernel: a DPP move under the EXEC
+        // mask of a short-circuit reads disabled source lanes as 0)
+        const int key_next = dpp_i<0x101>(key), key_prev = dpp_i<0x111>(key);
+        int ee = ((l15 == 15) | (key_next != key)) ? 1 : 0;   // run ends at this lane
 #define DSU_SEG_STEP(CTRL)                                              \
         {                                                               \
           const int eo = dpp_i<CTRL>(ee);                               \
@@ -919,7 +930,7 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
         }
         DSU_SEG_STEP(0x101) DSU_SEG_STEP(0x102) DSU_SEG_STEP(0x104) DSU_SEG_STEP(0x108)
 #undef DSU_SEG_STEP
-        const bool lead = l15 == 0 || dpp_i<0x111>(key) != key;
+        const bool lead = (l15 == 0) | (key_prev != key);
         const unsigned long long bal = __ballot(lead);
         if (lead) {
           const int pos = qn + 8 * __popcll(bal & ((1ull << lane) - 1ull));
@@ -1008,7 +1019,7 @@ extern "C" int dsu_sdf_fwd_valu(const dsu_hashgrid_cfg*, const void*, const dsu_
                                 const float*, int64_t, float, uint32_t, uint32_t, float*, void*);
 extern "C" int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg*, const void*, const dsu_sdf_mlp*,
                                    const float*, int64_t, float, float, uint32_t, float*, float*,
-                                   float*, float*, void*, void*);
+                                   float*, float*, void*, const int32_t*, void*);
 extern "C" int dsu_sdf_fd_bwd_valu(const dsu_hashgrid_cfg*, const void*, const dsu_sdf_mlp*,
                                    const float*, int64_t, float, float, uint32_t, const float*,
                                    const float*, const float*, const float*, float*, float*,
@@ -1022,13 +1033,9 @@ extern "C" int64_t dsu_sdf_fd_bwd_workspace_bytes_valu(const dsu_hashgrid_cfg*, 
 // Default (measured round 2, N = 262 144 ray-ordered samples at the training step size, 4/5/6 levels):
 //   fused 0.60 / 0.72 / 0.85 ms, two kernels 0.54 / 0.61 / 0.71 ms -> two kernels.
 // DSU_BWD_SPLIT=0 selects the fused kernel.
-static bool bwd_split() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("DSU_BWD_SPLIT");
-    v = (e && atoi(e) == 0) ? 0 : 1;
-  }
-  return v == 1;
+static bool bwd_split() {          // read per call: the tests run both forms in one process
+  const char* e = getenv("DSU_BWD_SPLIT");
+  return !(e && atoi(e) == 0);
 }
 
 static bool use_valu(bool forward) {
@@ -1069,13 +1076,14 @@ int dsu_sdf_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sd
   return DSU_OK;
 }
 
-int dsu_sdf_fd_fwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
-                   const float* pts, int64_t n, float radius, float eps,
+int dsu_sdf_fd_fwd_sorted(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                   const float* pts, const int32_t* perm, int64_t n, float radius, float eps,
                    uint32_t active_levels, float* sdf, float* grad, float* feature,
                    float* laplace, void* enc_cache, void* stream) {
-  if (use_valu(true) || enc_cache != nullptr)   // the cache is written by the VALU kernel
+  // the cache and the permuted write-back are features of the VALU kernel
+  if (use_valu(true) || enc_cache != nullptr || perm != nullptr)
     return dsu_sdf_fd_fwd_valu(cfg, table_f16, mlp, pts, n, radius, eps, active_levels, sdf, grad,
-                               feature, laplace, enc_cache, stream);
+                               feature, laplace, enc_cache, perm, stream);
   if (!cfg || !table_f16 || !mlp || (!pts && n) || (!sdf && n) || n < 0) return DSU_EINVAL;
   if (!mlp->w0 || !mlp->b0 || !mlp->w1 || !mlp->b1) return DSU_EINVAL;
   if (active_levels > cfg->n_levels || !(eps > 0.0f)) return DSU_EINVAL;
@@ -1095,12 +1103,20 @@ int dsu_sdf_fd_fwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16, co
   return DSU_OK;
 }
 
+int dsu_sdf_fd_fwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16,
+                          const dsu_sdf_mlp* mlp, const float* pts, int64_t n, float radius,
+                          float eps, uint32_t active_levels, float* sdf, float* grad,
+                          float* feature, float* laplace, void* enc_cache, void* stream) {
+  return dsu_sdf_fd_fwd_sorted(cfg, table_f16, mlp, pts, nullptr, n, radius, eps, active_levels,
+                               sdf, grad, feature, laplace, enc_cache, stream);
+}
+
 int dsu_sdf_fd_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
                    const float* pts, int64_t n, float radius, float eps,
                    uint32_t active_levels, float* sdf, float* grad, float* feature,
                    float* laplace, void* stream) {
-  return dsu_sdf_fd_fwd_cached(cfg, table_f16, mlp, pts, n, radius, eps, active_levels, sdf, grad,
-                               feature, laplace, nullptr, stream);
+  return dsu_sdf_fd_fwd_sorted(cfg, table_f16, mlp, pts, nullptr, n, radius, eps, active_levels,
+                               sdf, grad, feature, laplace, nullptr, stream);
 }
 
 int64_t dsu_sdf_fd_enc_cache_bytes(int64_t n, uint32_t active_levels) {
@@ -1119,12 +1135,13 @@ int64_t dsu_sdf_fd_bwd_workspace_bytes(const dsu_hashgrid_cfg* cfg, int64_t n) {
   return bytes;
 }
 
-int dsu_sdf_fd_bwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
-                   const float* pts, int64_t n, float radius, float eps,
+int dsu_sdf_fd_bwd_sorted(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                   const float* pts, const int32_t* perm, int64_t n, float radius, float eps,
                    uint32_t active_levels, const float* d_sdf, const float* d_grad,
                    const float* d_feature, const float* d_laplace, float* grad_table,
                    float* g_w0, float* g_b0, float* g_w1, float* g_b1, void* workspace,
                    int64_t workspace_bytes, const void* enc_cache, void* stream) {
+  if (use_valu(false) && perm) return DSU_EUNSUP;
   if (use_valu(false))
     return dsu_sdf_fd_bwd_valu(cfg, table_f16, mlp, pts, n, radius, eps, active_levels, d_sdf,
                                d_grad, d_feature, d_laplace, grad_table, g_w0, g_b0, g_w1, g_b1,
@@ -1163,7 +1180,7 @@ int dsu_sdf_fd_bwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16, co
       k1<<<dim3(blocks), dim3(256), shm1, s>>>(
           (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
           d_grad, d_feature, d_laplace, grad_table, (float*)workspace, (const __half2*)enc_cache,
-          dinbuf, ablate);
+          dinbuf, perm, ablate);
       k2<<<dim3(sblocks), dim3(SC_THREADS), shm2, s>>>(m, pts, n, radius, eps, active_levels,
                                                       dinbuf, grad_table);
       reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 63) / 64), dim3(1024), 0, s>>>(
@@ -1181,12 +1198,24 @@ int dsu_sdf_fd_bwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16, co
     k0<<<dim3(blocks), dim3(256), shm, s>>>(
         (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
         d_grad, d_feature, d_laplace, grad_table, (float*)workspace, (const __half2*)enc_cache,
-        nullptr, ablate);
+        nullptr, perm, ablate);
     reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 63) / 64), dim3(1024), 0, s>>>(
         (const float*)workspace, blocks, g_w0, g_b0, g_w1, g_b1);
   });
   DSU_CHECK_LAUNCH();
   return DSU_OK;
+}
+
+int dsu_sdf_fd_bwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16,
+                          const dsu_sdf_mlp* mlp, const float* pts, int64_t n, float radius,
+                          float eps, uint32_t active_levels, const float* d_sdf,
+                          const float* d_grad, const float* d_feature, const float* d_laplace,
+                          float* grad_table, float* g_w0, float* g_b0, float* g_w1, float* g_b1,
+                          void* workspace, int64_t workspace_bytes, const void* enc_cache,
+                          void* stream) {
+  return dsu_sdf_fd_bwd_sorted(cfg, table_f16, mlp, pts, nullptr, n, radius, eps, active_levels,
+                               d_sdf, d_grad, d_feature, d_laplace, grad_table, g_w0, g_b0, g_w1,
+                               g_b1, workspace, workspace_bytes, enc_cache, stream);
 }
 
 int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
@@ -1195,9 +1224,9 @@ int dsu_sdf_fd_bwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu
                    const float* d_feature, const float* d_laplace, float* grad_table,
                    float* g_w0, float* g_b0, float* g_w1, float* g_b1, void* workspace,
                    int64_t workspace_bytes, void* stream) {
-  return dsu_sdf_fd_bwd_cached(cfg, table_f16, mlp, pts, n, radius, eps, active_levels, d_sdf,
-                               d_grad, d_feature, d_laplace, grad_table, g_w0, g_b0, g_w1, g_b1,
-                               workspace, workspace_bytes, nullptr, stream);
+  return dsu_sdf_fd_bwd_sorted(cfg, table_f16, mlp, pts, nullptr, n, radius, eps, active_levels,
+                               d_sdf, d_grad, d_feature, d_laplace, grad_table, g_w0, g_b0, g_w1,
+                               g_b1, workspace, workspace_bytes, nullptr, stream);
 }
 
 #ifdef DSU_BWD_PROF

@@ -7,6 +7,8 @@ ellipse), random-init weights of the reference architectures.  Blender/Mixamo ri
 recon and stylisation is an external manual tool in the reference (README.md:183-186); the
 stylisation frames are synthetic colour / position / edge maps of the stated shapes.
 """
+import time
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -57,6 +59,8 @@ class DrawingPipeline:
                  with_clip=True, export_resolution=512, with_mv=True, with_contour=True):
         self.device = torch.device(device)
         self.mv_steps, self.nsr_steps, self.n_frames = mv_steps, nsr_steps, n_frames
+        self.time_substages = False          # bench.py: split the NSR stage into fit / export
+        self.substage_seconds = {}
         self.export_resolution = export_resolution
         self.mv = build_random_pipeline(self.device, seed, with_clip=with_clip) if with_mv else None
         torch.manual_seed(seed + 1)
@@ -134,12 +138,19 @@ class DrawingPipeline:
                              for v in VIEWS])
         data = OrthoData(col, masks, n_world, poses, dev)
         system = OrthoNeuSSystem(device=dev, seed=seed)
+        t0 = time.time()
         system.fit(data, max_steps=self.nsr_steps)
+        if self.time_substages:
+            torch.cuda.synchronize(dev)
+        t1 = time.time()
         # export (neus_ortho.py:183-200): smoothed binary volumes, front-mask cutting with the
         # drawing's own alpha (char/mask.png, rotated as ortho.py:155-156), marching cubes, colours
         front = (F.interpolate(drawing_rgba[3:4][None], size=(size, size), mode="nearest")[0, 0] * 255).to(torch.uint8)
         mesh = system.export_mesh(torch.rot90(front, k=-1, dims=(0, 1)).contiguous(), self.export_resolution)
         self.last_mesh = mesh
+        if self.time_substages:
+            torch.cuda.synchronize(dev)
+            self.substage_seconds = {"nsr_fit": t1 - t0, "nsr_export": time.time() - t1}
         return system, mesh["binary"]
 
     # ---------------------------------------------------------------- stage 3: test_stage1/2.py

@@ -343,25 +343,48 @@ def smooth_constrained(binary, max_iters=250, rel_tol=1e-6, band_radius=4.0, wei
     nv = pos.shape[0]
     if nv == 0:
         return dist
-    slot = torch.full(b.shape, -1, dtype=torch.int64, device=dev)
-    slot[band] = torch.arange(nv, device=dev)
+    slot = torch.full(b.shape, -1, dtype=torch.int32, device=dev)
+    slot[band] = torch.arange(nv, device=dev, dtype=torch.int32)
     shape = torch.tensor(b.shape, device=dev)
-    nbr, has = [], []                       # [axis][0: -1, 1: +1]
+    nbr_slots = []                          # -x, +x, -y, +y, -z, +z : slot or -1
     for a in range(3):
-        na_, ha_ = [], []
         for sgn in (-1, 1):
             q = pos.clone()
             q[:, a] += sgn
             ok = (q[:, a] >= 0) & (q[:, a] < shape[a])
             q[:, a].clamp_(0, int(shape[a]) - 1)
             n = slot[q[:, 0], q[:, 1], q[:, 2]]
-            ok = ok & (n >= 0)
-            na_.append(n.clamp(min=0))
-            ha_.append(ok.to(torch.float64))
-        nbr.append(na_); has.append(ha_)
-    cdiag = [-2.0 + (1 - has[a][0]) + (1 - has[a][1]) for a in range(3)]
+            nbr_slots.append(torch.where(ok, n, torch.full_like(n, -1)))
+    del slot
     x = dist[band]
     inside = b[band]
+    check_each = 10
+    cum_rel_tol = 1 - (1 - rel_tol) ** check_each
+    if b.is_cuda:
+        # the iteration itself: csrc/mesh_smooth.hip (two passes over the band per iteration)
+        from .. import ops
+        nbr_t = torch.stack(nbr_slots).contiguous()
+        inside_u8 = inside.to(torch.uint8).contiguous()
+        x = x.contiguous()
+        ybuf = torch.empty(3 * nv, dtype=torch.float64, device=dev)
+        energy_now = float(ops.smooth_energy(nbr_t, x, ybuf))
+        done = 0
+        while done < max_iters:
+            step = min(check_each, max_iters - done)
+            ops.smooth_iterate(nbr_t, inside_u8, x, ybuf, weight, step)
+            done += step
+            if step == check_each:
+                energy_before = energy_now
+                energy_now = float(ops.smooth_energy(nbr_t, x, ybuf))
+                if energy_before <= 0 or (energy_before - energy_now) / energy_before < cum_rel_tol:
+                    break
+        out = dist.clone()
+        out[band] = x
+        return out
+    # host tensors (CPU tests of the restatement): the same iteration as tensor programs
+    nbr = [[nbr_slots[2 * a + k].clamp(min=0).long() for k in range(2)] for a in range(3)]
+    has = [[(nbr_slots[2 * a + k] >= 0).to(torch.float64) for k in range(2)] for a in range(3)]
+    cdiag = [-2.0 + (1 - has[a][0]) + (1 - has[a][1]) for a in range(3)]
     ninf, pinf = float("-inf"), float("inf")
     lower = torch.where(inside, torch.zeros_like(x), torch.full_like(x, ninf))
     upper = torch.where(inside, torch.full_like(x, pinf), torch.zeros_like(x))
@@ -377,8 +400,6 @@ def smooth_constrained(binary, max_iters=250, rel_tol=1e-6, band_radius=4.0, wei
     for a in range(3):
         diag += cdiag[a] ** 2 + has[a][0] + has[a][1]
     inv_d = 1.0 / diag
-    check_each = 10
-    cum_rel_tol = 1 - (1 - rel_tol) ** check_each
     energy_now = float((x * apply_q(x)).sum()) / 2
     for i in range(max_iters):
         x1 = -inv_d * (apply_q(x) - diag * x)               # -D^-1 R x

@@ -27,6 +27,10 @@ DEFAULT_SYSTEM_CONFIG = Cfg({     # configs/neuralangelo-ortho-wmask.yaml:86-141
 })
 
 VIEWS = ["front", "front_right", "right", "back", "left", "front_left"]
+# Morton bins per axis (2^bits) for the sorted evaluation order of the geometry network in the
+# fused step; DSU_SPATIAL_SORT=0 keeps the marcher's ray-major order (A/B runs).
+_SPATIAL_SORT_BITS = int(os.environ.get("DSU_SPATIAL_SORT", "6"))
+
 _AZIMUTH = {"front": 0.0, "front_right": 45.0, "right": 90.0, "back": 180.0, "left": 270.0,
             "front_left": 315.0}
 
@@ -505,9 +509,15 @@ class OrthoNeuSSystem:
         eps, active = geo._finite_difference_eps, geo.active_levels
         with torch.no_grad():
             inv_s = m.variance.inv_s                     # exp(10 * variance)
+            # the geometry network is evaluated in Morton order of the sample positions (the
+            # ray-major order of random pixels scatters a wave's table accesses over the whole
+            # volume); its per-point results come back in ray order through `perm`
+            perm = None
+            if _SPATIAL_SORT_BITS:
+                allp, perm = ops.spatial_sort(allp, geo.radius, _SPATIAL_SORT_BITS)
             a_sdf, a_grad, a_feat, _, enc_cache = ops.sdf_fd_fwd(
                 enc.cfg, table, mlp, allp, geo.radius, eps, active, True, True, False,
-                enc_cache=True)
+                enc_cache=True, perm=perm)
             if not inject:
                 # issued once the geometry forward (0.3 ms of device work) is in the queue: the
                 # host's ~0.15 ms of launches for the next batch then cost the device nothing, and
@@ -564,7 +574,7 @@ class OrthoNeuSSystem:
                                              d_sdf_all, d_grad_all)
             g_table, g = ops.sdf_fd_bwd(enc.cfg, table, mlp, allp, geo.radius, eps, active,
                                         d_sdf_all, d_grad_all, d_feat_all, None,
-                                        enc_cache=enc_cache)
+                                        enc_cache=enc_cache, perm=perm)
         enc.params.grad = g_table
         if wn:
             with torch.no_grad():

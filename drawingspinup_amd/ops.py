@@ -89,9 +89,28 @@ def sdf_fwd(cfg, table_f16, mlp, pts, radius, active_levels, n_out=1):
     return out
 
 
+def spatial_sort(pts, radius, bits=6):
+    """Morton-bin the points of one step (csrc/spatial_sort.hip): returns (pts_sorted, perm) with
+    pts_sorted[i] = pts[perm[i]].  Pass both to sdf_fd_fwd / sdf_fd_bwd (perm=...)."""
+    pts = _f32c(pts)
+    n = pts.shape[0]
+    dev = pts.device
+    perm = torch.empty(n, dtype=torch.int32, device=dev)
+    out = torch.empty_like(pts)
+    wbytes = int(lib().dsu_spatial_sort_workspace_bytes(n, int(bits)))
+    if wbytes < 0:
+        check(wbytes, "dsu_spatial_sort_workspace_bytes")
+    ws = torch.empty(max(wbytes, 4) // 4, dtype=torch.int32, device=dev)
+    check(lib().dsu_spatial_sort(ptr(pts), n, float(radius), int(bits), ptr(perm), ptr(out),
+                                 ptr(ws), wbytes, stream()), "dsu_spatial_sort")
+    return out, perm
+
+
 def sdf_fd_fwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, with_grad=True,
-               with_feature=True, with_laplace=True, enc_cache=None):
-    """enc_cache: True -> also return the feature cache tensor for sdf_fd_bwd (5th value)."""
+               with_feature=True, with_laplace=True, enc_cache=None, perm=None):
+    """enc_cache: True -> also return the feature cache tensor for sdf_fd_bwd (5th value).
+    perm (int32, from spatial_sort): `pts` are the sorted points; outputs come back in the
+    caller's original row order (row perm[i] = result of pts[i]); the cache stays in sorted order."""
     pts = _f32c(pts)
     n = pts.shape[0]
     dev = pts.device
@@ -104,8 +123,9 @@ def sdf_fd_fwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, with_grad=T
     feat = torch.empty((n, 13), dtype=torch.float32, device=dev) if with_feature else None
     lap = torch.empty(n, dtype=torch.float32, device=dev) if with_laplace else None
     c, m = cfg.c(), _mlp_struct(*mlp)
-    check(lib().dsu_sdf_fd_fwd_cached(C.byref(c), ptr(table_f16, torch.float16), C.byref(m),
-                                      ptr(pts), n, float(radius), float(eps), int(active_levels),
+    check(lib().dsu_sdf_fd_fwd_sorted(C.byref(c), ptr(table_f16, torch.float16), C.byref(m),
+                                      ptr(pts), ptr(perm, torch.int32), n, float(radius),
+                                      float(eps), int(active_levels),
                                       ptr(sdf), ptr(grad), ptr(feat), ptr(lap), ptr(cache),
                                       stream()), "dsu_sdf_fd_fwd")
     if enc_cache:
@@ -114,7 +134,8 @@ def sdf_fd_fwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, with_grad=T
 
 
 def sdf_fd_bwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, d_sdf, d_grad, d_feature,
-               d_laplace, grad_table=None, enc_cache=None):
+               d_laplace, grad_table=None, enc_cache=None, perm=None):
+    """perm: as in sdf_fd_fwd (`pts` sorted, the upstream gradients in the original row order)."""
     pts = _f32c(pts)
     n = pts.shape[0]
     dev = pts.device
@@ -134,12 +155,34 @@ def sdf_fd_bwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, d_sdf, d_gr
         need = int(lib().dsu_sdf_fd_enc_cache_bytes(n, int(active_levels)))
         if enc_cache.numel() * enc_cache.element_size() < need:
             raise DsuError("feature cache smaller than dsu_sdf_fd_enc_cache_bytes")
-    check(lib().dsu_sdf_fd_bwd_cached(C.byref(c), ptr(table_f16, torch.float16), C.byref(m),
-                                      ptr(pts), n, float(radius), float(eps), int(active_levels),
+    check(lib().dsu_sdf_fd_bwd_sorted(C.byref(c), ptr(table_f16, torch.float16), C.byref(m),
+                                      ptr(pts), ptr(perm, torch.int32), n, float(radius),
+                                      float(eps), int(active_levels),
                                       ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]), ptr(grad_table),
                                       ptr(g[0]), ptr(g[1]), ptr(g[2]), ptr(g[3]), ptr(ws),
                                       int(wbytes), ptr(enc_cache), stream()), "dsu_sdf_fd_bwd")
     return grad_table, g
+
+
+# ------------------------------------------------------------------ export: mcubes.smooth
+def smooth_iterate(nbr, inside, x, y, weight, iters):
+    """`iters` projected weighted-Jacobi iterations on the band voxels, in place on x (f64)."""
+    nv = x.shape[0]
+    check(lib().dsu_smooth_iterate(ptr(nbr, torch.int32), nv, ptr(inside, torch.uint8),
+                                   float(weight), int(iters), ptr(x, torch.float64),
+                                   ptr(y, torch.float64), stream()), "dsu_smooth_iterate")
+    return x
+
+
+def smooth_energy(nbr, x, y):
+    """x . Q x / 2 (device scalar, f64; fixed summation order)."""
+    nv = x.shape[0]
+    part = torch.empty(int(lib().dsu_smooth_energy_partials()), dtype=torch.float64,
+                       device=x.device)
+    check(lib().dsu_smooth_energy(ptr(nbr, torch.int32), nv, ptr(x, torch.float64),
+                                  ptr(y, torch.float64), ptr(part), stream()),
+          "dsu_smooth_energy")
+    return part.sum() / 2
 
 
 # ------------------------------------------------------------------ nerfacc replacements

@@ -133,6 +133,31 @@ int dsu_sdf_fd_bwd_cached(const dsu_hashgrid_cfg* cfg, const void* table_f16,
                           void* stream);
 int64_t dsu_sdf_fd_enc_cache_bytes(int64_t n, uint32_t active_levels);
 
+/* Spatially sorted evaluation order for one optimisation step.  VolumeSDF.forward is pointwise
+ * (geometry.py:135-187), but its callers hand it the samples ray by ray (neus.py:119-129 ->
+ * nerfacc.ray_marching order) and the rays are random pixels of six views, so neighbouring
+ * lanes touch unrelated table neighbourhoods.  dsu_spatial_sort bins the points on a
+ * 2^bits-per-axis lattice of the [-radius, radius]^3 cube in Morton order (counting sort;
+ * bits 4..7): pts_sorted[i] = pts[perm[i]].  The *_sorted calls take the sorted points plus
+ * perm and read / write every per-point array (sdf, grad, feature, laplace, d_*) in the
+ * CALLER'S row order through it; the feature cache is kept in sorted order.  perm NULL = the
+ * plain calls.  Same per-point arithmetic, bit for bit. */
+int64_t dsu_spatial_sort_workspace_bytes(int64_t n, int32_t bits);
+int dsu_spatial_sort(const float* pts, int64_t n, float radius, int32_t bits, int32_t* perm,
+                     float* pts_sorted, void* workspace, int64_t workspace_bytes, void* stream);
+int dsu_sdf_fd_fwd_sorted(const dsu_hashgrid_cfg* cfg, const void* table_f16,
+                          const dsu_sdf_mlp* mlp, const float* pts_sorted, const int32_t* perm,
+                          int64_t n, float radius, float eps, uint32_t active_levels, float* sdf,
+                          float* grad, float* feature, float* laplace, void* enc_cache,
+                          void* stream);
+int dsu_sdf_fd_bwd_sorted(const dsu_hashgrid_cfg* cfg, const void* table_f16,
+                          const dsu_sdf_mlp* mlp, const float* pts_sorted, const int32_t* perm,
+                          int64_t n, float radius, float eps, uint32_t active_levels,
+                          const float* d_sdf, const float* d_grad, const float* d_feature,
+                          const float* d_laplace, float* grad_table, float* g_w0, float* g_b0,
+                          float* g_w1, float* g_b1, void* workspace, int64_t workspace_bytes,
+                          const void* enc_cache, void* stream);
+
 /* Bytes of device scratch dsu_sdf_fd_bwd needs for n points (per-workgroup partial MLP
  * gradients, summed by a second kernel: deterministic, no same-address atomics).  <0 = error. */
 int64_t dsu_sdf_fd_bwd_workspace_bytes(const dsu_hashgrid_cfg* cfg, int64_t n);
@@ -511,6 +536,20 @@ int dsu_layernorm_f16(const void* x, const void* gamma, const void* beta, int64_
 /* diffusers GEGLU (FeedForward activation_fn="geglu", transformer_mv2d.py:483):
  * h (rows, 2*D) f16 = proj output; out[r][j] = h[r][j] * gelu_erf(h[r][D+j]). */
 int dsu_geglu_f16(const void* h, int64_t rows, int32_t D, void* out, void* stream);
+
+/* mcubes.smooth on the export's binary volume (MarchingCubeHelper.forward,
+ * instant_nsr/models/geometry.py:57-58 -> PyMCubes' constrained smoothing): the weighted-Jacobi
+ * iteration on the compacted band voxels, float64.  nbr (6, nv) int32: slot of the -x,+x,-y,+y,
+ * -z,+z neighbour or -1 (outside the band: folds onto the diagonal); inside (nv) u8: the voxel's
+ * class (1: x >= 0 is enforced, 0: x <= 0); x (nv) in/out; y caller-owned scratch of 3*nv doubles.
+ * dsu_smooth_iterate runs `iters` iterations x <- proj(w * (-D^-1 R x) + (1 - w) x);
+ * dsu_smooth_energy writes dsu_smooth_energy_partials() partial sums of x . Q x (the caller adds
+ * them in order and halves: the energy of the stopping test). */
+int32_t dsu_smooth_energy_partials(void);
+int dsu_smooth_iterate(const int32_t* nbr, int64_t nv, const uint8_t* inside, double weight,
+                       int32_t iters, double* x, double* y, void* stream);
+int dsu_smooth_energy(const int32_t* nbr, int64_t nv, const double* x, double* y,
+                      double* partials, void* stream);
 
 #ifdef __cplusplus
 }

@@ -249,3 +249,102 @@ def test_sdf_fd_bwd_rejects_resolutions_beyond_the_cell_key(dev):
     ops.sdf_fd_bwd(cfg, tab, mlp, pts, 1.0, 0.01, 10, *d)          # level 9: 64 * s^9 = 776 cells
     with pytest.raises(Exception):
         ops.sdf_fd_bwd(cfg, tab, mlp, pts, 1.0, 0.01, 12, *d)      # level 11: 1353 cells
+
+
+# ---------------------------------------------------------------- sorted evaluation order
+def _morton_bins(pts, radius, bits):
+    nb = 1 << bits
+    c = np.clip(np.floor((pts.astype(np.float32) + np.float32(radius)) *
+                         np.float32(1.0 / (2.0 * radius)) * np.float32(nb)), 0, nb - 1).astype(np.int64)
+    key = np.zeros(len(pts), np.int64)
+    for b in range(bits):
+        for a in range(3):
+            key |= ((c[:, a] >> b) & 1) << (3 * b + a)
+    return key
+
+
+@pytest.mark.parametrize("n,bits", [(1, 6), (777, 4), (70001, 6), (70001, 7)])
+def test_spatial_sort_is_a_morton_ordered_permutation(dev, n, bits):
+    pts = _pts(n, 31, -1.0, 1.0)
+    pts[0] = torch.tensor([1.0, -1.0, 1.0])          # cube corners clamp into the last / first bin
+    ps, perm = ops.spatial_sort(pts.to(dev), 1.0, bits)
+    perm = perm.cpu().numpy()
+    assert np.array_equal(np.sort(perm), np.arange(n))                 # INT: a permutation
+    assert np.array_equal(ps.cpu().numpy(), pts.numpy()[perm])          # rows moved bit for bit
+    key = _morton_bins(pts.numpy()[perm], 1.0, bits)
+    assert (np.diff(key) >= 0).all()                                    # bins in Morton order
+
+
+def test_spatial_sort_empty(dev):
+    ps, perm = ops.spatial_sort(torch.empty(0, 3, device=dev), 1.0)
+    assert ps.shape == (0, 3) and perm.shape == (0,)
+
+
+@pytest.mark.parametrize("active", [4, 6])
+def test_sorted_order_gives_the_same_forward_and_backward(dev, active):
+    """dsu_sdf_fd_{fwd,bwd}_sorted == the plain calls: per-point outputs bit for bit (rows come
+    back in the caller's order), gradients to summation-order rounding."""
+    n = 40000
+    tab = _table(41, 0.5).to(dev)
+    mlp = [m.to(dev) for m in _mlp(42)]
+    pts = (_pts(n, 43, -0.7, 0.7)).to(dev)
+    g = torch.Generator().manual_seed(44)
+    d_sdf = torch.randn(n, generator=g).to(dev)
+    d_grad = (torch.randn(n, 3, generator=g) * 0.1).to(dev)
+    d_feat = (torch.randn(n, 13, generator=g) * 0.1).to(dev)
+    eps = 1.0 / 128
+    ref = ops.sdf_fd_fwd(CFG, tab, mlp, pts, 1.0, eps, active, True, True, True, enc_cache=True)
+    gt_ref, g_ref = ops.sdf_fd_bwd(CFG, tab, mlp, pts, 1.0, eps, active, d_sdf, d_grad, d_feat,
+                                   None, enc_cache=ref[4])
+    ps, perm = ops.spatial_sort(pts, 1.0, 6)
+    got = ops.sdf_fd_fwd(CFG, tab, mlp, ps, 1.0, eps, active, True, True, True, enc_cache=True,
+                         perm=perm)
+    for a, b in zip(ref[:4], got[:4]):
+        assert torch.equal(a, b)
+    gt, gg = ops.sdf_fd_bwd(CFG, tab, mlp, ps, 1.0, eps, active, d_sdf, d_grad, d_feat, None,
+                            enc_cache=got[4], perm=perm)
+    assert torch.equal(gt_ref != 0, gt != 0)                            # same touched entries
+    scale = float(gt_ref.abs().max())
+    np.testing.assert_allclose(gt.cpu().numpy(), gt_ref.cpu().numpy(), rtol=1e-4,
+                               atol=2e-6 * scale)
+    for a, b in zip(g_ref, gg):
+        np.testing.assert_allclose(b.cpu().numpy(), a.cpu().numpy(), rtol=2e-4,
+                                   atol=2e-5 * float(a.abs().max()))
+
+
+@pytest.mark.parametrize("kind", ["ray", "repeat"])
+def test_sdf_fd_bwd_on_samples_that_share_cells(dev, kind, monkeypatch):
+    """Neighbouring lanes in the SAME cell (samples along a ray, repeated points): the same-cell
+    run merge of the backward scatter against float64 autograd.  (Uniform random points never
+    put two neighbouring lanes into one cell; a DPP move under a short-circuit's EXEC mask once
+    dropped / doubled the row-end lanes of such runs without any test noticing.)"""
+    tab = _table(51, 0.5)
+    mlp = _mlp(52)
+    if kind == "ray":
+        t = torch.linspace(0.0, 0.45, 333)
+        pts = torch.cat([torch.tensor([[0.12, -0.3, -0.2]]) + t[:, None] * torch.tensor([[0.1, 0.2, 1.0]]),
+                         torch.tensor([[-0.4, 0.33, 0.5]]) - t[:, None] * torch.tensor([[0.0, 1.0, 0.3]])])
+    else:
+        pts = torch.cat([(torch.tensor([[0.1234, -0.3, 0.21]]) + 0.11 * k).repeat(r, 1)
+                         for k, r in enumerate((1, 2, 15, 16, 17, 33, 64, 5))])
+    n = pts.shape[0]
+    eps, active, radius = 1.0 / 128, 5, 1.0
+    g = torch.Generator().manual_seed(53)
+    d = [torch.randn(n, generator=g), torch.randn(n, 3, generator=g) * 0.1,
+         torch.randn(n, 13, generator=g) * 0.1, torch.randn(n, generator=g) * 1e-4]
+    tab64 = tab.double().requires_grad_(True)
+    mlp64 = [m.double().requires_grad_(True) for m in mlp]
+    _torch_fd_loss(tab64, mlp64, pts.numpy(), eps, active, radius, [x.double() for x in d]).backward()
+    ref_t = tab64.grad.numpy()
+    scale = np.abs(ref_t).max()
+    for split in ("1", "0"):                 # two-kernel form and fused kernel
+        monkeypatch.setenv("DSU_BWD_SPLIT", split)
+        gt, gm = ops.sdf_fd_bwd(CFG, tab.to(dev), [m.to(dev) for m in mlp], pts.to(dev), radius, eps,
+                                active, *[x.to(dev) for x in d])
+        gt = gt.cpu().numpy().reshape(-1, 2)
+        assert np.array_equal(ref_t != 0, gt != 0)
+        np.testing.assert_allclose(gt, ref_t, rtol=1e-4, atol=1e-5 * scale)
+        for got, ref in zip(gm, mlp64):
+            r = ref.grad.numpy()
+            np.testing.assert_allclose(got.cpu().numpy(), r, rtol=1e-4,
+                                       atol=1e-5 * max(np.abs(r).max(), 1.0))
