@@ -47,6 +47,7 @@ class Encoding(nn.Module):
         self.params = nn.Parameter(init)
         self._shadow = None
         self._shadow_version = -1
+        self._shadow_locked = False
         self.active_levels = self.cfg.n_levels
 
     def table_f16(self):
@@ -57,6 +58,8 @@ class Encoding(nn.Module):
         `invalidate()`; while the module is in training mode the image is simply rebuilt on every
         call (one 15 us pass over 12.6 M entries)."""
         p = self.params
+        if self._shadow_locked and self._shadow is not None and self._shadow.device == p.device:
+            return self._shadow          # maintained by the fused table optimizer (TableAdamW)
         if (self._shadow is None or self.training or self._shadow_version != p._version
                 or self._shadow.device != p.device):
             self._shadow = p.detach().to(torch.float16).contiguous()
@@ -66,6 +69,17 @@ class Encoding(nn.Module):
     def invalidate(self):
         """Force the next table_f16() to re-read the master parameters."""
         self._shadow_version = -1
+        self._shadow_locked = False
+
+    def lock_shadow(self):
+        """The caller keeps the f16 image in step with the master parameters itself (the fused
+        table optimizer writes both in one pass); until invalidate() the image is not rebuilt."""
+        self._shadow_locked = False
+        img = self.table_f16() if not self.training else \
+            self.params.detach().to(torch.float16).contiguous()
+        self._shadow, self._shadow_version = img, self.params._version
+        self._shadow_locked = True
+        return img
 
     def set_shadow(self, table_f16):
         """Used by the fused optimizer step, which writes master and f16 image in one pass."""

@@ -238,6 +238,65 @@ class RayLossGraph:
         return terms, self.out_grad[:r]
 
 
+class TableAdamW:
+    """torch.optim.AdamW for the hash-table parameter alone (same update, configs/
+    neuralangelo-ortho-wmask.yaml:96-110), one fused launch per step over the ACTIVE levels:
+    update + f16 image + gradient reset (csrc/nsr_step.hip table_adamw_kernel).  Levels the
+    progressive schedule still masks have zero gradients and zero moments, so their AdamW step is
+    `p *= 1 - lr * wd` only; that product is accumulated on the host (float64) and applied when
+    the level is switched on and in finalize() — every level ends at the value the dense
+    optimizer gives, without 3000 passes over the 80 % of the table nobody reads."""
+
+    def __init__(self, enc, lr, betas, eps, weight_decay=0.01):
+        self.enc = enc
+        p = enc.params
+        self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
+        self.m = torch.zeros_like(p.data)
+        self.v = torch.zeros_like(p.data)
+        self.grad = torch.zeros_like(p.data)       # persistent gradient buffer, zeroed by the step
+        self.step_count = 0
+        self.offsets = [2 * o for o in enc.cfg.levels()["offsets"]]      # float offsets per level
+        self.n_levels = enc.cfg.n_levels
+        self.active = 0                            # levels below this index are up to date
+        self.pending = 1.0                         # product of (1 - lr wd) not yet applied to levels >= active
+        self.img = None                            # locked at the first step (parameters may still be loaded)
+
+    def _catch_up(self, upto):
+        """Apply the pending decay to levels [self.active, upto) and mark them active."""
+        if upto > self.active:
+            a, b = self.offsets[self.active], self.offsets[upto]
+            if self.pending != 1.0 and b > a:
+                ops.table_decay(self.enc.params.data, self.img, a, b - a, self.pending)
+            self.active = upto
+
+    def step(self, active_levels, lr=None):
+        lr = self.lr if lr is None else lr
+        if self.img is None or self.enc._shadow is not self.img or not self.enc._shadow_locked:
+            self.img = self.enc.lock_shadow()      # first step, or someone invalidated the image
+        if active_levels < self.active:
+            # a level was switched OFF again (not in the reference's schedule): its moments are
+            # live, handle everything densely from here on
+            active_levels = self.active
+        self._catch_up(active_levels)
+        self.step_count += 1
+        b1, b2 = self.betas
+        bc1 = 1.0 - b1 ** self.step_count
+        bc2_sqrt = math.sqrt(1.0 - b2 ** self.step_count)
+        n = self.offsets[self.active]
+        ops.table_adamw(self.enc.params.data, self.grad, self.m, self.v, self.img, n, lr, b1, b2,
+                        self.eps, self.wd, bc1, bc2_sqrt)
+        self.pending *= 1.0 - lr * self.wd
+
+    def finalize(self):
+        """Bring the still-masked levels up to date (end of fit, before state_dict / export)."""
+        if self.img is None:
+            return
+        act = self.active
+        self._catch_up(self.n_levels)
+        self.active = act
+        self.pending = 1.0           # the levels >= act are current; later steps accumulate from 1
+
+
 class OrthoNeuSSystem:
     def __init__(self, model_config=None, system_config=None, device="cuda", seed=123456):
         torch.manual_seed(seed)
@@ -250,7 +309,16 @@ class OrthoNeuSSystem:
         self.train_num_rays = mc.train_num_rays
         self.global_step = 0
         oc = self.config.optimizer
-        groups = [{"params": list(getattr(self.model, n).parameters()), "name": n, "lr": lr}
+        # the hash table has its own fused optimizer step (TableAdamW, same AdamW update);
+        # DSU_TABLE_ADAM=0 leaves it in the torch optimizer (A/B runs)
+        enc = self.model.geometry.hashgrid
+        self.table_opt = None
+        self.keep_table_grad = False
+        if self.device.type == "cuda" and os.environ.get("DSU_TABLE_ADAM", "1") != "0":
+            self.table_opt = TableAdamW(enc, dict(oc.params)["geometry"], tuple(oc.betas), oc.eps)
+        groups = [{"params": [p for p in getattr(self.model, n).parameters()
+                              if self.table_opt is None or p is not enc.params],
+                   "name": n, "lr": lr}
                   for n, lr in oc.params.items()]
         # same update rule as the reference's torch.optim.AdamW; the fused (single-launch per
         # group) implementation on the GPU instead of ~10 foreach launches per group
@@ -368,6 +436,22 @@ class OrthoNeuSSystem:
         f = 1.0 if s < self.config.constant_steps else self._gamma ** (s - self.config.constant_steps)
         for g, base in zip(self.optimizer.param_groups, self._base_lrs):
             g["lr"] = base * f
+
+    def zero_grad(self):
+        self.optimizer.zero_grad(set_to_none=True)
+        self.model.geometry.hashgrid.params.grad = None     # not in the torch optimizer's groups
+
+    def _step_table(self, active_levels):
+        """Optimizer step of the hash table: the fused kernel (gradient in table_opt.grad), or —
+        when the table sits in the torch optimizer — just the image invalidation (torch's fused
+        AdamW does not bump ._version)."""
+        if self.table_opt is None:
+            self.model.geometry.hashgrid.invalidate()
+            return
+        lr = next(g["lr"] for g in self.optimizer.param_groups if g.get("name") == "geometry")
+        if self.keep_table_grad:              # tests: the step's table gradient stays readable
+            self.model.geometry.hashgrid.params.grad = self.table_opt.grad.clone()
+        self.table_opt.step(int(active_levels), lr)
 
     def training_step(self, inject=None):
         if self.step_mode == "fused" and self.model.fused_shading \
@@ -492,7 +576,7 @@ class OrthoNeuSSystem:
                                       m.config.max_train_num_rays)
         n_all = n_s + 2 * n_r
         self._set_lr()
-        self.optimizer.zero_grad(set_to_none=True)
+        self.zero_grad()
 
         # ---- forward
         lin0, lin1 = [l for l in geo.network.layers if isinstance(l, torch.nn.Linear)]
@@ -574,8 +658,11 @@ class OrthoNeuSSystem:
                                              d_sdf_all, d_grad_all)
             g_table, g = ops.sdf_fd_bwd(enc.cfg, table, mlp, allp, geo.radius, eps, active,
                                         d_sdf_all, d_grad_all, d_feat_all, None,
+                                        grad_table=None if self.table_opt is None
+                                        else self.table_opt.grad,
                                         enc_cache=enc_cache, perm=perm)
-        enc.params.grad = g_table
+        if self.table_opt is None:
+            enc.params.grad = g_table
         if wn:
             with torch.no_grad():
                 bw = torch.ops.aten._weight_norm_interface_backward
@@ -585,7 +672,7 @@ class OrthoNeuSSystem:
             lin0.weight.grad, lin1.weight.grad = g[0], g[2]
         lin0.bias.grad, lin1.bias.grad = g[1], g[3]
         self.optimizer.step()
-        self.model.geometry.hashgrid.invalidate()     # fused AdamW does not bump ._version
+        self._step_table(active)
         self.global_step += 1
         terms = {"rgb_mse": rterms[0]}
         if L.lambda_rgb_l1:
@@ -615,7 +702,7 @@ class OrthoNeuSSystem:
             self.train_num_rays = min(int(self.train_num_rays * 0.9 + tr * 0.1),
                                       self.model.config.max_train_num_rays)
         self._set_lr()
-        self.optimizer.zero_grad(set_to_none=True)
+        self.zero_grad()
         if self.use_loss_graph and "comp_raw" in out:
             # ray-level losses + their gradient w.r.t. the composite: one captured HIP graph
             # (fixed max_train_num_rays capacity, real rays marked by a device-side count)
@@ -631,7 +718,12 @@ class OrthoNeuSSystem:
             loss = sum(terms.values())
             loss.backward()
         self.optimizer.step()
-        self.model.geometry.hashgrid.invalidate()     # fused AdamW does not bump ._version
+        enc = self.model.geometry.hashgrid
+        if self.table_opt is not None:
+            if enc.params.grad is not None:
+                self.table_opt.grad.copy_(enc.params.grad.reshape(-1))
+            enc.params.grad = None
+        self._step_table(self.model.geometry.active_levels)
         self.global_step += 1
         self.last = {"loss": loss.detach(), "n_samples": n_samples,
                      "n_rays": batch["rays"].shape[0], **{k: v.detach() for k, v in terms.items()}}
@@ -644,6 +736,8 @@ class OrthoNeuSSystem:
             if log_every and self.global_step % log_every == 0:
                 print(f"[nsr] step {self.global_step} loss {float(r['loss']):.4f} "
                       f"rays {r['n_rays']} samples {r['n_samples']}", flush=True)
+        if self.table_opt is not None:
+            self.table_opt.finalize()          # masked levels: apply their accumulated decay
 
     # ----------------------------------------------------------------- export
     @torch.no_grad()

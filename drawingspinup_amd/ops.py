@@ -164,6 +164,24 @@ def sdf_fd_bwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, d_sdf, d_gr
     return grad_table, g
 
 
+# ------------------------------------------------------------------ hash-table optimizer
+def table_adamw(p, g, m, v, img_f16, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2_sqrt):
+    """One torch.optim.AdamW update of the first n floats of the table (active levels), fused
+    with the f16 image rewrite and the gradient reset."""
+    check(lib().dsu_table_adamw(ptr(p, torch.float32), ptr(g, torch.float32), ptr(m, torch.float32),
+                                ptr(v, torch.float32), ptr(img_f16, torch.float16), int(n),
+                                float(lr), float(beta1), float(beta2), float(eps),
+                                float(weight_decay), float(bc1), float(bc2_sqrt), stream()),
+          "dsu_table_adamw")
+
+
+def table_decay(p, img_f16, start, n, factor):
+    """p[start:start+n] *= factor (+ f16 image); start, n multiples of 4 floats."""
+    check(lib().dsu_table_decay(C.c_void_p(p.data_ptr() + 4 * int(start)),
+                                C.c_void_p(img_f16.data_ptr() + 2 * int(start)), int(n),
+                                float(factor), stream()), "dsu_table_decay")
+
+
 # ------------------------------------------------------------------ export: mcubes.smooth
 def smooth_iterate(nbr, inside, x, y, weight, iters):
     """`iters` projected weighted-Jacobi iterations on the band voxels, in place on x (f64)."""

@@ -537,6 +537,18 @@ int dsu_layernorm_f16(const void* x, const void* gamma, const void* beta, int64_
  * h (rows, 2*D) f16 = proj output; out[r][j] = h[r][j] * gelu_erf(h[r][D+j]). */
 int dsu_geglu_f16(const void* h, int64_t rows, int32_t D, void* out, void* stream);
 
+/* torch.optim.AdamW step on a range of the hash-table parameters (the optimizer the reference
+ * configures in configs/neuralangelo-ortho-wmask.yaml:96-110 -> systems/utils.py parse_optimizer;
+ * torch's update: p -= lr*wd*p; m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g;
+ * p -= (lr / bias_correction1) * m / (sqrt(v) / bias_correction2_sqrt + eps)), fused with the f16
+ * image rewrite (img_f16[i] = half(p[i])) and the gradient reset (g = 0).  n floats, n % 4 == 0,
+ * 16-byte aligned pointers.  dsu_table_decay: p *= factor (+ image) — the accumulated
+ * `1 - lr*wd` factors of steps in which a level of the progressive grid was still masked. */
+int dsu_table_adamw(float* p, float* g, float* m, float* v, void* img_f16, int64_t n, float lr,
+                    float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
+                    float bias_correction2_sqrt, void* stream);
+int dsu_table_decay(float* p, void* img_f16, int64_t n, float factor, void* stream);
+
 /* mcubes.smooth on the export's binary volume (MarchingCubeHelper.forward,
  * instant_nsr/models/geometry.py:57-58 -> PyMCubes' constrained smoothing): the weighted-Jacobi
  * iteration on the compacted band voxels, float64.  nbr (6, nv) int32: slot of the -x,+x,-y,+y,

@@ -28,7 +28,7 @@ def _loss_and_grads(sysm, fused, inj):
     out = sysm.model(batch["rays"], jitter=inj["jitter"], pts_random=inj["pts_random"],
                      perturb=inj["perturb"])
     loss = sum(sysm.losses(out, batch).values())
-    sysm.optimizer.zero_grad(set_to_none=True)
+    sysm.zero_grad()
     loss.backward()
     grads = {n: p.grad.detach().clone() for n, p in sysm.model.named_parameters() if p.grad is not None}
     return float(loss.detach()), {k: v.detach() for k, v in out.items()}, grads
