@@ -4,11 +4,16 @@ saicinpainting/training/data/datasets.py:44-74, aug.py:78-105).
     texture.png (RGBA) --prepare_input--> (1,4,512,512) --FFC-ResNet--> contour probability
       --contour_masks--> predicted contour mask, inpaint mask = max(contour, 255 - alpha)
 
+      --inpaint--> the drawing without its contour lines (RGBA, predict.py:63-66)
+
 The last step of the reference, `cv2.inpaint(img, inpaint_mask, 3, cv2.INPAINT_TELEA)`
-(predict.py:63), is OpenCV's CPU fast-marching inpainting; OpenCV is not available in this
-image, so `inpaint` calls it when importable and raises otherwise ("a
-TELEA-equivalent inpaint" is the remaining part of that row).
+(predict.py:63), is OpenCV's CPU fast-marching inpainting.  `inpaint` runs the library's own
+restatement of it (csrc/inpaint_telea.hip, host code behind the C ABI as in the reference; OpenCV
+is not installed here, so it is unpinned against the real cv2 — oracle/telea_ref.py documents what
+the tests do check).
 """
+import ctypes as C
+
 import numpy as np
 import torch
 from PIL import Image
@@ -48,12 +53,25 @@ def contour_masks(model, inp, threshold=0.2):
 
 
 def inpaint(img, inpaint_mask, radius=3):
-    try:
-        import cv2
-    except ImportError as e:            # pragma: no cover - depends on the host image
-        raise RuntimeError("cv2.inpaint(INPAINT_TELEA) needs OpenCV on the host; it is CPU work "
-                           "outside this library (SURVEY.md §8f-3)") from e
-    return cv2.inpaint(img, inpaint_mask, radius, cv2.INPAINT_TELEA)
+    """cv2.inpaint(img, inpaint_mask, radius, cv2.INPAINT_TELEA): img (H,W,3) uint8, mask (H,W) uint8
+    (non-zero = fill) on the host -> (H,W,3) uint8."""
+    from .._lib import check, lib
+    img = np.ascontiguousarray(img, np.uint8)
+    mask = np.ascontiguousarray(inpaint_mask, np.uint8)
+    if img.ndim != 3 or img.shape[2] != 3 or mask.shape != img.shape[:2]:
+        raise ValueError("inpaint: img (H,W,3) uint8 and mask (H,W) uint8 expected")
+    out = np.empty_like(img)
+    check(lib().dsu_inpaint_telea_u8c3(img.ctypes.data_as(C.c_void_p), mask.ctypes.data_as(C.c_void_p),
+                                       img.shape[0], img.shape[1], int(radius),
+                                       out.ctypes.data_as(C.c_void_p)), "dsu_inpaint_telea_u8c3")
+    return out
+
+
+def remove_contour(model, rgba_image, size=512, threshold=0.2, radius=3):
+    """predict.py:47-66 for one drawing: RGBA uint8 (size, size, 4) with the contour lines (and the
+    background) inpainted from the character's own pixels; alpha = the resized input alpha."""
+    img, alpha, _, mask = contour_masks(model, prepare_input(rgba_image, size), threshold)
+    return np.concatenate([inpaint(img, mask, radius), alpha[..., None]], 2)
 
 
 def load_generator(checkpoint=None, device="cuda", config=None):

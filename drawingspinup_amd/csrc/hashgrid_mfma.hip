@@ -73,6 +73,13 @@ __device__ __forceinline__ void swap_halves(float a, float b, float& o0, float& 
   o1 = __uint_as_float(r[1]);
 }
 
+// value of lane ^ 32 (one v_permlane32_swap instead of a ds_bpermute round trip through LDS)
+__device__ __forceinline__ float partner32(float x, int h) {
+  float a, b;
+  swap_halves(x, x, a, b);
+  return h ? a : b;
+}
+
 // DPP row shifts inside 16-lane rows (0x101.. = row_shl:n -> lane i reads lane i+n,
 // 0x111.. = row_shr:n -> lane i reads lane i-n); lanes shifted in from outside the row read 0.
 template <int CTRL>
@@ -164,19 +171,26 @@ template <int NL>
 __device__ __forceinline__ void layer0_mfma_half(const Frags<NL>& f, const float* in,
                                                  uint32_t active, int half, f32x16 (&acc)[2],
                                                  int ablate = 0) {
+  // B operands of this half's points, one per k-pair
+  float b[MC<NL>::KP];
 #pragma unroll
-  for (int T = 0; T < 2; ++T)
+  for (int t = 0; t < MC<NL>::KP; ++t) {
+    float b0, b1;
+    swap_halves(in[2 * t], in[2 * t + 1], b0, b1);
+    b[t] = half ? b1 : b0;
+  }
+  // tile by tile: the Softplus of tile 0 (VALU + transcendental unit) runs while the matrix pipe
+  // works through the k-pairs of tile 1 (both tiles interleaved finished together and the 64
+  // Softplus evaluations started only then: 1.5 k + 1.6 k clocks in sequence per half)
+#pragma unroll
+  for (int T = 0; T < 2; ++T) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[T][r] = 0.0f;
 #pragma unroll
-  for (int t = 0; t < MC<NL>::KP; ++t) {
-    if (t < NL && (uint32_t)t >= active) continue;   // masked level: both inputs are zero
-    float b0, b1;
-    swap_halves(in[2 * t], in[2 * t + 1], b0, b1);
-    const float b = half ? b1 : b0;
-#pragma unroll
-    for (int T = 0; T < 2; ++T)
-      acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w0[T][t], b, acc[T], 0, 0, 0);
+    for (int t = 0; t < MC<NL>::KP; ++t) {
+      if (t < NL && (uint32_t)t >= active) continue;   // masked level: both inputs are zero
+      acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w0[T][t], b[t], acc[T], 0, 0, 0);
+    }
   }
   if (DSU_ABL(32)) return;
 #pragma unroll
@@ -463,11 +477,18 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     for (int r = 0; r < 16; ++r) gw1c0[T][r] = 0.0f;
 
   DSU_PROF_DECL
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t bbase = blockIdx.x * (int64_t)blockDim.x; bbase < n; bbase += stride) {
+  // One contiguous range of points per workgroup (one workgroup per CU, one wave per SIMD): the
+  // remainder of n over 256 CUs x 256 points is spread over ALL workgroups as a last partial
+  // iteration of <= 32 points — one wave, one point half — instead of a full extra round on a
+  // few CUs (n ~ 2^18 + 4096 made the grid-stride form run 5 rounds where 4.06 were needed).
+  const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 31) / 32 * 32;
+  const int64_t r0 = blockIdx.x * per;
+  const int64_t r1 = r0 + per < n ? r0 + per : n;
+  for (int64_t bbase = r0; bbase < r1; bbase += blockDim.x) {
     const int64_t i = bbase + threadIdx.x;
-    const bool valid = i < n;
-    const int64_t ii = valid ? i : n - 1;
+    const bool valid = i < r1;
+    const int64_t ii = valid ? i : r1 - 1;
+    const int64_t wave_first = bbase + wave * 64;            // wave-uniform
     const float p[3] = {pts[ii * 3], pts[ii * 3 + 1], pts[ii * 3 + 2]};
     float ds = 0.f, dl = 0.f, dg[3] = {0.f, 0.f, 0.f};
     // sorted evaluation order: the upstream gradients stay in the caller's row order
@@ -477,8 +498,18 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
       if (d_laplace) dl = d_laplace[gi];
       if (d_grad) { dg[0] = d_grad[gi * 3]; dg[1] = d_grad[gi * 3 + 1]; dg[2] = d_grad[gi * 3 + 2]; }
     }
+    __half2 rw[NL];                    // feature-cache row of the NEXT evaluation (ENC path)
+#pragma unroll
+    for (int l = 0; l < NL; ++l) rw[l] = __float2half2_rn(0.0f);
+    if (ENC) {
+      const __half2* row = enc + (size_t)ii * active;
+#pragma unroll
+      for (int l = 0; l < NL; ++l)
+        if ((uint32_t)l < active) rw[l] = row[l];
+    }
+    const int n_eval = wave_first < r1 ? 7 : 0;             // a wave beyond the range only joins the barriers
 #pragma unroll 1
-    for (int e = 0; e < 7; ++e) {
+    for (int e = 0; e < n_eval; ++e) {
       float q[3];
       fd_point(p, e, eps, radius, q);
       const float cx = contract(q[0], radius), cy = contract(q[1], radius),
@@ -488,14 +519,20 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
 #pragma unroll
         for (int k = 0; k < KIN; ++k) in[k] = cx * (float)k + cy;
       } else if (ENC) {
-        // features saved by the forward pass: no table gathers in the backward pass
-        const __half2* row = enc + ((size_t)e * n + ii) * active;
+        // features saved by the forward pass: no table gathers in the backward pass.  The row of
+        // evaluation e was requested one evaluation earlier (at one wave per SIMD nothing else
+        // hides the ~1.2 us of a dependent global load: 10 % of the kernel's clocks)
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-          float2 f = make_float2(0.0f, 0.0f);
-          if ((uint32_t)l < active) f = __half22float2(row[l]);
+          const float2 f = __half22float2(rw[l]);
           in[2 * l] = f.x;
           in[2 * l + 1] = f.y;
+        }
+        if (e < 6) {
+          const __half2* row = enc + ((size_t)(e + 1) * n + ii) * active;
+#pragma unroll
+          for (int l = 0; l < NL; ++l)
+            if ((uint32_t)l < active) rw[l] = row[l];
         }
         in[2 * NL + 0] = cx * 2.0f + -1.0f;
         in[2 * NL + 1] = cy * 2.0f + -1.0f;
@@ -527,17 +564,18 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
       for (int o = 0; o < NOUT; ++o)
         if (o < no) gb1[o] += dout[o];
       // partner's position (for the scatter of the other point half)
-      const float pcx = __shfl_xor(cx, 32), pcy = __shfl_xor(cy, 32), pcz = __shfl_xor(cz, 32);
+      const float pcx = partner32(cx, h), pcy = partner32(cy, h), pcz = partner32(cz, h);
 
       DSU_PROF(1)   // upstream gradient loads
 #pragma unroll 1
       for (int half = 0; half < 2; ++half) {
+        if (wave_first + half * 32 >= r1) continue;          // no point in this half (wave-uniform)
         // gradient on the outputs of the points of this half: own if this lane owns the half
         float d[NOUT];
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
           float other = 0.0f;
-          if (o < no) other = __shfl_xor(dout[o], 32);
+          if (o < no) other = partner32(dout[o], h);
           d[o] = (h == half) ? dout[o] : other;
         }
         DSU_PROF(2)   // partner shuffles
@@ -648,8 +686,8 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
           // dIn of this half's points -> dinbuf: lane (l31, h) holds the feature pairs of levels
           // {0,1,4,5,8,9} (h = 0) or {2,3,6,7} (h = 1) of point (half, l31)
           // layout [evaluation][level][point]: the 32 lanes of a half write 256 contiguous bytes
-          const int64_t pi = bbase + wave * 64 + half * 32 + l31;
-          if (pi < n) {
+          const int64_t pi = wave_first + half * 32 + l31;
+          if (pi < r1) {
 #pragma unroll
             for (int r = 0; r < 16; r += 2) {
               const int lev = ((r & 3) + 8 * (r >> 2)) / 2 + 2 * h;
@@ -842,9 +880,49 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
 // workgroup, one LEVEL at a time for the workgroup's 512 points (so the 4096-slot cache only ever
 // holds one level's entries and is flushed per level), all 7 evaluations of that level back to
 // back.  Same segmented DPP merge, per-wave queue and fixed-point cache as the fused kernel.
-constexpr int SC_THREADS = 512;
-constexpr int SC_QCAP = 704;                                  // triples per wave queue
-constexpr int SC_LDS_F = GC_SLOTS + 4 * GC_SLOTS + (SC_THREADS / 64) * 3 * SC_QCAP;
+// Sizes (variant builds override them: -DDSU_SC_THREADS / -DDSU_SC_LOG2 / -DDSU_SC_QCAP).  With the
+// samples in Morton order a workgroup's points of one level touch a compact block of entries, so a
+// small cache is enough and what matters is how many waves a CU holds to hide the returning LDS
+// atomics: LDS bytes per workgroup = 20 * slots + 12 * QCAP * waves.
+#ifndef DSU_SC_THREADS
+#define DSU_SC_THREADS 512
+#endif
+#ifndef DSU_SC_LOG2
+#define DSU_SC_LOG2 12
+#endif
+#ifndef DSU_SC_QCAP
+#define DSU_SC_QCAP 704
+#endif
+#ifndef DSU_SC_MAXBLOCKS
+#define DSU_SC_MAXBLOCKS 256
+#endif
+constexpr int SC_MAXBLOCKS = DSU_SC_MAXBLOCKS;                // resident workgroups (256 CUs x per-CU count)
+constexpr int SC_THREADS = DSU_SC_THREADS;
+constexpr int SC_QCAP = DSU_SC_QCAP;                          // triples per wave queue (>= 512 + 64)
+constexpr int SC_LOG2 = DSU_SC_LOG2;
+constexpr int SC_SLOTS = 1 << SC_LOG2;
+constexpr int SC_LDS_F = SC_SLOTS + 4 * SC_SLOTS + (SC_THREADS / 64) * 3 * SC_QCAP;
+static_assert(SC_QCAP % 4 == 0 && SC_QCAP >= 512, "queue: one full evaluation of a wave must fit");
+
+__device__ __forceinline__ uint32_t sc_slot(uint32_t entry) {
+  return (entry * 2654435761u) >> (32 - SC_LOG2);
+}
+__device__ __forceinline__ void sc_commit_from(uint32_t* keys, unsigned long long* acc,
+                                               float* __restrict__ gtable, uint32_t entry,
+                                               uint32_t slot, float v0, float v1) {
+#pragma unroll
+  for (int probe = 1; probe < 3; ++probe) {
+    slot = (slot + 1) & (SC_SLOTS - 1);
+    const uint32_t old = atomicCAS(&keys[slot], GC_EMPTY, entry);
+    if (old == GC_EMPTY || old == entry) {
+      atomicAdd(&acc[2 * slot], gc_fix(v0));
+      atomicAdd(&acc[2 * slot + 1], gc_fix(v1));
+      return;
+    }
+  }
+  unsafeAtomicAdd(gtable + (size_t)entry * 2, v0);
+  unsafeAtomicAdd(gtable + (size_t)entry * 2 + 1, v1);
+}
 
 template <int NL>
 __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
@@ -852,51 +930,58 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
     const float2* __restrict__ dinbuf, float* __restrict__ gtable) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   uint32_t* c_keys = reinterpret_cast<uint32_t*>(lds);
-  unsigned long long* c_acc = reinterpret_cast<unsigned long long*>(lds + GC_SLOTS);
+  unsigned long long* c_acc = reinterpret_cast<unsigned long long*>(lds + SC_SLOTS);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* qbase = lds + 5 * GC_SLOTS + wave * 3 * SC_QCAP;
+  float* qbase = lds + 5 * SC_SLOTS + wave * 3 * SC_QCAP;
   uint32_t* q_ent = reinterpret_cast<uint32_t*>(qbase);
   float* q_v0 = qbase + SC_QCAP;
   float* q_v1 = qbase + 2 * SC_QCAP;
-  for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
+  for (int t = threadIdx.x; t < SC_SLOTS; t += blockDim.x) {
     c_keys[t] = GC_EMPTY;
     c_acc[2 * t] = 0ull;
     c_acc[2 * t + 1] = 0ull;
   }
   __syncthreads();
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t bbase = blockIdx.x * (int64_t)blockDim.x; bbase < n; bbase += stride) {
-    const int64_t i = bbase + threadIdx.x;
-    const bool valid = i < n;
-    const int64_t ii = valid ? i : n - 1;
-    const float p[3] = {pts[ii * 3], pts[ii * 3 + 1], pts[ii * 3 + 2]};
+  // Every workgroup owns ONE contiguous range of the (Morton-ordered) points and walks it once
+  // per level: the cache is flushed once per (workgroup, level) — a grid-stride walk flushed it
+  // after every 512 points, and with n = 2.03 x 256 x 512 its third round ran on 8 of 256 CUs —
+  // and neighbouring ranges of the sorted order keep hitting the same entries.
+  const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 63) / 64 * 64;
+  const int64_t r0 = blockIdx.x * per;
+  const int64_t r1 = r0 + per < n ? r0 + per : n;
 #pragma unroll 1
-    for (int lev = 0; lev < NL; ++lev) {
-      if ((uint32_t)lev >= active) break;
-      const float l_scale = m.scale[lev];
-      const uint32_t l_off = m.off[lev], hsize = m.off[lev + 1] - m.off[lev];
-      const uint32_t l_res = m.res[lev], l_hashed = m.hashed[lev];
-      int qn = 0;
-      auto drain = [&]() {
-        __builtin_amdgcn_wave_barrier();
-        for (int i0 = 0; i0 < qn; i0 += 64) {
-          const int qi = i0 + lane;
-          if (qi < qn) {
-            const uint32_t ent = q_ent[qi];
-            const float a0 = q_v0[qi], a1 = q_v1[qi];
-            const uint32_t slot = grad_cache_slot(ent);
-            const uint32_t old = atomicCAS(&c_keys[slot], GC_EMPTY, ent);
-            if (old == GC_EMPTY || old == ent) {
-              atomicAdd(&c_acc[2 * slot], gc_fix(a0));
-              atomicAdd(&c_acc[2 * slot + 1], gc_fix(a1));
-            } else {
-              gc_commit_from(c_keys, c_acc, gtable, ent, slot, a0, a1);
-            }
+  for (int lev = 0; lev < NL; ++lev) {
+    if ((uint32_t)lev >= active) break;
+    const float l_scale = m.scale[lev];
+    const uint32_t l_off = m.off[lev], hsize = m.off[lev + 1] - m.off[lev];
+    const uint32_t l_res = m.res[lev], l_hashed = m.hashed[lev];
+    int qn = 0;
+    auto drain = [&]() {
+      __builtin_amdgcn_wave_barrier();
+      for (int i0 = 0; i0 < qn; i0 += 64) {
+        const int qi = i0 + lane;
+        if (qi < qn) {
+          const uint32_t ent = q_ent[qi];
+          const float a0 = q_v0[qi], a1 = q_v1[qi];
+          const uint32_t slot = sc_slot(ent);
+          const uint32_t old = atomicCAS(&c_keys[slot], GC_EMPTY, ent);
+          if (old == GC_EMPTY || old == ent) {
+            atomicAdd(&c_acc[2 * slot], gc_fix(a0));
+            atomicAdd(&c_acc[2 * slot + 1], gc_fix(a1));
+          } else {
+            sc_commit_from(c_keys, c_acc, gtable, ent, slot, a0, a1);
           }
         }
-        __builtin_amdgcn_wave_barrier();
-        qn = 0;
-      };
+      }
+      __builtin_amdgcn_wave_barrier();
+      qn = 0;
+    };
+#pragma unroll 1
+    for (int64_t wbase = r0 + wave * 64; wbase < r1; wbase += blockDim.x) {   // wave-uniform trip count
+      const int64_t i = wbase + lane;
+      const bool valid = i < r1;
+      const int64_t ii = valid ? i : r1 - 1;
+      const float p[3] = {pts[ii * 3], pts[ii * 3 + 1], pts[ii * 3 + 2]};
 #pragma unroll 1
       for (int e = 0; e < 7; ++e) {
         float q[3];
@@ -930,7 +1015,9 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
         }
         DSU_SEG_STEP(0x101) DSU_SEG_STEP(0x102) DSU_SEG_STEP(0x104) DSU_SEG_STEP(0x108)
 #undef DSU_SEG_STEP
-        const bool lead = (l15 == 0) | (key_prev != key);
+        // padding lanes (beyond the range) repeat the last point with d = 0: they may extend a run
+        // but never lead one
+        const bool lead = ((l15 == 0) | (key_prev != key)) & valid;
         const unsigned long long bal = __ballot(lead);
         if (lead) {
           const int pos = qn + 8 * __popcll(bal & ((1ull << lane) - 1ull));
@@ -952,21 +1039,21 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
         qn += 8 * __popcll(bal);
         if (qn + 512 > SC_QCAP) drain();
       }
-      drain();
-      // flush this level: one global atomic pair per touched entry, then reset
-      __syncthreads();
-      for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
-        const uint32_t key = c_keys[t];
-        if (key != GC_EMPTY) {
-          unsafeAtomicAdd(gtable + (size_t)key * 2, gc_unfix(c_acc[2 * t]));
-          unsafeAtomicAdd(gtable + (size_t)key * 2 + 1, gc_unfix(c_acc[2 * t + 1]));
-          c_keys[t] = GC_EMPTY;
-          c_acc[2 * t] = 0ull;
-          c_acc[2 * t + 1] = 0ull;
-        }
-      }
-      __syncthreads();
     }
+    drain();
+    // flush this level: one global atomic pair per touched entry, then reset
+    __syncthreads();
+    for (int t = threadIdx.x; t < SC_SLOTS; t += blockDim.x) {
+      const uint32_t key = c_keys[t];
+      if (key != GC_EMPTY) {
+        unsafeAtomicAdd(gtable + (size_t)key * 2, gc_unfix(c_acc[2 * t]));
+        unsafeAtomicAdd(gtable + (size_t)key * 2 + 1, gc_unfix(c_acc[2 * t + 1]));
+        c_keys[t] = GC_EMPTY;
+        c_acc[2 * t] = 0ull;
+        c_acc[2 * t + 1] = 0ull;
+      }
+    }
+    __syncthreads();
   }
 }
 
@@ -1003,7 +1090,7 @@ __global__ void reduce_partials_mfma_kernel(const float* __restrict__ partials, 
   }
 }
 
-constexpr int BWD_MFMA_MAX_BLOCKS = 512;
+constexpr int BWD_MFMA_MAX_BLOCKS = 256;   // one workgroup per CU (458 registers: one wave per SIMD)
 
 }  // namespace
 
@@ -1169,7 +1256,7 @@ int dsu_sdf_fd_bwd_sorted(const dsu_hashgrid_cfg* cfg, const void* table_f16, co
     const size_t shm2 = (size_t)SC_LDS_F * sizeof(float);
     float2* dinbuf = reinterpret_cast<float2*>((char*)workspace +
                                                (size_t)blocks * PART_STRIDE * sizeof(float));
-    const int sblocks = dsu_capped_blocks(n, SC_THREADS, 256);
+    const int sblocks = dsu_capped_blocks(n, SC_THREADS, SC_MAXBLOCKS);
     DSU_DISPATCH_NL(cfg->n_levels, {
       auto k1 = enc_cache ? sdf_fd_bwd_mfma_kernel<NL, true, true>
                           : sdf_fd_bwd_mfma_kernel<NL, true, false>;

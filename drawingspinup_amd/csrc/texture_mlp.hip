@@ -154,11 +154,19 @@ __global__ __launch_bounds__(256) void texture_fwd_kernel(dsu_tex_mlp m,
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   load_weights(lds, m);
   __syncthreads();
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t base = blockIdx.x * (int64_t)blockDim.x; base < n; base += stride) {
+  // one contiguous range of samples per workgroup: the remainder of n over 256 x 256 samples
+  // becomes a short last iteration everywhere (one wave, one sample half) instead of a full extra
+  // round on a few CUs
+  const int wave = threadIdx.x >> 6;
+  const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 31) / 32 * 32;
+  const int64_t r0 = blockIdx.x * per;
+  const int64_t r1 = r0 + per < n ? r0 + per : n;
+  for (int64_t base = r0; base < r1; base += blockDim.x) {
     const int64_t i = base + threadIdx.x;
-    const bool valid = i < n;
-    const int64_t ii = valid ? i : n - 1;
+    const bool valid = i < r1;
+    const int64_t ii = valid ? i : r1 - 1;
+    const int64_t wave_first = base + wave * 64;
+    if (wave_first >= r1) continue;                    // wave-uniform, no barrier in the loop
     float in[TIN];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -168,6 +176,7 @@ __global__ __launch_bounds__(256) void texture_fwd_kernel(dsu_tex_mlp m,
     float out[TOUT] = {0.0f, 0.0f, 0.0f};
 #pragma unroll 1
     for (int a = 0; a < 2; ++a) {
+      if (wave_first + a * 32 >= r1) continue;
       f32x16 H0[2], H1[2];
       forward_half(lds, in, a, l31, h, H0, H1);
       float p[TOUT];
@@ -210,11 +219,15 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
       gb1[T][r] = 0.0f;
     }
 
-  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t base = blockIdx.x * (int64_t)blockDim.x; base < n; base += stride) {
+  const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 31) / 32 * 32;   // see texture_fwd_kernel
+  const int64_t r0 = blockIdx.x * per;
+  const int64_t r1 = r0 + per < n ? r0 + per : n;
+  for (int64_t base = r0; base < r1; base += blockDim.x) {
     const int64_t i = base + threadIdx.x;
-    const bool valid = i < n;
-    const int64_t ii = valid ? i : n - 1;
+    const bool valid = i < r1;
+    const int64_t ii = valid ? i : r1 - 1;
+    const int64_t wave_first = base + wave * 64;
+    if (wave_first >= r1) continue;                    // wave-uniform, no workgroup barrier in the loop
     float in[TIN];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -231,6 +244,7 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
     }
 #pragma unroll 1
     for (int a = 0; a < 2; ++a) {
+      if (wave_first + a * 32 >= r1) continue;
       f32x16 H0[2], H1[2];
       forward_half(lds, in, a, l31, h, H0, H1);
       // dz of the samples of half a, in every lane of the pair
@@ -347,8 +361,8 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
           const float wa = l31 < TIN ? lds[L_W0 + feat_of(T, r, h) * W0_ROW + l31] : 0.0f;
           din = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, D0[T][r], din, 0, 0, 0);
         }
-      const int64_t si = base + wave * 64 + a * 32 + l31;        // the sample of column l31
-      if (si < n) {
+      const int64_t si = wave_first + a * 32 + l31;              // the sample of column l31
+      if (si < r1) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
           *reinterpret_cast<float4*>(d_x + si * TIN + 8 * q + 4 * h) =

@@ -7,6 +7,7 @@ ellipse), random-init weights of the reference architectures.  Blender/Mixamo ri
 recon and stylisation is an external manual tool in the reference (README.md:183-186); the
 stylisation frames are synthetic colour / position / edge maps of the stated shapes.
 """
+import os
 import time
 
 import numpy as np
@@ -59,6 +60,7 @@ class DrawingPipeline:
                  with_clip=True, export_resolution=512, with_mv=True, with_contour=True):
         self.device = torch.device(device)
         self.mv_steps, self.nsr_steps, self.n_frames = mv_steps, nsr_steps, n_frames
+        self.style_batch = int(os.environ.get("DSU_STYLE_BATCH", "4"))   # frames per generator call
         self.time_substages = False          # bench.py: split the NSR stage into fit / export
         self.substage_seconds = {}
         self.export_resolution = export_resolution
@@ -71,6 +73,21 @@ class DrawingPipeline:
             from .contour.predict import load_generator
             torch.manual_seed(seed + 2)
             self.contour = load_generator(None, self.device)
+            self._calibrate_random_contour()
+
+    @torch.no_grad()
+    def _calibrate_random_contour(self, fraction=0.03):
+        """Random-init weights put the contour probability near 0.5 everywhere: the whole image
+        would be "contour", the inpainting front empty and the stage's host tail a no-op.  Shift
+        the output bias so that ~3 % of a synthetic drawing's pixels exceed predict.py's 0.2
+        threshold (thin-line coverage), i.e. the TELEA tail does representative work."""
+        last = [m for m in self.contour.modules() if isinstance(m, torch.nn.Conv2d)][-1]
+        d = synthetic_drawing(4242, device=self.device)
+        x = torch.cat([d[:3] * d[3:4] + (1 - d[3:4]), d[3:4]], 0)[None]
+        p = self.contour(x)[0, 0].float().clamp(1e-6, 1 - 1e-6)
+        logit = torch.log(p / (1 - p)).flatten()
+        q = torch.quantile(logit[::5], 1.0 - fraction)
+        last.bias += float(np.log(0.2 / 0.8)) - float(q)
 
     def shared_modules(self):
         mods = [self.gen1, self.gen2]
@@ -84,20 +101,27 @@ class DrawingPipeline:
 
     # ---------------------------------------------------------------- stage 1: predict.py
     @torch.no_grad()
-    def remove_contour(self, drawing_rgba, threshold=0.2):
-        """1_lama_contour_remover/predict.py:46-62 on the device: the drawing composited on white
-        + its alpha -> FFC-ResNet generator -> contour mask (prob > 0.2) and inpaint mask
-        max(contour, 255 - alpha).  The CPU tail of the reference (cv2.inpaint TELEA over that
-        mask, predict.py:63) is host geometry and not part of this path; the drawing handed on is
-        the composited input with its alpha, the masks ride along for a host inpainter."""
+    def remove_contour(self, drawing_rgba, threshold=0.2, radius=3):
+        """1_lama_contour_remover/predict.py:46-66: the drawing composited on white + its alpha ->
+        FFC-ResNet generator (device) -> contour mask (prob > 0.2), inpaint mask
+        max(contour, 255 - alpha) -> TELEA inpainting of the uint8 image (host code in
+        libdsu_hip.so, as the reference's cv2.inpaint: fast marching is serial) -> RGBA with the
+        input alpha, handed to the diffusion stage in memory instead of `_inpainted.png`."""
         if self.contour is None:
             return drawing_rgba
+        from .contour.predict import inpaint
         rgb, a = drawing_rgba[:3], drawing_rgba[3:4]
         x = torch.cat([rgb * a + (1 - a), a], 0)[None]
         prob = self.contour(x)[0, 0].float()
         contour = prob > threshold
         self.last_contour_masks = (contour, contour | (a[0] < 1.0))
-        return drawing_rgba
+        # predict.py:55-62 on the host (uint8 truncation as .astype('uint8') there)
+        xh = (x[0] * 255).to(torch.uint8).permute(1, 2, 0).contiguous().cpu().numpy()
+        img, alpha = np.ascontiguousarray(xh[:, :, :3]), xh[:, :, 3]
+        mask = np.maximum(contour.to(torch.uint8).mul(255).cpu().numpy(), 255 - alpha)
+        inpainted = inpaint(img, mask, radius)
+        out = np.concatenate([inpainted, alpha[:, :, None]], 2)
+        return torch.from_numpy(out).to(self.device).permute(2, 0, 1).float() / 255.0
 
     # ---------------------------------------------------------------- stage 2a: mv.py
     @torch.no_grad()
@@ -156,17 +180,19 @@ class DrawingPipeline:
     # ---------------------------------------------------------------- stage 3: test_stage1/2.py
     @torch.no_grad()
     def stylize(self, frames):
-        """frames (n,6,H,W).  Stage 1 per frame, quantised to uint8 like the PNG hand-off, then
-        stage 2 on the re-normalised stage-1 RGB (+ mask + pos)."""
+        """frames (n,6,H,W).  Stage 1, quantised to uint8 like the PNG hand-off, then stage 2 on the
+        re-normalised stage-1 RGB (+ mask + pos) — test_stage1.py / test_stage2.py loop over the
+        frames one by one; the generators are per-image functions in eval mode, so the frames
+        go through in chunks of `style_batch` (same per-frame results, and the 64^2 / 128^2
+        levels of the U-net get enough tiles to fill the chip)."""
         outs = []
-        for f in frames:
-            x = f[None]
-            s1 = self.gen1(x)[0]
+        for i in range(0, frames.shape[0], self.style_batch):
+            x = frames[i:i + self.style_batch]
+            s1 = self.gen1(x)
             q = to_image_space(s1).float() / 255.0 * 2 - 1                 # PNG round trip
-            x2 = torch.cat([q, x[0, 3:]], 0)[None]
-            s2 = self.gen2(x2)[0]
-            outs.append(torch.cat([to_image_space(s2), (x[0, 3:4] * 255).to(torch.uint8)], 0))
-        return torch.stack(outs)
+            s2 = self.gen2(torch.cat([q, x[:, 3:]], 1))
+            outs.append(torch.cat([to_image_space(s2), (x[:, 3:4] * 255).to(torch.uint8)], 1))
+        return torch.cat(outs)
 
     def run(self, seed):
         drawing = synthetic_drawing(seed, device=self.device)

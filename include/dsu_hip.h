@@ -537,6 +537,14 @@ int dsu_layernorm_f16(const void* x, const void* gamma, const void* beta, int64_
  * h (rows, 2*D) f16 = proj output; out[r][j] = h[r][j] * gelu_erf(h[r][D+j]). */
 int dsu_geglu_f16(const void* h, int64_t rows, int32_t D, void* out, void* stream);
 
+/* cv2.inpaint(img, mask, radius, cv2.INPAINT_TELEA) on an 8-bit 3-channel HOST image
+ * (1_lama_contour_remover/predict.py:63: the predicted contour pixels and the background are
+ * filled from the character's own pixels).  Host code, as in the reference: fast marching is a
+ * strictly ordered front propagation.  img/out (rows, cols, 3) u8, mask (rows, cols) u8
+ * (non-zero = fill); rows, cols >= 3. */
+int dsu_inpaint_telea_u8c3(const uint8_t* img, const uint8_t* mask, int32_t rows, int32_t cols,
+                           int32_t radius, uint8_t* out);
+
 /* torch.optim.AdamW step on a range of the hash-table parameters (the optimizer the reference
  * configures in configs/neuralangelo-ortho-wmask.yaml:96-110 -> systems/utils.py parse_optimizer;
  * torch's update: p -= lr*wd*p; m = lerp(m, g, 1-b1); v = b2*v + (1-b2)*g*g;

@@ -20,6 +20,10 @@ def wrap(name):
             st = k.get('stride',1); up = k.get('upsample2x', False)
             OH, OW = r.shape[1], r.shape[2]
             key = (name, B,H,W,C,O,kk,st,int(up)); fl = 2.0*B*OH*OW*O*kk*kk*C
+        elif name in ('linear_f16', 'linear_geglu_f16'):
+            xx, w = a[0], a[1]
+            K = xx.shape[-1]; M = xx.numel() // K; N = w.shape[0]
+            key = (name, M, K, N, int(k.get('transposed_tokens', 0) > 0)); fl = 2.0 * M * K * N
         elif name == 'mv_attention':
             q = a[0]; key = (name,)+tuple(q.shape)+tuple(a[1].shape); fl = 0
         else:
@@ -27,7 +31,7 @@ def wrap(name):
         rec.append((key, s, e, fl))
         return r
     setattr(ops, name, g)
-for n in ('conv2d_nhwc_f16','mv_attention','groupnorm_nhwc_f16','layernorm_f16','geglu_f16'):
+for n in ('conv2d_nhwc_f16','mv_attention','groupnorm_nhwc_f16','layernorm_f16','geglu_f16','linear_f16','linear_geglu_f16'):
     wrap(n)
 # the mv modules may have imported the functions by name: patch there too
 import drawingspinup_amd.mv.unet as U
