@@ -12,7 +12,11 @@ t=torch.linspace(-0.6,0.6,128)
 pts=torch.cat([r[:,None,:].expand(-1,128,-1), t[None,:,None].expand(2048,-1,1)],-1).reshape(-1,3).contiguous().to(dev)
 d=[torch.randn(N,device=dev),torch.randn(N,3,device=dev),torch.randn(N,13,device=dev),torch.randn(N,device=dev)*1e-3]
 gt=torch.zeros(cfg.n_params,device=dev)
+# round 2: the step evaluates the points in Morton order (ops.spatial_sort), eps = the finest cell
+ACT = int(os.environ.get("PMC_ACTIVE", "5"))
+EPS = 1.0 / 128
 for _ in range(5):
-    out = ops.sdf_fd_fwd(cfg,tab,mlp,pts,1.0,0.02,4,enc_cache=True)
-    ops.sdf_fd_bwd(cfg,tab,mlp,pts,1.0,0.02,4,*d,grad_table=gt,enc_cache=out[4])
+    ps, perm = ops.spatial_sort(pts, 1.0, 6)
+    out = ops.sdf_fd_fwd(cfg,tab,mlp,ps,1.0,EPS,ACT,True,True,False,enc_cache=True,perm=perm)
+    ops.sdf_fd_bwd(cfg,tab,mlp,ps,1.0,EPS,ACT,d[0],d[1],d[2],None,grad_table=gt,enc_cache=out[4],perm=perm)
 torch.cuda.synchronize()
