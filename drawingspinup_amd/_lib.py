@@ -52,6 +52,14 @@ class RayLossCfg(C.Structure):
 # name -> argtypes; every function returns int.  Kept in one table so that the CPU test
 # "the library exports every symbol the header declares" can walk it.
 P = c_vp
+class AdamwTensor(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p),
+                ("n", C.c_int64), ("lr", C.c_float), ("bias_correction1", C.c_float),
+                ("bias_correction2_sqrt", C.c_float), ("reserved", C.c_float)]
+
+
+ADAMW_MAX_TENSORS = 24
+
 _PROTOS = {
     "dsu_abi_version": [],
     "dsu_hashgrid_make_levels": [C.POINTER(HashGridCfg), C.POINTER(HashGridLevels)],
@@ -76,6 +84,7 @@ _PROTOS = {
     "dsu_inpaint_telea_u8c3": [P, P, c_i32, c_i32, c_i32, P],
     "dsu_table_adamw": [P, P, P, P, P, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, P],
     "dsu_table_decay": [P, P, c_i64, c_f32, P],
+    "dsu_adamw_multi": [P, c_i32, c_f32, c_f32, c_f32, c_f32, P],
     "dsu_smooth_iterate": [P, c_i64, P, C.c_double, c_i32, P, P, P],
     "dsu_smooth_energy": [P, c_i64, P, P, P, P],
     "dsu_smooth_energy_partials": [],

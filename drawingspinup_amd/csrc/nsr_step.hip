@@ -360,19 +360,32 @@ __global__ __launch_bounds__(256) void sample_losses_kernel(
   }
 }
 
-// offsets = exclusive scan(counts); stats = {sum, max}.  One workgroup, chunks of blockDim.
+// offsets = exclusive scan(counts); stats = {sum, max}.  One workgroup; every thread owns 8
+// consecutive rays per pass (one pass for the <= 8192 rays of a training batch: the first version
+// ran one barrier-heavy block scan per 1024 rays, 92 us on the side stream, and whichever
+// one-wave-per-SIMD kernel of the main stream shared its CU waited for it).
 __global__ __launch_bounds__(1024) void ray_offsets_kernel(const int32_t* __restrict__ counts,
                                                            int64_t n, int32_t* __restrict__ offsets,
                                                            int32_t* __restrict__ stats) {
   __shared__ int red[32];
+  constexpr int PER = 8;
   int carry = 0, mx = 0;
-  for (int64_t base = 0; base < n; base += blockDim.x) {
-    const int64_t i = base + threadIdx.x;
-    const int c = i < n ? counts[i] : 0;
-    mx = max(mx, c);
+  for (int64_t base = 0; base < n; base += (int64_t)blockDim.x * PER) {
+    const int64_t i0 = base + (int64_t)threadIdx.x * PER;
+    int c[PER], tsum = 0;
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      c[k] = i0 + k < n ? counts[i0 + k] : 0;
+      mx = max(mx, c[k]);
+      tsum += c[k];
+    }
     int total;
-    const int ex = block_excl_scan(c, red, &total);
-    if (i < n) offsets[i] = carry + ex;
+    int ex = carry + block_excl_scan(tsum, red, &total);
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      if (i0 + k < n) offsets[i0 + k] = ex;
+      ex += c[k];
+    }
     carry += total;
   }
 #pragma unroll
@@ -440,6 +453,8 @@ __global__ __launch_bounds__(256) void table_adamw_kernel(
     __half2* __restrict__ img, int64_t n4, float lr, float beta1, float beta2, float eps, float wd,
     float bc1, float bc2_sqrt) {
   const float step_size = lr / bc1;
+  // 1 - beta from the double values torch uses (1 - 0.99f is 9.5e-7 off 0.01)
+  const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
        i += (int64_t)gridDim.x * blockDim.x) {
     float4 P = p[i], G = g[i], M = m[i], V = v[i];
@@ -448,8 +463,8 @@ __global__ __launch_bounds__(256) void table_adamw_kernel(
     for (int k = 0; k < 4; ++k) {
       float x = pp[k];
       x -= lr * wd * x;
-      const float mk = mm[k] + (gg[k] - mm[k]) * (1.0f - beta1);        // lerp, as torch
-      const float vk = beta2 * vv[k] + (1.0f - beta2) * gg[k] * gg[k];
+      const float mk = mm[k] + (gg[k] - mm[k]) * omb1;                  // lerp, as torch
+      const float vk = beta2 * vv[k] + omb2 * gg[k] * gg[k];
       const float denom = sqrtf(vk) / bc2_sqrt + eps;
       x -= step_size * mk / denom;
       pp[k] = x; mm[k] = mk; vv[k] = vk;
@@ -458,6 +473,30 @@ __global__ __launch_bounds__(256) void table_adamw_kernel(
     g[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
     img[2 * i] = __floats2half2_rn(P.x, P.y);
     img[2 * i + 1] = __floats2half2_rn(P.z, P.w);
+  }
+}
+
+// torch.optim.AdamW for the model's small tensors (SDF MLP, texture MLP, variance: 13 tensors of
+// 1..4096 elements in three parameter groups) in ONE launch: torch's fused optimizer needs a
+// step-counter launch + an update launch per group (6 launches, ~45 us of a 1.45 ms step).
+struct AdamwMultiArgs {
+  dsu_adamw_tensor t[DSU_ADAMW_MAX_TENSORS];
+  float beta1, beta2, eps, wd;
+};
+
+__global__ __launch_bounds__(256) void adamw_multi_kernel(AdamwMultiArgs a) {
+  const dsu_adamw_tensor t = a.t[blockIdx.y];
+  const float step_size = t.lr / t.bias_correction1;
+  const float omb1 = (float)(1.0 - (double)a.beta1), omb2 = (float)(1.0 - (double)a.beta2);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < t.n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float g = t.g[i];
+    float x = t.p[i];
+    x -= t.lr * a.wd * x;
+    const float mk = t.m[i] + (g - t.m[i]) * omb1;
+    const float vk = a.beta2 * t.v[i] + omb2 * g * g;
+    x -= step_size * mk / (sqrtf(vk) / t.bias_correction2_sqrt + a.eps);
+    t.p[i] = x; t.m[i] = mk; t.v[i] = vk;
   }
 }
 
@@ -487,6 +526,26 @@ int dsu_table_adamw(float* p, float* g, float* m, float* v, void* img_f16, int64
   table_adamw_kernel<<<dsu_capped_blocks(n / 4, 256, 2048), 256, 0, (hipStream_t)stream>>>(
       (float4*)p, (float4*)g, (float4*)m, (float4*)v, (__half2*)img_f16, n / 4, lr, beta1, beta2,
       eps, weight_decay, bias_correction1, bias_correction2_sqrt);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_adamw_multi(const dsu_adamw_tensor* tensors, int32_t count, float beta1, float beta2,
+                    float eps, float weight_decay, void* stream) {
+  if (count < 0 || count > DSU_ADAMW_MAX_TENSORS || (count && !tensors)) return DSU_EINVAL;
+  if (count == 0) return DSU_OK;
+  AdamwMultiArgs a;
+  int64_t nmax = 0;
+  for (int i = 0; i < count; ++i) {
+    const dsu_adamw_tensor& t = tensors[i];
+    if (t.n < 0 || (t.n && (!t.p || !t.g || !t.m || !t.v))) return DSU_EINVAL;
+    if (!(t.bias_correction1 > 0.0f) || !(t.bias_correction2_sqrt > 0.0f)) return DSU_EINVAL;
+    a.t[i] = t;
+    if (t.n > nmax) nmax = t.n;
+  }
+  a.beta1 = beta1; a.beta2 = beta2; a.eps = eps; a.wd = weight_decay;
+  if (nmax == 0) return DSU_OK;
+  adamw_multi_kernel<<<dim3(dsu_capped_blocks(nmax, 256, 64), count), 256, 0, (hipStream_t)stream>>>(a);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }

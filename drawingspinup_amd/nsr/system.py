@@ -297,6 +297,39 @@ class TableAdamW:
         self.pending = 1.0           # the levels >= act are current; later steps accumulate from 1
 
 
+class SmallAdamW:
+    """torch.optim.AdamW (same update, per-group lr, per-tensor step count) for the model's small
+    tensors in ONE launch (`dsu_adamw_multi`): torch's fused optimizer spends a step-counter launch
+    and an update launch per parameter group.  Tensors without a gradient are skipped, as torch
+    does."""
+
+    def __init__(self, torch_optimizer, betas, eps, weight_decay=0.01):
+        self.opt = torch_optimizer                    # owns the groups (lr schedule, zero_grad)
+        self.betas, self.eps, self.wd = betas, eps, weight_decay
+        self.state = {}                               # id(param) -> [m, v, step]
+        n = sum(len(g["params"]) for g in self.opt.param_groups)
+        assert n <= ops._lib.ADAMW_MAX_TENSORS, "more small tensors than dsu_adamw_multi takes"
+
+    def step(self):
+        b1, b2 = self.betas
+        entries = []
+        for group in self.opt.param_groups:
+            lr = group["lr"]
+            for p in group["params"]:
+                g = p.grad
+                if g is None:
+                    continue
+                st = self.state.get(id(p))
+                if st is None:
+                    st = self.state[id(p)] = [torch.zeros_like(p.data), torch.zeros_like(p.data), 0]
+                st[2] += 1
+                if not g.is_contiguous():
+                    g = g.contiguous()
+                entries.append((p.data, g, st[0], st[1], lr, 1.0 - b1 ** st[2],
+                                math.sqrt(1.0 - b2 ** st[2])))
+        ops.adamw_multi(entries, b1, b2, self.eps, self.wd)
+
+
 class OrthoNeuSSystem:
     def __init__(self, model_config=None, system_config=None, device="cuda", seed=123456):
         torch.manual_seed(seed)
@@ -326,6 +359,10 @@ class OrthoNeuSSystem:
         self.optimizer = torch.optim.AdamW(groups, lr=oc.lr, betas=tuple(oc.betas), eps=oc.eps,
                                            **({"fused": True} if fused else {}))
         self._base_lrs = [g["lr"] for g in groups]
+        # the small tensors' AdamW as one launch (DSU_SMALL_ADAM=0: torch's fused optimizer)
+        self.small_opt = None
+        if self.device.type == "cuda" and os.environ.get("DSU_SMALL_ADAM", "1") != "0":
+            self.small_opt = SmallAdamW(self.optimizer, tuple(oc.betas), oc.eps)
         # ExponentialLR gamma = 0.1 ** (1 / (max_steps - constant_steps))  (recon.py:13)
         self._gamma = 0.1 ** (1.0 / (self.config.max_steps - self.config.constant_steps))
         self.dataset = None
@@ -440,6 +477,12 @@ class OrthoNeuSSystem:
     def zero_grad(self):
         self.optimizer.zero_grad(set_to_none=True)
         self.model.geometry.hashgrid.params.grad = None     # not in the torch optimizer's groups
+
+    def _step_small(self):
+        if self.small_opt is not None:
+            self.small_opt.step()
+        else:
+            self.optimizer.step()
 
     def _step_table(self, active_levels):
         """Optimizer step of the hash table: the fused kernel (gradient in table_opt.grad), or —
@@ -671,7 +714,7 @@ class OrthoNeuSSystem:
         else:                                            # no weight norm: w is the parameter
             lin0.weight.grad, lin1.weight.grad = g[0], g[2]
         lin0.bias.grad, lin1.bias.grad = g[1], g[3]
-        self.optimizer.step()
+        self._step_small()
         self._step_table(active)
         self.global_step += 1
         terms = {"rgb_mse": rterms[0]}
@@ -717,7 +760,7 @@ class OrthoNeuSSystem:
             terms = self.losses(out, batch)
             loss = sum(terms.values())
             loss.backward()
-        self.optimizer.step()
+        self._step_small()
         enc = self.model.geometry.hashgrid
         if self.table_opt is not None:
             if enc.params.grad is not None:

@@ -175,6 +175,21 @@ def table_adamw(p, g, m, v, img_f16, n, lr, beta1, beta2, eps, weight_decay, bc1
           "dsu_table_adamw")
 
 
+def adamw_multi(entries, beta1, beta2, eps, weight_decay):
+    """entries: list of (p, g, m, v, lr, bc1, bc2_sqrt) f32 device tensors / floats (<= 24): one
+    launch of torch.optim.AdamW's update for all of them."""
+    n = len(entries)
+    if n == 0:
+        return
+    arr = (_lib.AdamwTensor * n)()
+    for k, (p, g, m, v, lr, bc1, bc2s) in enumerate(entries):
+        a = arr[k]
+        a.p, a.g, a.m, a.v = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+        a.n, a.lr, a.bias_correction1, a.bias_correction2_sqrt = p.numel(), lr, bc1, bc2s
+    check(lib().dsu_adamw_multi(arr, n, float(beta1), float(beta2), float(eps), float(weight_decay),
+                                stream()), "dsu_adamw_multi")
+
+
 def table_decay(p, img_f16, start, n, factor):
     """p[start:start+n] *= factor (+ f16 image); start, n multiples of 4 floats."""
     check(lib().dsu_table_decay(C.c_void_p(p.data_ptr() + 4 * int(start)),

@@ -556,6 +556,17 @@ int dsu_table_adamw(float* p, float* g, float* m, float* v, void* img_f16, int64
                     float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
                     float bias_correction2_sqrt, void* stream);
 int dsu_table_decay(float* p, void* img_f16, int64_t n, float factor, void* stream);
+/* The same AdamW update for up to DSU_ADAMW_MAX_TENSORS small tensors in one launch (the SDF MLP,
+ * texture MLP and variance parameters of the three optimizer groups, each with its group's lr and
+ * its own bias corrections); `tensors` is a HOST array. */
+#define DSU_ADAMW_MAX_TENSORS 24
+typedef struct {
+  float* p; float* g; float* m; float* v;
+  int64_t n;
+  float lr, bias_correction1, bias_correction2_sqrt, reserved;
+} dsu_adamw_tensor;
+int dsu_adamw_multi(const dsu_adamw_tensor* tensors, int32_t count, float beta1, float beta2,
+                    float eps, float weight_decay, void* stream);
 
 /* mcubes.smooth on the export's binary volume (MarchingCubeHelper.forward,
  * instant_nsr/models/geometry.py:57-58 -> PyMCubes' constrained smoothing): the weighted-Jacobi

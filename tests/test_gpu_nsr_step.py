@@ -302,3 +302,31 @@ def test_table_adamw_matches_torch_adamw_with_progressive_levels(dev):
     n = off[7]
     torch.testing.assert_close(enc.params.detach()[:n], ref.detach()[:n], rtol=5e-6, atol=1e-9)
     assert torch.equal(enc.table_f16()[:n], enc.params.detach()[:n].half())
+
+
+def test_small_adamw_matches_torch_adamw(dev):
+    """dsu_adamw_multi (one launch for all small tensors, per-group lr, per-tensor step count, tensors
+    without a gradient skipped) against torch.optim.AdamW."""
+    from drawingspinup_amd.nsr.system import SmallAdamW
+    g = torch.Generator().manual_seed(0)
+    shapes = [(64, 23), (64,), (13, 64), (13,), (64, 16), (64, 64), (3, 64), (1,), (4096,)]
+    ps = [torch.nn.Parameter(torch.randn(*s, generator=g).to(dev)) for s in shapes]
+    rs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    mk = lambda params: torch.optim.AdamW([{"params": params[:4], "lr": 1e-3}, {"params": params[4:7], "lr": 1e-2},
+                                           {"params": params[7:], "lr": 5e-3}], lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    topt, holder = mk(rs), mk(ps)
+    sopt = SmallAdamW(holder, (0.9, 0.99), 1e-15)
+    for it in range(6):
+        for grp_t, grp_s in zip(topt.param_groups, holder.param_groups):
+            grp_t["lr"] = grp_s["lr"] = grp_s["lr"] * 0.9
+        for k, (p, r) in enumerate(zip(ps, rs)):
+            if k == 5 and it % 2 == 0:                   # a tensor that sometimes has no gradient
+                p.grad = r.grad = None
+                continue
+            gr = (torch.randn(p.shape, generator=g) * (10.0 ** (k % 3 - 2))).to(dev)
+            p.grad, r.grad = gr.clone(), gr.clone()
+        topt.step()
+        sopt.step()
+        for p, r in zip(ps, rs):
+            # absolute rounding differences scale with the step (lr <= 1e-2), not with the value
+            torch.testing.assert_close(p.detach(), r.detach(), rtol=3e-6, atol=3e-8)

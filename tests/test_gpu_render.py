@@ -152,3 +152,18 @@ def test_single_pass_march_equals_two_pass(dev):
     b = ops.ray_march_single_pass(to, td, tmin, tmax, AABB, None, 0, STEP)
     for x, y in zip(a, b):
         assert torch.equal(x, y)
+
+
+@pytest.mark.parametrize("n", [1, 7, 1000, 8192, 8193, 20011])
+def test_ray_offsets_scan(dev, n):
+    """dsu_ray_offsets: exclusive scan of the per-ray sample counts + (total, max), INT exact."""
+    from drawingspinup_amd._lib import check, lib, ptr, stream
+    g = torch.Generator().manual_seed(n)
+    counts = torch.randint(0, 600, (n,), generator=g, dtype=torch.int32)
+    c = counts.to(dev)
+    off = torch.empty_like(c)
+    stats = torch.empty(2, dtype=torch.int32, device=dev)
+    check(lib().dsu_ray_offsets(ptr(c), n, ptr(off), ptr(stats), stream()), "dsu_ray_offsets")
+    ref = torch.cumsum(counts.long(), 0) - counts.long()
+    assert torch.equal(off.cpu().long(), ref)
+    assert stats.cpu().tolist() == [int(counts.sum()), int(counts.max())]

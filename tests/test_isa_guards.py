@@ -50,7 +50,10 @@ def test_dominant_nsr_kernels_have_no_scratch():
         assert md["scratch"] == 0 and md["vspill"] == 0, (name, md)
         assert sum(o.startswith("scratch_") for o in ops) == 0, name
         assert md["vgpr"] <= 512
-    # the production variant <NL=10, fused scatter, feature cache>: the gather path and its level
-    # metadata are compiled out (SGPR spills 130 -> 36 when that was introduced)
-    md, _ = ks["sdf_fd_bwd_mfma_kernel<10,0,1>"]
+    # the production variant <NL=10, MLP part only (split), feature cache>: the gather path and its
+    # level metadata are compiled out (SGPR spills 130 -> 36 when that was introduced for the fused
+    # form, which is kept as an option and allowed a few more for the per-workgroup range scalars)
+    md, _ = ks["sdf_fd_bwd_mfma_kernel<10,1,1>"]
     assert md["sspill"] <= 48, md
+    md, _ = ks["sdf_fd_bwd_mfma_kernel<10,0,1>"]
+    assert md["sspill"] <= 72, md
