@@ -96,6 +96,9 @@ _PROTOS = {
     "dsu_ray_march_scratch": [P, P, P, P, c_i64, P, P, c_i32, c_f32, c_i32, P, P, P, P],
     "dsu_ray_compact": [P, P, c_i32, P, P, c_i64, P, P, P, P],
     "dsu_ray_compact_points": [P, P, c_i32, P, P, c_i64, P, P, P, P, P, P],
+    "dsu_ray_compact_points_cap": [P, P, c_i32, P, P, c_i64, P, P, P, P, P, c_i64, P],
+    "dsu_points_tail": [P, c_i64, P, P, P, c_i64, c_f32, P],
+    "dsu_spatial_sort_dev": [P, c_i64, P, c_i64, c_f32, c_i32, P, P, P, c_i64, P],
     "dsu_ray_offsets": [P, c_i64, P, P, P],
     "dsu_ortho_ray_batch": [P, P, P, c_i64, P, P, P, P, c_i32, P, P, P, c_i32, c_i32, P, P, P, P, P,
                             P, P],

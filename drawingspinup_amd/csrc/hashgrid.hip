@@ -256,11 +256,17 @@ __device__ __forceinline__ void mlp_stream_sgpr(const dsu_sdf_mlp& mlp, const fl
   mlp_stream_sgpr<NLv, NOv, LMAXv>(mlp, in, kmax, out)
 #define DSU_FWD_LOAD_MLP(NLv, lds, mlp)
 #define DSU_FWD_LDS_BYTES(NLv) ((size_t)0)
+// no LDS, no barrier: one-wave workgroups, so that the dispatcher balances n / 64 waves over the
+// 1024 SIMDs (256-point workgroups: 1040 of them for 256 CUs, i.e. 16 CUs carried 5 and set the pace)
+#ifndef DSU_FWD_THREADS
+#define DSU_FWD_THREADS 64
+#endif
 #else
 #define DSU_MLP_STREAM(NLv, NOv, LMAXv, lds, mlp, in, kmax, out) \
   mlp_stream<NLv, NOv, LMAXv>(lds, in, kmax, out)
 #define DSU_FWD_LOAD_MLP(NLv, lds, mlp) load_mlp_to_lds<NLv>(lds, mlp.w0, mlp.b0, mlp.w1, mlp.b1)
 #define DSU_FWD_LDS_BYTES(NLv) (MlpLds<NLv>::TOTAL * sizeof(float))
+#define DSU_FWD_THREADS 256
 #endif
 
 template <int NL, int NO>
@@ -772,14 +778,14 @@ int dsu_sdf_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, const d
   if (rc) return rc;
   if (n == 0) return DSU_OK;
   hipStream_t s = (hipStream_t)stream;
-  const int blocks = dsu_capped_blocks(n, 256, 8192);
+  const int blocks = dsu_capped_blocks(n, DSU_FWD_THREADS, 8192 * (256 / DSU_FWD_THREADS));
   DSU_DISPATCH_NL(cfg->n_levels, {
     const size_t shm = DSU_FWD_LDS_BYTES(NL);
     if (n_out == 1)
-      sdf_fwd_kernel<NL, 1><<<dim3(blocks), dim3(256), shm, s>>>(
+      sdf_fwd_kernel<NL, 1><<<dim3(blocks), dim3(DSU_FWD_THREADS), shm, s>>>(
           (const __half2*)table_f16, m, *mlp, pts, n, radius, active_levels, out);
     else
-      sdf_fwd_kernel<NL, NOUT><<<dim3(blocks), dim3(256), shm, s>>>(
+      sdf_fwd_kernel<NL, NOUT><<<dim3(blocks), dim3(DSU_FWD_THREADS), shm, s>>>(
           (const __half2*)table_f16, m, *mlp, pts, n, radius, active_levels, out);
   });
   DSU_CHECK_LAUNCH();
@@ -799,15 +805,15 @@ int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, cons
   if (n == 0) return DSU_OK;
   hipStream_t s = (hipStream_t)stream;
   const float eps2 = (float)((double)eps * (double)eps);
-  const int blocks = dsu_capped_blocks(n, 256, 8192);
+  const int blocks = dsu_capped_blocks(n, DSU_FWD_THREADS, 8192 * (256 / DSU_FWD_THREADS));
   DSU_DISPATCH_NL(cfg->n_levels, {
     const size_t shm = DSU_FWD_LDS_BYTES(NL);
     if (active_levels <= 6)
-      sdf_fd_fwd_kernel<NL, 6><<<dim3(blocks), dim3(256), shm, s>>>(
+      sdf_fd_fwd_kernel<NL, 6><<<dim3(blocks), dim3(DSU_FWD_THREADS), shm, s>>>(
           (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, sdf, grad,
           feature, laplace, (__half2*)enc_cache, perm);
     else
-      sdf_fd_fwd_kernel<NL, NL><<<dim3(blocks), dim3(256), shm, s>>>(
+      sdf_fd_fwd_kernel<NL, NL><<<dim3(blocks), dim3(DSU_FWD_THREADS), shm, s>>>(
           (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, sdf, grad,
           feature, laplace, (__half2*)enc_cache, perm);
   });

@@ -264,12 +264,15 @@ __global__ __launch_bounds__(256) void ray_compact_points_kernel(
     const float* __restrict__ t0s, const float* __restrict__ t1s, int cap,
     const int32_t* __restrict__ off, const int32_t* __restrict__ cnt, int64_t n_rays,
     const float* __restrict__ ro, const float* __restrict__ rd, float* __restrict__ t_starts,
-    float* __restrict__ t_ends, float* __restrict__ positions) {
+    float* __restrict__ t_ends, float* __restrict__ positions, int64_t out_cap) {
   const int lane = threadIdx.x & 63;
   const int64_t r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= n_rays) return;
   const int64_t b = off[r];
-  const int c = cnt[r];
+  int c = cnt[r];
+  // fixed-capacity outputs (prefetch path: the total is not known to the host yet): rows beyond
+  // the capacity are dropped here and the caller, who sees the total later, re-packs
+  if (b + c > out_cap) c = b < out_cap ? (int)(out_cap - b) : 0;
   const float o[3] = {ro[r * 3], ro[r * 3 + 1], ro[r * 3 + 2]};
   const float d[3] = {rd[r * 3], rd[r * 3 + 1], rd[r * 3 + 2]};
   for (int j = lane; j < c; j += 64) {
@@ -716,20 +719,30 @@ int dsu_ray_compact(const float* scratch_t_starts, const float* scratch_t_ends, 
   return DSU_OK;
 }
 
-int dsu_ray_compact_points(const float* scratch_t_starts, const float* scratch_t_ends,
-                           int32_t capacity, const int32_t* offsets, const int32_t* counts,
-                           int64_t n_rays, const float* rays_o, const float* rays_d,
-                           float* t_starts, float* t_ends, float* positions, void* stream) {
-  if (n_rays < 0 || capacity <= 0) return DSU_EINVAL;
+int dsu_ray_compact_points_cap(const float* scratch_t_starts, const float* scratch_t_ends,
+                               int32_t capacity, const int32_t* offsets, const int32_t* counts,
+                               int64_t n_rays, const float* rays_o, const float* rays_d,
+                               float* t_starts, float* t_ends, float* positions,
+                               int64_t out_capacity, void* stream) {
+  if (n_rays < 0 || capacity <= 0 || out_capacity < 0) return DSU_EINVAL;
   if (n_rays && (!scratch_t_starts || !scratch_t_ends || !offsets || !counts || !rays_o ||
                  !rays_d || !t_starts || !t_ends || !positions))
     return DSU_EINVAL;
   if (n_rays == 0) return DSU_OK;
   ray_compact_points_kernel<<<(unsigned)((n_rays + 3) / 4), 256, 0, (hipStream_t)stream>>>(
       scratch_t_starts, scratch_t_ends, capacity, offsets, counts, n_rays, rays_o, rays_d,
-      t_starts, t_ends, positions);
+      t_starts, t_ends, positions, out_capacity);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
+}
+
+int dsu_ray_compact_points(const float* scratch_t_starts, const float* scratch_t_ends,
+                           int32_t capacity, const int32_t* offsets, const int32_t* counts,
+                           int64_t n_rays, const float* rays_o, const float* rays_d,
+                           float* t_starts, float* t_ends, float* positions, void* stream) {
+  return dsu_ray_compact_points_cap(scratch_t_starts, scratch_t_ends, capacity, offsets, counts,
+                                    n_rays, rays_o, rays_d, t_starts, t_ends, positions,
+                                    INT64_MAX, stream);
 }
 
 int dsu_weights_from_alpha_fwd(const float* alpha, const int32_t* offsets, const int32_t* counts,

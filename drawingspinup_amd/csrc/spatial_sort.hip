@@ -44,11 +44,21 @@ __device__ __forceinline__ uint32_t bin_key(const float* __restrict__ pts, int64
   return part1by2(c[0]) | (part1by2(c[1]) << 1) | (part1by2(c[2]) << 2);
 }
 
+// n_dev != nullptr: the point count lives on the device (n = n_dev[0] + n, capped at n_cap) — the
+// prefetch path sorts on the side stream before the host has seen the sample total
+__device__ __forceinline__ int64_t resolve_n(const int32_t* n_dev, int64_t n, int64_t n_cap) {
+  if (n_dev) n += n_dev[0];
+  return n < n_cap ? n : n_cap;
+}
+
 __global__ __launch_bounds__(256) void bin_count_kernel(const float* __restrict__ pts, int64_t n,
                                                         float radius, int bits,
                                                         uint32_t* __restrict__ counters,
                                                         uint32_t* __restrict__ keys,
-                                                        uint32_t* __restrict__ ranks) {
+                                                        uint32_t* __restrict__ ranks,
+                                                        const int32_t* __restrict__ n_dev,
+                                                        int64_t n_cap) {
+  n = resolve_n(n_dev, n, n_cap);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t k = bin_key(pts, i, radius, bits);
@@ -112,7 +122,10 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const float* __restric
                                                           const uint32_t* __restrict__ keys,
                                                           const uint32_t* __restrict__ ranks,
                                                           int32_t* __restrict__ perm,
-                                                          float* __restrict__ pts_sorted) {
+                                                          float* __restrict__ pts_sorted,
+                                                          const int32_t* __restrict__ n_dev,
+                                                          int64_t n_cap) {
+  n = resolve_n(n_dev, n, n_cap);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
     const uint32_t slot = starts[keys[i]] + ranks[i];
@@ -120,6 +133,24 @@ __global__ __launch_bounds__(256) void bin_scatter_kernel(const float* __restric
     pts_sorted[(size_t)slot * 3 + 0] = pts[i * 3 + 0];
     pts_sorted[(size_t)slot * 3 + 1] = pts[i * 3 + 1];
     pts_sorted[(size_t)slot * 3 + 2] = pts[i * 3 + 2];
+  }
+}
+
+// rows [total, total + n_r) = pts_random, [total + n_r, total + 2 n_r) = pts_random + alpha * perturb
+// (neus.py:155-162: the random points of the sparsity / smoothness terms ride in the same
+// geometry launch as the ray samples)
+__global__ __launch_bounds__(256) void points_tail_kernel(float* __restrict__ points, int64_t cap_rows,
+                                                          const int32_t* __restrict__ total_dev,
+                                                          const float* __restrict__ pr,
+                                                          const float* __restrict__ pe, int64_t n_r,
+                                                          float alpha) {
+  const int64_t total = total_dev[0];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n_r * 3;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / 3;
+    const float v = pr[i];
+    if (total + row < cap_rows) points[(total) * 3 + i] = v;
+    if (total + n_r + row < cap_rows) points[(total + n_r) * 3 + i] = v + alpha * pe[i];
   }
 }
 
@@ -135,8 +166,41 @@ int64_t dsu_spatial_sort_workspace_bytes(int64_t n, int32_t bits) {
   return (nb + nb / SCAN_BLOCK + 2 * n) * (int64_t)sizeof(uint32_t);
 }
 
+int dsu_points_tail(float* points, int64_t capacity_rows, const int32_t* total_dev,
+                    const float* pts_random, const float* perturb, int64_t n_random, float alpha,
+                    void* stream) {
+  if (!points || !total_dev || n_random < 0 || capacity_rows < 0 ||
+      (n_random && (!pts_random || !perturb)))
+    return DSU_EINVAL;
+  if (n_random == 0) return DSU_OK;
+  points_tail_kernel<<<dsu_capped_blocks(n_random * 3, 256, 256), 256, 0, (hipStream_t)stream>>>(
+      points, capacity_rows, total_dev, pts_random, perturb, n_random, alpha);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+static int spatial_sort_impl(const float* pts, int64_t n, const int32_t* n_dev, int64_t n_cap,
+                             float radius, int32_t bits, int32_t* perm, float* pts_sorted,
+                             void* workspace, int64_t workspace_bytes, void* stream);
+
 int dsu_spatial_sort(const float* pts, int64_t n, float radius, int32_t bits, int32_t* perm,
                      float* pts_sorted, void* workspace, int64_t workspace_bytes, void* stream) {
+  return spatial_sort_impl(pts, n, nullptr, n, radius, bits, perm, pts_sorted, workspace,
+                           workspace_bytes, stream);
+}
+
+int dsu_spatial_sort_dev(const float* pts, int64_t n_capacity, const int32_t* n_dev, int64_t n_add,
+                         float radius, int32_t bits, int32_t* perm, float* pts_sorted,
+                         void* workspace, int64_t workspace_bytes, void* stream) {
+  if (!n_dev || n_add < 0) return DSU_EINVAL;
+  return spatial_sort_impl(pts, n_add, n_dev, n_capacity, radius, bits, perm, pts_sorted, workspace,
+                           workspace_bytes, stream);
+}
+
+static int spatial_sort_impl(const float* pts, int64_t n_host, const int32_t* n_dev, int64_t n,
+                             float radius, int32_t bits, int32_t* perm, float* pts_sorted,
+                             void* workspace, int64_t workspace_bytes, void* stream) {
+  // n = capacity (the exact count when n_dev is null)
   if ((!pts && n) || (!perm && n) || (!pts_sorted && n) || n < 0 || n > 0x7FFFFFFF)
     return DSU_EINVAL;
   if (!(radius > 0.0f)) return DSU_EINVAL;
@@ -154,11 +218,12 @@ int dsu_spatial_sort(const float* pts, int64_t n, float radius, int32_t bits, in
   if (hipMemsetAsync(counters, 0, (size_t)nb * sizeof(uint32_t), s) != hipSuccess)
     return DSU_ELAUNCH;
   const int blocks = dsu_capped_blocks(n, 256, 2048);
-  bin_count_kernel<<<dim3(blocks), dim3(256), 0, s>>>(pts, n, radius, bits, counters, keys, ranks);
+  bin_count_kernel<<<dim3(blocks), dim3(256), 0, s>>>(pts, n_host, radius, bits, counters, keys, ranks,
+                                                      n_dev, n);
   bin_block_sum_kernel<<<dim3(nblk), dim3(256), 0, s>>>(counters, sums);
   bin_scan_kernel<<<dim3(nblk), dim3(256), 0, s>>>(counters, sums);
-  bin_scatter_kernel<<<dim3(blocks), dim3(256), 0, s>>>(pts, n, counters, keys, ranks, perm,
-                                                        pts_sorted);
+  bin_scatter_kernel<<<dim3(blocks), dim3(256), 0, s>>>(pts, n_host, counters, keys, ranks, perm,
+                                                        pts_sorted, n_dev, n);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }

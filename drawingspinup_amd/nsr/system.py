@@ -31,6 +31,10 @@ VIEWS = ["front", "front_right", "right", "back", "left", "front_left"]
 # fused step; DSU_SPATIAL_SORT=0 keeps the marcher's ray-major order (A/B runs).
 _SPATIAL_SORT_BITS = int(os.environ.get("DSU_SPATIAL_SORT", "6"))
 
+# capacity (samples) of the fixed-size buffers the prefetch path packs into: 2x the schedule's
+# target of 2^18 samples per step; a step that exceeds it is re-packed on the main stream
+_PACK_CAPACITY = 1 << 19
+
 _AZIMUTH = {"front": 0.0, "front_right": 45.0, "right": 90.0, "back": 180.0, "left": 270.0,
             "front_left": 315.0}
 
@@ -376,6 +380,8 @@ class OrthoNeuSSystem:
         self.use_prefetch = os.environ.get("DSU_PREFETCH", "1") != "0" and self.device.type == "cuda"
         self.fused_batch = os.environ.get("DSU_FUSED_BATCH", "1") != "0"
         self._side, self._prefetched = None, None
+        self.pack_on_side_stream = os.environ.get("DSU_PACK_PREFETCH", "1") != "0"
+        self._packed = {}
         self._stats_pinned = [torch.empty(2, dtype=torch.int32).pin_memory() for _ in range(2)] \
             if self.device.type == "cuda" and torch.cuda.is_available() else None
 
@@ -555,6 +561,18 @@ class OrthoNeuSSystem:
         self._side.wait_event(done)            # compaction of THIS step (and a grid refresh) done
         with torch.cuda.stream(self._side):
             prep = self._march_begin()
+            if self.pack_on_side_stream:
+                # compaction + random tail + Morton sort of the next step's points, off the main
+                # stream (8 launches, ~55 us per step)
+                n_r = prep["pts_random"].shape[0]
+                key = nxt & 1
+                bufs = self._packed.get(key)
+                if bufs is None or bufs.tail_rows != 2 * n_r:
+                    bufs = self._packed[key] = ops.PackedStepBuffers(
+                        _PACK_CAPACITY, 2 * n_r, _SPATIAL_SORT_BITS, self.device)
+                ops.ray_pack_prefetched(prep["handle"], bufs, prep["pts_random"], prep["perturb"],
+                                        self.model.geometry.radius)
+                prep["packed"] = bufs
             host = self._stats_pinned[nxt & 1]
             host.copy_(prep["handle"].stats, non_blocking=True)
             prep["stats_host"] = host
@@ -604,12 +622,24 @@ class OrthoNeuSSystem:
         n_rays = rays_d.shape[0]
         pts_random, perturb = prep["pts_random"], prep["perturb"]
         n_r = pts_random.shape[0]
-        with torch.no_grad():
-            allp, ts, te = ops.ray_march_finish(h, total, cmax, tail_rows=2 * n_r)
-            off, cnt, n_s = h.offsets, h.counts, total
-            RayPacking.total = n_s
-            allp[n_s:n_s + n_r] = pts_random
-            torch.add(pts_random, perturb, alpha=1e-2, out=allp[n_s + n_r:])
+        packed = prep.get("packed")
+        perm, presorted = None, False
+        off, cnt, n_s = h.offsets, h.counts, total
+        RayPacking.total = n_s
+        if packed is not None and cmax <= h.cap and total <= packed.capacity:
+            # the side stream already packed the samples, appended the random points and sorted
+            # everything (fixed-capacity buffers; the total was on the device only)
+            n_pk = n_s + 2 * n_r
+            ts, te = packed.t_starts[:n_s], packed.t_ends[:n_s]
+            if packed.bits:
+                allp, perm, presorted = packed.sorted[:n_pk], packed.perm[:n_pk], True
+            else:
+                allp = packed.points[:n_pk]
+        else:
+            with torch.no_grad():
+                allp, ts, te = ops.ray_march_finish(h, total, cmax, tail_rows=2 * n_r)
+                allp[n_s:n_s + n_r] = pts_random
+                torch.add(pts_random, perturb, alpha=1e-2, out=allp[n_s + n_r:])
         # the march scratch rows may be overwritten by the next prefetch once this has run
         done_event = torch.cuda.Event()
         done_event.record(torch.cuda.current_stream())
@@ -639,8 +669,7 @@ class OrthoNeuSSystem:
             # the geometry network is evaluated in Morton order of the sample positions (the
             # ray-major order of random pixels scatters a wave's table accesses over the whole
             # volume); its per-point results come back in ray order through `perm`
-            perm = None
-            if _SPATIAL_SORT_BITS:
+            if _SPATIAL_SORT_BITS and not presorted:
                 allp, perm = ops.spatial_sort(allp, geo.radius, _SPATIAL_SORT_BITS)
             a_sdf, a_grad, a_feat, _, enc_cache = ops.sdf_fd_fwd(
                 enc.cfg, table, mlp, allp, geo.radius, eps, active, True, True, False,

@@ -352,6 +352,44 @@ def ray_march_finish(h, total, cmax, tail_rows=0):
     return points, t_starts, t_ends
 
 
+class PackedStepBuffers:
+    """Fixed-capacity outputs of the prefetch path (one set per step parity): packed sample
+    positions + tail rows, t_starts / t_ends, their Morton-sorted copy + permutation, sort scratch."""
+
+    def __init__(self, capacity, tail_rows, bits, device):
+        self.capacity, self.tail_rows, self.bits = int(capacity), int(tail_rows), int(bits)
+        rows = self.capacity + self.tail_rows
+        f32 = dict(dtype=torch.float32, device=device)
+        self.points = torch.empty(rows, 3, **f32)
+        self.t_starts = torch.empty(self.capacity, **f32)
+        self.t_ends = torch.empty(self.capacity, **f32)
+        self.sorted = torch.empty(rows, 3, **f32) if bits else None
+        self.perm = torch.empty(rows, dtype=torch.int32, device=device) if bits else None
+        self.ws_bytes = int(lib().dsu_spatial_sort_workspace_bytes(rows, self.bits)) if bits else 0
+        self.ws = torch.empty(max(self.ws_bytes, 4) // 4, dtype=torch.int32, device=device)
+
+
+def ray_pack_prefetched(h, bufs, pts_random, perturb, radius, alpha=1e-2):
+    """On the CURRENT (side) stream, without knowing the sample total on the host: compaction of
+    the march scratch into bufs.points / t_starts / t_ends, the random + perturbed points behind
+    the samples, and the Morton sort of all of them (count read from h.stats on the device)."""
+    n_r = pts_random.shape[0]
+    assert 2 * n_r == bufs.tail_rows
+    check(lib().dsu_ray_compact_points_cap(ptr(h.scratch[0]), ptr(h.scratch[1]), h.cap,
+                                           ptr(h.offsets), ptr(h.counts), h.n, ptr(h.rays_o),
+                                           ptr(h.rays_d), ptr(bufs.t_starts), ptr(bufs.t_ends),
+                                           ptr(bufs.points), bufs.capacity, stream()),
+          "dsu_ray_compact_points_cap")
+    check(lib().dsu_points_tail(ptr(bufs.points), bufs.capacity + bufs.tail_rows, ptr(h.stats),
+                                ptr(_f32c(pts_random)), ptr(_f32c(perturb)), n_r, float(alpha),
+                                stream()), "dsu_points_tail")
+    if bufs.bits:
+        check(lib().dsu_spatial_sort_dev(ptr(bufs.points), bufs.capacity + bufs.tail_rows,
+                                         ptr(h.stats), bufs.tail_rows, float(radius), bufs.bits,
+                                         ptr(bufs.perm), ptr(bufs.sorted), ptr(bufs.ws),
+                                         bufs.ws_bytes, stream()), "dsu_spatial_sort_dev")
+
+
 def ray_march_points(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step, tail_rows=0):
     """Single-pass march for the fused optimisation step: returns
     (points (total + tail_rows, 3), t_starts, t_ends, offsets, counts, total) where

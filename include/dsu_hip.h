@@ -145,6 +145,18 @@ int64_t dsu_sdf_fd_enc_cache_bytes(int64_t n, uint32_t active_levels);
 int64_t dsu_spatial_sort_workspace_bytes(int64_t n, int32_t bits);
 int dsu_spatial_sort(const float* pts, int64_t n, float radius, int32_t bits, int32_t* perm,
                      float* pts_sorted, void* workspace, int64_t workspace_bytes, void* stream);
+/* Prefetch-path variants: the sample total of the next step is still on the device when the side
+ * stream packs and sorts its points.  dsu_ray_compact_points_cap = dsu_ray_compact_points into
+ * fixed-capacity outputs (rows beyond out_capacity are dropped: the caller checks the total
+ * later); dsu_points_tail writes the 2 x n_random random / perturbed points of neus.py:155-162
+ * behind the ray samples (row total_dev[0]); dsu_spatial_sort_dev sorts n_dev[0] + n_add points
+ * (at most n_capacity). */
+int dsu_points_tail(float* points, int64_t capacity_rows, const int32_t* total_dev,
+                    const float* pts_random, const float* perturb, int64_t n_random, float alpha,
+                    void* stream);
+int dsu_spatial_sort_dev(const float* pts, int64_t n_capacity, const int32_t* n_dev, int64_t n_add,
+                         float radius, int32_t bits, int32_t* perm, float* pts_sorted,
+                         void* workspace, int64_t workspace_bytes, void* stream);
 int dsu_sdf_fd_fwd_sorted(const dsu_hashgrid_cfg* cfg, const void* table_f16,
                           const dsu_sdf_mlp* mlp, const float* pts_sorted, const int32_t* perm,
                           int64_t n, float radius, float eps, uint32_t active_levels, float* sdf,
@@ -209,6 +221,11 @@ int dsu_ray_compact_points(const float* scratch_t_starts, const float* scratch_t
                            int32_t capacity, const int32_t* offsets, const int32_t* counts,
                            int64_t n_rays, const float* rays_o, const float* rays_d,
                            float* t_starts, float* t_ends, float* positions, void* stream);
+int dsu_ray_compact_points_cap(const float* scratch_t_starts, const float* scratch_t_ends,
+                           int32_t capacity, const int32_t* offsets, const int32_t* counts,
+                           int64_t n_rays, const float* rays_o, const float* rays_d,
+                           float* t_starts, float* t_ends, float* positions, int64_t out_capacity,
+                               void* stream);
 /* offsets = exclusive prefix sum of counts; stats[0] = total, stats[1] = max(counts)
  * (nerfacc's packed_info construction; one launch, read back with ONE host copy). */
 int dsu_ray_offsets(const int32_t* counts, int64_t n_rays, int32_t* offsets, int32_t* stats,

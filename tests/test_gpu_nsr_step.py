@@ -330,3 +330,65 @@ def test_small_adamw_matches_torch_adamw(dev):
         for p, r in zip(ps, rs):
             # absolute rounding differences scale with the step (lr <= 1e-2), not with the value
             torch.testing.assert_close(p.detach(), r.detach(), rtol=3e-6, atol=3e-8)
+
+
+def test_side_stream_packing_matches_main_stream_packing(dev):
+    """The prefetch path packs / appends the random points / sorts the next step's samples on the
+    side stream into fixed-capacity buffers (sample total still on the device); the optimisation
+    must follow the same trajectory as with the main-stream packing (same RNG draws; only the
+    order inside a Morton bin, i.e. float summation order, may differ)."""
+    def run(pack):
+        ds = OrthoData.synthetic_sphere(256, device=dev)
+        sysm = OrthoNeuSSystem(device=dev, seed=11)
+        sysm.dataset = ds
+        sysm.pack_on_side_stream = pack
+        out = []
+        for _ in range(40):
+            r = sysm.training_step()
+            out.append((float(r["loss"]), int(r["n_samples"]), int(r["n_rays"])))
+        used = sum(1 for k in sysm._packed) if pack else 0
+        return out, used
+    a, used_a = run(True)
+    b, used_b = run(False)
+    assert used_a == 2 and used_b == 0                       # both parities of the packed buffers in use
+    # INT: same rays, same sample counts (up to the first occupancy refresh at step 16, which
+    # thresholds float densities)
+    assert [x[1:] for x in a[:15]] == [x[1:] for x in b[:15]]
+    la, lb = np.array([x[0] for x in a]), np.array([x[0] for x in b])
+    np.testing.assert_allclose(la[:15], lb[:15], rtol=2e-3)
+    assert la[-1] < la[0] and lb[-1] < lb[0]
+
+
+def test_packed_step_buffers_equal_the_plain_calls(dev):
+    """dsu_ray_compact_points_cap + dsu_points_tail + dsu_spatial_sort_dev (device-side total)
+    against ray_march_finish + the tensor-level tail + dsu_spatial_sort."""
+    g = torch.Generator().manual_seed(5)
+    n = 700
+    o = torch.cat([torch.rand(n, 2, generator=g) * 1.2 - 0.6, torch.full((n, 1), -2.0)], 1).to(dev)
+    d = torch.tensor([[0.0, 0.0, 1.0]]).expand(n, 3).contiguous().to(dev)
+    aabb = [-1.0] * 3 + [1.0] * 3
+    tmin, tmax = ops.ray_aabb(o, d, aabb)
+    occ = (torch.rand(128 ** 3, generator=g) < 0.3).to(torch.uint8).to(dev)
+    step = 2 * 3 ** 0.5 / 1024
+    h = ops.ray_march_begin(o, d, tmin, tmax, aabb, occ, 128, step)
+    total, cmax = h.stats.tolist()
+    pr = (torch.rand(64, 3, generator=g) * 2 - 1).to(dev)
+    pe = torch.randn(64, 3, generator=g).to(dev)
+    pts, ts, te = ops.ray_march_finish(h, total, cmax, tail_rows=128)
+    pts[total:total + 64] = pr
+    torch.add(pr, pe, alpha=1e-2, out=pts[total + 64:])
+    for cap in (total + 1000, total, total - 37):             # roomy, exact, too small (rows dropped)
+        bufs = ops.PackedStepBuffers(cap, 128, 6, dev)
+        bufs.points.fill_(7.0)
+        ops.ray_pack_prefetched(h, bufs, pr, pe, 1.0)
+        m = min(total, cap)
+        assert torch.equal(bufs.t_starts[:m], ts[:m]) and torch.equal(bufs.t_ends[:m], te[:m])
+        assert torch.equal(bufs.points[:m], pts[:m])
+        if cap >= total:
+            nn = total + 128
+            assert torch.equal(bufs.points[:total + 64], pts[:total + 64])
+            # perturbed copies: torch.add(alpha=) may contract a + alpha * b into one fma
+            torch.testing.assert_close(bufs.points[total + 64:nn], pts[total + 64:nn], rtol=0, atol=2e-7)
+            perm = bufs.perm[:nn].long()
+            assert torch.equal(torch.sort(perm).values, torch.arange(nn, device=dev))
+            assert torch.equal(bufs.sorted[:nn], bufs.points[:nn][perm])
