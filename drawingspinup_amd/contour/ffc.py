@@ -28,6 +28,8 @@ LAMA_FOURIER_GENERATOR = dict(
     downsample_conv_kwargs=dict(ratio_gin=0, ratio_gout=0, enable_lfu=False),
     resnet_conv_kwargs=dict(ratio_gin=0.75, ratio_gout=0.75, enable_lfu=False))
 
+# lazily built, process-wide, NOT locked: the package drives one GPU from one Python thread per process
+# (one process per GPU); guard with a mutex before calling these paths from several threads
 _DFT_CACHE = {}
 
 

@@ -256,10 +256,10 @@ __device__ __forceinline__ void mlp_stream_sgpr(const dsu_sdf_mlp& mlp, const fl
   mlp_stream_sgpr<NLv, NOv, LMAXv>(mlp, in, kmax, out)
 #define DSU_FWD_LOAD_MLP(NLv, lds, mlp)
 #define DSU_FWD_LDS_BYTES(NLv) ((size_t)0)
-// no LDS, no barrier: one-wave workgroups, so that the dispatcher balances n / 64 waves over the
-// 1024 SIMDs (256-point workgroups: 1040 of them for 256 CUs, i.e. 16 CUs carried 5 and set the pace)
+// no LDS, no barrier: any workgroup size works; one-wave workgroups (-DDSU_FWD_THREADS=64, finer
+// balance of n / 64 waves over the SIMDs) measured no faster than 256 (0.1945 vs 0.187 ms)
 #ifndef DSU_FWD_THREADS
-#define DSU_FWD_THREADS 64
+#define DSU_FWD_THREADS 256
 #endif
 #else
 #define DSU_MLP_STREAM(NLv, NOv, LMAXv, lds, mlp, in, kmax, out) \

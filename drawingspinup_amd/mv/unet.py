@@ -157,6 +157,8 @@ class FeedForward(nn.Module):
         return ops.linear_f16(h, self.net[2].weight, self.net[2].bias, residual=residual)
 
 
+# lazily built, process-wide, NOT locked: the package drives one GPU from one Python thread per process
+# (one process per GPU); guard with a mutex before calling these paths from several threads
 _SEG_CACHE = {}
 
 
@@ -172,10 +174,28 @@ def _seg_table(kind, B, num_views, device):
     return _SEG_CACHE[key]
 
 
+_QK_CACHE = {}
+
+
+def _qk_weight(attn):
+    """to_q and to_k stacked (2C, C): ONE GEMM for both projections of a self-attention (the 768 ..
+    3072-row projections fill 60-120 of 256 CUs each; Q and K are strided views of the result,
+    the attention kernel takes row strides).  Rebuilt when either parameter is written."""
+    wq, wk = attn.to_q.weight, attn.to_k.weight
+    key = id(attn)
+    tag = (wq._version, wk._version, wq.data_ptr(), wk.data_ptr())
+    hit = _QK_CACHE.get(key)
+    if hit is None or hit[0] != tag:
+        hit = (tag, torch.cat([wq.detach(), wk.detach()], 0).contiguous())
+        _QK_CACHE[key] = hit
+    return hit[1]
+
+
 def _self_attention(attn, x, residual, table):
     """x (B,N,C) normalised input; returns to_out(attention) + residual."""
-    q = ops.linear_f16(x, attn.to_q.weight)
-    k = ops.linear_f16(x, attn.to_k.weight)
+    c = attn.to_q.weight.shape[0]
+    qk = ops.linear_f16(x, _qk_weight(attn))
+    q, k = qk[..., :c], qk[..., c:]
     vt = ops.linear_f16(x, attn.to_v.weight, transposed_tokens=x.shape[1])   # (B, C, N): V^T per head
     o = ops.mv_attention(q, k, vt, table, attn.heads, x.shape[1])
     return ops.linear_f16(o, attn.to_out[0].weight, attn.to_out[0].bias, residual=residual)

@@ -256,6 +256,8 @@ def ray_march(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step):
     return ray_indices, t_starts, t_ends, offsets, counts
 
 
+# lazily built, process-wide, NOT locked: the package drives one GPU from one Python thread per process
+# (one process per GPU); guard with a mutex before calling these paths from several threads
 _MARCH_SCRATCH = {}
 
 
