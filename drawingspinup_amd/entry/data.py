@@ -127,8 +127,24 @@ def write_mv_outputs(out_dir, normals, colors, single_image, res=(1024, 1024), u
 
 
 # ------------------------------------------------------------------ ortho dataset (recon.py)
-def load_mv_prediction(mv_dir, device, pose_dir=None, size=(1024, 1024)):
-    """instant_nsr/datasets/ortho.py:54-97 -> drawingspinup_amd.nsr.system.OrthoData."""
+# instant_nsr/datasets/ortho.py:113-127: drawings reconstructed from a subset of the six views
+TWO_VIEW_UIDS = ("025dc91b146d4f57bd114e07165ff7bd", "b03fed9c34f64114a62c7a963fa804e5",
+                 "e91d8a6d3aa444f9b10f3a14a6e0a287")
+FOUR_VIEW_UIDS = ("b32e37e2f0354f569ea9265d753891f7", "b718c3fb937a416b9fe49ff984a1504e",
+                  "d12bed5708ed42f2b615b7911c0291fa", "d2f443e21595431f9f2cd580f291f51b")
+
+
+def view_types_for(uid):
+    if uid in TWO_VIEW_UIDS:
+        return ["front", "back"]
+    if uid in FOUR_VIEW_UIDS:
+        return ["front", "front_right", "back", "front_left"]
+    return list(VIEWS)
+
+
+def load_mv_prediction(mv_dir, device, pose_dir=None, size=(1024, 1024), uid=None):
+    """instant_nsr/datasets/ortho.py:54-97,113-127 -> drawingspinup_amd.nsr.system.OrthoData
+    (the view subset of the uid's special cases; all view weights 1)."""
     from ..nsr import system as S
     imgs, masks, normals, poses = [], [], [], []
 
@@ -138,7 +154,7 @@ def load_mv_prediction(mv_dir, device, pose_dir=None, size=(1024, 1024)):
         return S.ideal_w2c(v)
 
     front_c2w = S.inv_rt(S.rt_opengl2opencv(pose("front")))[:3, :3]
-    for v in VIEWS:
+    for v in view_types_for(uid):
         normal = np.array(Image.open(os.path.join(mv_dir, "normal", f"{v}.png")).convert("RGB"), np.float32)
         normal = normal / 255.0 * 2 - 1
         mask = np.array(Image.open(os.path.join(mv_dir, "mask", f"{v}.png")).convert("L"))

@@ -30,7 +30,7 @@ def main(argv=None):
     dev = torch.device("cuda", local)
     uids = json.load(open(args.uid_list_file)) if args.all else [args.uid]
     for uid in ddist.shard(uids, rank, world):
-        ds = D.load_mv_prediction(os.path.join(args.data_root, uid, "mv"), dev, args.pose_dir)
+        ds = D.load_mv_prediction(os.path.join(args.data_root, uid, "mv"), dev, args.pose_dir, uid=uid)
         system = OrthoNeuSSystem(device=dev, seed=args.seed)
         system.fit(ds, max_steps=args.max_steps, log_every=500)
         front = None
