@@ -99,17 +99,33 @@ __device__ __forceinline__ void forward_half(const float* lds, const float* in, 
       H0[T][r] = fmaxf(H0[T][r], 0.0f);
       H1[T][r] = 0.0f;
     }
-  // layer 1: H1^T = W1 . H0^T ; register (T, r) of H0 is the k-pair (feat_of(T,r,0), +4)
+  // layer 1: H1^T = W1 . H0^T ; register (T, r) of H0 is the k-pair (feat_of(T,r,0), +4).
+  // The weight operands of the NEXT four k-pairs are requested from LDS before the eight MFMAs of
+  // the current four are issued (written per k-pair, the compiler put every `ds_read` right in
+  // front of its MFMA with `s_waitcnt lgkmcnt(0)` in between: one MFMA per LDS round trip).
+  {
+    float a[2][8];
+    auto load = [&](int s_, float* dst) {
+      const int T = s_ >> 2, rq = s_ & 3;
 #pragma unroll
-  for (int T = 0; T < 2; ++T)
+      for (int j = 0; j < 4; ++j) {
+        const int k = feat_of(T, 4 * rq + j, h);
+        dst[2 * j + 0] = lds[L_W1 + l31 * W1_ROW + k];
+        dst[2 * j + 1] = lds[L_W1 + (32 + l31) * W1_ROW + k];
+      }
+    };
+    load(0, a[0]);
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int k = feat_of(T, r, h);
+    for (int s_ = 0; s_ < 8; ++s_) {
+      if (s_ + 1 < 8) load(s_ + 1, a[(s_ + 1) & 1]);
 #pragma unroll
-      for (int To = 0; To < 2; ++To)
-        H1[To] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[L_W1 + (32 * To + l31) * W1_ROW + k],
-                                                      H0[T][r], H1[To], 0, 0, 0);
+      for (int j = 0; j < 4; ++j) {
+        const float b = H0[s_ >> 2][4 * (s_ & 3) + j];
+        H1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_ & 1][2 * j + 0], b, H1[0], 0, 0, 0);
+        H1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_ & 1][2 * j + 1], b, H1[1], 0, 0, 0);
+      }
     }
+  }
   {
     const float one = h == 0 ? 1.0f : 0.0f;
 #pragma unroll
@@ -313,16 +329,29 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
       for (int T = 0; T < 2; ++T)
 #pragma unroll
         for (int r = 0; r < 16; ++r) D0[T][r] = 0.0f;
+      {   // weight operands one batch of four k-pairs ahead of their MFMAs (see forward_half)
+        float a[2][8];
+        auto load = [&](int s_, float* dst) {
+          const int T = s_ >> 2, rq = s_ & 3;
 #pragma unroll
-      for (int T = 0; T < 2; ++T)
+          for (int j = 0; j < 4; ++j) {
+            const int k = feat_of(T, 4 * rq + j, h);
+            dst[2 * j + 0] = lds[L_W1 + k * W1_ROW + l31];
+            dst[2 * j + 1] = lds[L_W1 + k * W1_ROW + 32 + l31];
+          }
+        };
+        load(0, a[0]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int k = feat_of(T, r, h);
+        for (int s_ = 0; s_ < 8; ++s_) {
+          if (s_ + 1 < 8) load(s_ + 1, a[(s_ + 1) & 1]);
 #pragma unroll
-          for (int To = 0; To < 2; ++To)
-            D0[To] = __builtin_amdgcn_mfma_f32_32x32x2f32(lds[L_W1 + k * W1_ROW + 32 * To + l31],
-                                                          D1[T][r], D0[To], 0, 0, 0);
+          for (int j = 0; j < 4; ++j) {
+            const float b = D1[s_ >> 2][4 * (s_ & 3) + j];
+            D0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_ & 1][2 * j + 0], b, D0[0], 0, 0, 0);
+            D0[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_ & 1][2 * j + 1], b, D0[1], 0, 0, 0);
+          }
         }
+      }
 #pragma unroll
       for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -354,13 +383,27 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
       f32x16 din;
 #pragma unroll
       for (int r = 0; r < 16; ++r) din[r] = 0.0f;
+      {   // same batching for the 32 weight operands of dIn
+        float a[2][8];
+        const int lc = l31 < TIN ? l31 : 0;
+        auto load = [&](int s_, float* dst) {
 #pragma unroll
-      for (int T = 0; T < 2; ++T)
+          for (int j = 0; j < 8; ++j) {
+            const int T = s_ >> 1, r = 8 * (s_ & 1) + j;
+            const float w = lds[L_W0 + feat_of(T, r, h) * W0_ROW + lc];
+            dst[j] = l31 < TIN ? w : 0.0f;
+          }
+        };
+        load(0, a[0]);
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const float wa = l31 < TIN ? lds[L_W0 + feat_of(T, r, h) * W0_ROW + l31] : 0.0f;
-          din = __builtin_amdgcn_mfma_f32_32x32x2f32(wa, D0[T][r], din, 0, 0, 0);
+        for (int s_ = 0; s_ < 4; ++s_) {
+          if (s_ + 1 < 4) load(s_ + 1, a[(s_ + 1) & 1]);
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+            din = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s_ & 1][j], D0[s_ >> 1][8 * (s_ & 1) + j],
+                                                      din, 0, 0, 0);
         }
+      }
       const int64_t si = wave_first + a * 32 + l31;              // the sample of column l31
       if (si < r1) {
 #pragma unroll
