@@ -645,13 +645,42 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
         __builtin_amdgcn_wave_barrier();
         DSU_PROF(5)   // input / dOut staging
         // gW0[feat][k'] += sum_points dPre[point][feat] * In'[point][k']
-        if (!DSU_ABL(2))
+        if (!DSU_ABL(2) && !SPLIT) {
+          // the fused form (153 KB of LDS, scatter code resident) has no registers to spare for the
+          // read-ahead below (NL = 12 would spill)
 #pragma unroll 4
-        for (int t = 0; t < 16; ++t) {
-          const int pr = 2 * t + h;
-          const float b = sin_[pr * SIN_ROW + l31];
-          gw0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + l31], b, gw0[0], 0, 0, 0);
-          gw0[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + 32 + l31], b, gw0[1], 0, 0, 0);
+          for (int t = 0; t < 16; ++t) {
+            const int pr = 2 * t + h;
+            const float b = sin_[pr * SIN_ROW + l31];
+            gw0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + l31], b, gw0[0], 0, 0, 0);
+            gw0[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + 32 + l31], b, gw0[1], 0, 0, 0);
+          }
+        }
+        if (!DSU_ABL(2) && SPLIT) {
+          // operands of the next four k-pairs are requested from LDS before the eight MFMAs of the
+          // current four are issued (with `#pragma unroll 4` the reads sat right in front of their
+          // MFMAs behind `s_waitcnt lgkmcnt(0)`; the same change took texture_bwd from 231 to 169 us)
+          float q[2][12];
+          auto ld = [&](int tb, float* d) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const int pr = 2 * (4 * tb + u) + h;
+              d[3 * u + 0] = sd[pr * SD_ROW + l31];
+              d[3 * u + 1] = sd[pr * SD_ROW + 32 + l31];
+              d[3 * u + 2] = sin_[pr * SIN_ROW + l31];
+            }
+          };
+          ld(0, q[0]);
+#pragma unroll
+          for (int tb = 0; tb < 4; ++tb) {
+            if (tb + 1 < 4) ld(tb + 1, q[(tb + 1) & 1]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              const float* d = q[tb & 1] + 3 * u;
+              gw0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[0], d[2], gw0[0], 0, 0, 0);
+              gw0[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[1], d[2], gw0[1], 0, 0, 0);
+            }
+          }
         }
         __builtin_amdgcn_wave_barrier();
         DSU_PROF(6)   // gW0 GEMM
@@ -664,13 +693,37 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
               *reinterpret_cast<float4*>(&sd[l31 * SD_ROW + 32 * T + 8 * qd + 4 * h]) =
                   make_float4(Hh[T][4 * qd], Hh[T][4 * qd + 1], Hh[T][4 * qd + 2], Hh[T][4 * qd + 3]);
           __builtin_amdgcn_wave_barrier();
-          if (!DSU_ABL(2))
+          if (!DSU_ABL(2) && !SPLIT) {
 #pragma unroll 4
-          for (int t = 0; t < 16; ++t) {
-            const int pr = 2 * t + h;
-            const float b = sdo[pr * SIN_ROW + l31];
-            gw1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + l31], b, gw1[0], 0, 0, 0);
-            gw1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + 32 + l31], b, gw1[1], 0, 0, 0);
+            for (int t = 0; t < 16; ++t) {
+              const int pr = 2 * t + h;
+              const float b = sdo[pr * SIN_ROW + l31];
+              gw1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + l31], b, gw1[0], 0, 0, 0);
+              gw1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sd[pr * SD_ROW + 32 + l31], b, gw1[1], 0, 0, 0);
+            }
+          }
+          if (!DSU_ABL(2) && SPLIT) {
+            float q[2][12];
+            auto ld = [&](int tb, float* d) {
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const int pr = 2 * (4 * tb + u) + h;
+                d[3 * u + 0] = sd[pr * SD_ROW + l31];
+                d[3 * u + 1] = sd[pr * SD_ROW + 32 + l31];
+                d[3 * u + 2] = sdo[pr * SIN_ROW + l31];
+              }
+            };
+            ld(0, q[0]);
+#pragma unroll
+            for (int tb = 0; tb < 4; ++tb) {
+              if (tb + 1 < 4) ld(tb + 1, q[(tb + 1) & 1]);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) {
+                const float* d = q[tb & 1] + 3 * u;
+                gw1[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[0], d[2], gw1[0], 0, 0, 0);
+                gw1[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[1], d[2], gw1[1], 0, 0, 0);
+              }
+            }
           }
         } else {
           // the six offset evaluations only feed output 0: gW1[feat][0] += H[point][feat] * d0

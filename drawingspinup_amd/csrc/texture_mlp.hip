@@ -294,12 +294,30 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
       if (h == a)
         *reinterpret_cast<float4*>(&sDo[l31 * SDO_ROW]) = make_float4(dz[0], dz[1], dz[2], 0.0f);
       __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-      for (int t = 0; t < 16; ++t) {
-        const int pr = 2 * t + h;
-        const float b = l31 < SDO_ROW ? sDo[pr * SDO_ROW + l31] : 0.0f;
-        gw2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sH[pr * SD_ROW + l31], b, gw2[0], 0, 0, 0);
-        gw2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sH[pr * SD_ROW + 32 + l31], b, gw2[1], 0, 0, 0);
+      {   // operands of the next four k-pairs in flight while the current eight MFMAs run
+        float q[2][12];
+        const int lo = l31 < SDO_ROW ? l31 : 0;
+        auto ld = [&](int tb, float* d) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int pr = 2 * (4 * tb + u) + h;
+            const float b = sDo[pr * SDO_ROW + lo];
+            d[3 * u + 0] = sH[pr * SD_ROW + l31];
+            d[3 * u + 1] = sH[pr * SD_ROW + 32 + l31];
+            d[3 * u + 2] = l31 < SDO_ROW ? b : 0.0f;
+          }
+        };
+        ld(0, q[0]);
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+          if (tb + 1 < 4) ld(tb + 1, q[(tb + 1) & 1]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float* d = q[tb & 1] + 3 * u;
+            gw2[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[0], d[2], gw2[0], 0, 0, 0);
+            gw2[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[1], d[2], gw2[1], 0, 0, 0);
+          }
+        }
       }
       // ---- gW1[i][j] += sum_samples dPre1[sample][i] * H0[sample][j]
       __builtin_amdgcn_wave_barrier();
@@ -313,15 +331,31 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
               make_float4(H0[T][4 * qd], H0[T][4 * qd + 1], H0[T][4 * qd + 2], H0[T][4 * qd + 3]);
         }
       __builtin_amdgcn_wave_barrier();
-#pragma unroll 2
-      for (int t = 0; t < 16; ++t) {
-        const int pr = 2 * t + h;
-        const float a0 = sP[pr * SD_ROW + l31], a1 = sP[pr * SD_ROW + 32 + l31];
-        const float b0 = sH[pr * SD_ROW + l31], b1 = sH[pr * SD_ROW + 32 + l31];
-        gw1[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, gw1[0][0], 0, 0, 0);
-        gw1[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, gw1[0][1], 0, 0, 0);
-        gw1[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, gw1[1][0], 0, 0, 0);
-        gw1[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, gw1[1][1], 0, 0, 0);
+      {
+        float q[2][8];
+        auto ld = [&](int tb, float* d) {
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int pr = 2 * (2 * tb + u) + h;
+            d[4 * u + 0] = sP[pr * SD_ROW + l31];
+            d[4 * u + 1] = sP[pr * SD_ROW + 32 + l31];
+            d[4 * u + 2] = sH[pr * SD_ROW + l31];
+            d[4 * u + 3] = sH[pr * SD_ROW + 32 + l31];
+          }
+        };
+        ld(0, q[0]);
+#pragma unroll
+        for (int tb = 0; tb < 8; ++tb) {
+          if (tb + 1 < 8) ld(tb + 1, q[(tb + 1) & 1]);
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const float* d = q[tb & 1] + 4 * u;
+            gw1[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[0], d[2], gw1[0][0], 0, 0, 0);
+            gw1[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[0], d[3], gw1[0][1], 0, 0, 0);
+            gw1[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[1], d[2], gw1[1][0], 0, 0, 0);
+            gw1[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[1], d[3], gw1[1][1], 0, 0, 0);
+          }
+        }
       }
       // ---- dH0^T = W1^T . dPre1^T, then dPre0 = dH0 * relu'(H0)
       f32x16 D0[2];
@@ -372,12 +406,30 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
         sIn[l31 * SIN_ROW + 16] = 1.0f;
       }
       __builtin_amdgcn_wave_barrier();
-#pragma unroll 4
-      for (int t = 0; t < 16; ++t) {
-        const int pr = 2 * t + h;
-        const float b = l31 <= TIN ? sIn[pr * SIN_ROW + l31] : 0.0f;
-        gw0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(sP[pr * SD_ROW + l31], b, gw0[0], 0, 0, 0);
-        gw0[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(sP[pr * SD_ROW + 32 + l31], b, gw0[1], 0, 0, 0);
+      {
+        float q[2][12];
+        const int li = l31 <= TIN ? l31 : 0;
+        auto ld = [&](int tb, float* d) {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int pr = 2 * (4 * tb + u) + h;
+            const float b = sIn[pr * SIN_ROW + li];
+            d[3 * u + 0] = sP[pr * SD_ROW + l31];
+            d[3 * u + 1] = sP[pr * SD_ROW + 32 + l31];
+            d[3 * u + 2] = l31 <= TIN ? b : 0.0f;
+          }
+        };
+        ld(0, q[0]);
+#pragma unroll
+        for (int tb = 0; tb < 4; ++tb) {
+          if (tb + 1 < 4) ld(tb + 1, q[(tb + 1) & 1]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float* d = q[tb & 1] + 3 * u;
+            gw0[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[0], d[2], gw0[0], 0, 0, 0);
+            gw0[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[1], d[2], gw0[1], 0, 0, 0);
+          }
+        }
       }
       // ---- dIn^T = W0^T . dPre0^T : row k = (r&3) + 8(r>>2) + 4h of the sample in column l31
       f32x16 din;
