@@ -123,3 +123,43 @@ def test_product_never_imports_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M):
                     bad.append(os.path.join(dp, f))
     assert not bad, bad
+
+
+def test_round2_entry_points_validate_before_launching():
+    """Host-side planning and argument checks of the round-2 entry points (no GPU here: every call
+    must return before a launch)."""
+    from drawingspinup_amd import _lib
+    lib = _lib.lib()
+    # Morton sort: counters (8^bits) + block sums + keys / ranks
+    assert lib.dsu_spatial_sort_workspace_bytes(1000, 6) == (262144 + 256 + 2 * 1000) * 4
+    assert lib.dsu_spatial_sort_workspace_bytes(0, 4) == (4096 + 4) * 4
+    assert lib.dsu_spatial_sort_workspace_bytes(10, 3) == -1 and lib.dsu_spatial_sort_workspace_bytes(10, 8) == -1
+    assert lib.dsu_spatial_sort(None, 5, 1.0, 6, None, None, None, 0, None) == -1
+    assert lib.dsu_spatial_sort(None, 0, 1.0, 6, None, None, None, 0, None) == 0          # empty: nothing to do
+    assert lib.dsu_spatial_sort_dev(None, 5, None, 0, 1.0, 6, None, None, None, 0, None) == -1
+    assert lib.dsu_points_tail(None, 0, None, None, None, 0, 0.01, None) == -1
+    # optimizers
+    assert lib.dsu_table_adamw(None, None, None, None, None, 6, 1e-3, 0.9, 0.99, 1e-15, 0.01, 0.1, 0.1, None) == -1  # n % 4
+    assert lib.dsu_table_adamw(None, None, None, None, None, 0, 1e-3, 0.9, 0.99, 1e-15, 0.01, 0.1, 0.1, None) == 0
+    assert lib.dsu_table_decay(None, None, 8, 0.5, None) == -1
+    assert lib.dsu_adamw_multi(None, 3, 0.9, 0.99, 1e-15, 0.01, None) == -1
+    assert lib.dsu_adamw_multi(None, 0, 0.9, 0.99, 1e-15, 0.01, None) == 0
+    assert lib.dsu_adamw_multi(None, _lib.ADAMW_MAX_TENSORS + 1, 0.9, 0.99, 1e-15, 0.01, None) == -1
+    # export smoothing
+    assert lib.dsu_smooth_energy_partials() == 1024
+    assert lib.dsu_smooth_iterate(None, 5, None, 0.5, 10, None, None, None) == -1
+    assert lib.dsu_smooth_iterate(None, 0, None, 0.5, 10, None, None, None) == 0
+    # TELEA: host function, runs here
+    import numpy as np
+    img = np.full((5, 6, 3), 9, np.uint8)
+    out = np.zeros_like(img)
+    m = np.zeros((5, 6), np.uint8)
+    m[2, 3] = 1
+    P = ctypes.c_void_p
+    assert lib.dsu_inpaint_telea_u8c3(P(img.ctypes.data), P(m.ctypes.data), 5, 6, 3, P(out.ctypes.data)) == 0
+    # a one-pixel hole in a constant image: Ia / s + 0.5 = 9.5, rounded to even = 10 (OpenCV's
+    # formula adds 0.5 AND rounds); everything else untouched
+    assert out[2, 3].tolist() == [10, 10, 10]
+    out[2, 3] = 9
+    assert (out == 9).all()
+    assert lib.dsu_inpaint_telea_u8c3(P(img.ctypes.data), P(m.ctypes.data), 2, 6, 3, P(out.ctypes.data)) == -3
