@@ -78,3 +78,102 @@ def test_sharding():
     parts = [dist.shard(uids, r, 8) for r in range(8)]
     assert sorted(sum(parts, [])) == uids and all(len(p) == 3 for p in parts)
     assert dist.shard(uids, 0, 1) == uids
+
+
+# ---------------------------------------------------------------------------------------------
+# Host bookkeeping of the fused optimizers (the kernels are stood in for by torch CPU code — test
+# infrastructure only; the GPU tests run the real kernels against torch.optim.AdamW)
+# ---------------------------------------------------------------------------------------------
+def _cpu_adamw(p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s):
+    import torch
+    P, G, M, V = p[:n], g[:n], m[:n], v[:n]
+    P.mul_(1 - lr * wd)
+    M.lerp_(G, 1 - b1)
+    V.mul_(b2).addcmul_(G, G, value=1 - b2)
+    P.addcdiv_(M, V.sqrt() / bc2s + eps, value=-lr / bc1)
+    G.zero_()
+
+
+def test_table_adamw_lazy_decay_bookkeeping(monkeypatch):
+    """TableAdamW: levels the schedule still masks only accumulate their decay factor on the host;
+    it is applied when a level is switched on and in finalize().  Against torch.optim.AdamW on the
+    whole tensor (zero gradients on the masked levels), on the CPU with stub kernels."""
+    import torch
+    from drawingspinup_amd import ops
+    from drawingspinup_amd.nsr import system as S
+    from drawingspinup_amd.nsr.encoding import Encoding
+
+    def table_adamw(p, g, m, v, img, n, lr, b1, b2, eps, wd, bc1, bc2s):
+        _cpu_adamw(p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2s)
+        img[:n] = p[:n].half()
+
+    def table_decay(p, img, start, n, factor):
+        p[start:start + n].mul_(factor)
+        img[start:start + n] = p[start:start + n].half()
+
+    monkeypatch.setattr(ops, "table_adamw", table_adamw)
+    monkeypatch.setattr(ops, "table_decay", table_decay)
+    enc = Encoding(3, {"otype": "HashGrid", "n_levels": 10, "n_features_per_level": 2,
+                       "log2_hashmap_size": 12, "base_resolution": 4,
+                       "per_level_scale": 1.3195079107728942}).train()
+    ref = enc.params.detach().clone().double().requires_grad_(True)
+    topt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.99), eps=1e-15)
+    opt = S.TableAdamW(enc, 1e-3, (0.9, 0.99), 1e-15)
+    off = opt.offsets
+    g = torch.Generator().manual_seed(0)
+    for it, (lr, act) in enumerate(zip([1e-3, 9e-4, 8e-4, 7e-4, 6e-4, 5e-4], [4, 4, 6, 6, 6, 9])):
+        grad = torch.zeros(ref.shape[0])
+        grad[:off[act]] = torch.randn(off[act], generator=g) * 1e-3
+        ref.grad = grad.double()
+        topt.param_groups[0]["lr"] = lr
+        topt.step()
+        opt.grad.copy_(grad)
+        opt.step(act, lr)
+        assert opt.active == act and not opt.grad.any()
+        n = off[act]
+        torch.testing.assert_close(enc.params.detach()[:n].double(), ref.detach()[:n], rtol=1e-5, atol=1e-8)
+        if act < 10:                                          # masked levels untouched so far
+            assert opt.pending < 1.0
+    opt.finalize()
+    assert opt.pending == 1.0 and opt.active == 9
+    torch.testing.assert_close(enc.params.detach().double(), ref.detach(), rtol=1e-5, atol=1e-8)
+    assert torch.equal(enc.table_f16(), enc.params.detach().half())      # image kept in step
+    enc.invalidate()                                                     # e.g. a checkpoint load
+    assert not enc._shadow_locked
+
+
+def test_small_adamw_entries_and_step_counts(monkeypatch):
+    import math
+    import torch
+    from drawingspinup_amd import ops
+    from drawingspinup_amd.nsr import system as S
+    seen = []
+
+    def adamw_multi(entries, b1, b2, eps, wd):
+        seen.append(len(entries))
+        for p, g, m, v, lr, bc1, bc2s in entries:
+            _cpu_adamw(p.view(-1), g.clone().view(-1), m.view(-1), v.view(-1), p.numel(), lr, b1, b2, eps, wd,
+                       bc1, bc2s)
+
+    monkeypatch.setattr(ops, "adamw_multi", adamw_multi)
+    ps = [torch.nn.Parameter(torch.randn(4, 3)), torch.nn.Parameter(torch.randn(5)),
+          torch.nn.Parameter(torch.randn(1))]
+    rs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    mk = lambda q: torch.optim.AdamW([{"params": q[:2], "lr": 1e-3}, {"params": q[2:], "lr": 1e-2}],
+                                     lr=1e-2, betas=(0.9, 0.99), eps=1e-15)
+    holder, topt = mk(ps), mk(rs)
+    sopt = S.SmallAdamW(holder, (0.9, 0.99), 1e-15)
+    for it in range(4):
+        for k, (p, r) in enumerate(zip(ps, rs)):
+            if k == 1 and it == 1:
+                p.grad = r.grad = None                        # skipped, step count not advanced
+                continue
+            gr = torch.randn(p.shape)
+            p.grad, r.grad = gr.clone(), gr.clone()
+        topt.step()
+        sopt.step()
+        for p, r in zip(ps, rs):
+            torch.testing.assert_close(p.detach(), r.detach(), rtol=1e-5, atol=1e-8)
+    assert seen == [3, 2, 3, 3]
+    assert [sopt.state[id(p)][2] for p in ps] == [4, 3, 4]
+    assert math.isclose(topt.state[rs[1]]["step"].item(), 3)
