@@ -110,3 +110,36 @@ def test_prepare_input_and_masks_follow_predict_py():
     assert img8.shape == (32, 32, 3) and img8.dtype == np.uint8
     assert contour[10:12].min() == 255 and contour[20].max() == 0 and contour[:10].max() == 0
     np.testing.assert_array_equal(mask, np.maximum(contour, 255 - alpha))
+
+
+def test_remove_contour_end_to_end_on_the_host():
+    """predict.py:47-66 for one drawing (prepare -> generator -> masks -> TELEA -> RGBA) with a
+    model whose contour map is known: contour strokes are repainted from the character's own
+    pixels, known character pixels and the alpha channel are untouched."""
+    from drawingspinup_amd.contour.predict import prepare_input, remove_contour
+    size = 48
+    yy, xx = np.mgrid[0:size, 0:size]
+    inside = ((yy - 24) / 18.0) ** 2 + ((xx - 24) / 14.0) ** 2 < 1.0
+    stroke = inside & (np.abs(yy - 24) < 1)
+    rgba = np.zeros((size, size, 4), np.uint8)
+    rgba[inside] = (180, 90, 40, 255)
+    rgba[stroke, :3] = 0                                  # a dark contour line across the body
+
+    class Known(torch.nn.Module):                         # probability 0.9 on the stroke, 0.05 elsewhere
+        def __init__(self):
+            super().__init__()
+            self.p = torch.nn.Parameter(torch.zeros(1))
+
+        def forward(self, x):
+            m = torch.from_numpy(stroke).float()
+            return (0.05 + 0.85 * m)[None, None] + 0 * self.p
+
+    out = remove_contour(Known(), rgba, size=size)
+    assert out.shape == (size, size, 4) and out.dtype == np.uint8
+    x = prepare_input(rgba, size)[0].permute(1, 2, 0).numpy()
+    alpha = (x[:, :, 3] * 255).astype(np.uint8)
+    assert np.array_equal(out[:, :, 3], alpha)
+    keep = inside & ~stroke
+    assert np.array_equal(out[keep][:, :3], (x[:, :, :3] * 255).astype(np.uint8)[keep])
+    body = out[stroke & (xx > 14) & (xx < 34)][:, :3].astype(int)
+    assert np.abs(body - np.array([180, 90, 40])).max() <= 3          # the line is gone
