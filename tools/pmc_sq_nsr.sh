@@ -14,7 +14,7 @@ pass_a="SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ
 pass_b="SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS"
 i=0
 for counters in "$pass_a" "$pass_b"; do
-  i=$((i + 1)); w=/tmp/sq_$tag_$i; rm -rf $w
+  i=$((i + 1)); w=/tmp/sq_${tag}_$i; rm -rf $w
   timeout 300 rocprofv3 --pmc $counters --kernel-trace --output-format csv -d $w -o sq -- \
       python tools/nsr_stage_ab.py $steps > $out/sq_pass$i.log 2>&1
   f=$(find $w -name '*counter_collection.csv' | head -1)
