@@ -585,6 +585,11 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
         f32x16 din;
 #pragma unroll
         for (int r = 0; r < 16; ++r) din[r] = 0.0f;
+#ifdef DSU_DIN_2ACC
+        f32x16 din_b;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) din_b[r] = 0.0f;
+#endif
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
@@ -622,6 +627,18 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
             for (int r = 0; r < 16; ++r)
               din = __builtin_amdgcn_mfma_f32_32x32x2f32(w0t[T][r], dpre[r], din, 0, 0, 0);
           }
+#elif defined(DSU_DIN_2ACC)
+          // Staged variant (not measured yet): even / odd hidden units accumulate into two
+          // accumulators, so that the VALU work sits between MFMAs on DIFFERENT accumulators
+          // (~6 cycles per issue slot instead of the +43 cliff); the two partial sums are added
+          // after the second tile (summation order differs from the default: not bit-identical).
+          if (!DSU_ABL(64))
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            dpre[r] *= 1.0f - __builtin_amdgcn_exp2f(Hh[T][r] * -144.26950408889634f);
+            if (r & 1) din_b = __builtin_amdgcn_mfma_f32_32x32x2f32(w0t[T][r], dpre[r], din_b, 0, 0, 0);
+            else din = __builtin_amdgcn_mfma_f32_32x32x2f32(w0t[T][r], dpre[r], din, 0, 0, 0);
+          }
 #else
           if (!DSU_ABL(64))
 #pragma unroll
@@ -637,6 +654,10 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
             *reinterpret_cast<float4*>(&sd[l31 * SD_ROW + 32 * T + 8 * qd + 4 * h]) =
                 make_float4(dpre[4 * qd], dpre[4 * qd + 1], dpre[4 * qd + 2], dpre[4 * qd + 3]);
         }
+#ifdef DSU_DIN_2ACC
+#pragma unroll
+        for (int r = 0; r < 16; ++r) din[r] += din_b[r];
+#endif
         DSU_PROF(4)   // dPre, sigmoid, dIn MFMAs, dPre staging
         if (h == half) {
 #pragma unroll

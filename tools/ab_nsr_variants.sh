@@ -6,14 +6,17 @@
 # Staged for the next visit:
 #   dinbatch  -DDSU_DIN_BATCH   k1: the 16 derivative factors of a hidden tile first, then its 16 dIn
 #             MFMAs back to back (no VALU issue slots between MFMAs on the one accumulator)
+#   din2acc   -DDSU_DIN_2ACC    k1: even / odd hidden units into two dIn accumulators (VALU between MFMAs
+#             on different accumulators); summation order differs: check the gradient tests
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd "$R"
-VARIANTS="default dinbatch"
+VARIANTS="default dinbatch din2acc"
 case "${1:-}" in
   build)
     python -m drawingspinup_amd.build
     python -m drawingspinup_amd.build --variant dinbatch -DDSU_DIN_BATCH
+    python -m drawingspinup_amd.build --variant din2acc -DDSU_DIN_2ACC
     ;;
   run)
     mkdir -p gpurun_out/ab
