@@ -179,6 +179,21 @@ __device__ __forceinline__ void layer0_mfma_half(const Frags<NL>& f, const float
     swap_halves(in[2 * t], in[2 * t + 1], b0, b1);
     b[t] = half ? b1 : b0;
   }
+#ifdef DSU_L0_INTERLEAVED
+  // A/B variant: the two hidden tiles alternate per k-pair (the form before round 2's tile-major
+  // order; MFMAs on different accumulators back to back, all Softplus work afterwards)
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[T][r] = 0.0f;
+#pragma unroll
+  for (int t = 0; t < MC<NL>::KP; ++t) {
+    if (t < NL && (uint32_t)t >= active) continue;     // masked level: both inputs are zero
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+      acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w0[T][t], b[t], acc[T], 0, 0, 0);
+  }
+#else
   // tile by tile: the Softplus of tile 0 (VALU + transcendental unit) runs while the matrix pipe
   // works through the k-pairs of tile 1 (both tiles interleaved finished together and the 64
   // Softplus evaluations started only then: 1.5 k + 1.6 k clocks in sequence per half)
@@ -192,6 +207,7 @@ __device__ __forceinline__ void layer0_mfma_half(const Frags<NL>& f, const float
       acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.w0[T][t], b[t], acc[T], 0, 0, 0);
     }
   }
+#endif
   if (DSU_ABL(32)) return;
 #pragma unroll
   for (int T = 0; T < 2; ++T)
