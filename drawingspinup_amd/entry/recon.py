@@ -25,6 +25,11 @@ def main(argv=None):
     ap.add_argument("--pose_dir", default=None, help=".../instant_nsr/datasets/fixed_poses")
     ap.add_argument("--max_steps", type=int, default=3000)
     ap.add_argument("--seed", type=int, default=123456)          # recon.py:30
+    # export.smoothing / export.shearing of the reference's config (mesh_utils.py:42-58); off by
+    # default here: they are host-side steps on the full-resolution mesh (the reference decimates to
+    # 50 000 faces first, which needs trimesh); smoothing adds the reference's `_s` to the save name
+    ap.add_argument("--smoothing", action="store_true")
+    ap.add_argument("--shearing", action="store_true")
     args = ap.parse_args(argv)
     rank, world, local = ddist.init()
     dev = torch.device("cuda", local)
@@ -43,8 +48,9 @@ def main(argv=None):
         out = os.path.join(args.data_root, uid, "mesh")
         os.makedirs(out, exist_ok=True)
         from ..nsr.mesh import save_obj
-        save_obj(os.path.join(out, system.export_name(front is not None) + ".obj"), mesh["verts"],
-                 mesh["faces"], mesh["vert_colors"])
+        name = system.export_name(front is not None) + ("_s" if args.smoothing else "")   # neus_ortho.py:190-191
+        save_obj(os.path.join(out, name + ".obj"), mesh["verts"], mesh["faces"], mesh["vert_colors"],
+                 smoothing=args.smoothing, shearing=args.shearing)
         torch.save(system.model.state_dict(), os.path.join(out, f"it{system.global_step}.ckpt"))
         print(uid, flush=True)
 

@@ -524,20 +524,88 @@ def vertex_colors(model, verts, chunk=2097152):
     return torch.cat(out, 0) if out else torch.zeros((0, 3), device=verts.device)
 
 
-def save_obj(path, verts, faces, colors=None, ortho_scale=1.35):
-    """save_mesh (mesh_utils.py:25-73) with its geometry switches off (thinning, smoothing, colour
-    back-projection, shearing are CPU steps outside this path): halve, swap to the front-facing
-    convention (x right, y up, z front), apply ortho_scale, write an OBJ with per-vertex colours
-    (trimesh's OBJ export of `vertex_colors`: `v x y z r g b`, faces 1-based)."""
+# ------------------------------------------------------------------------------------------------
+# save_mesh's host-side geometry steps that need no ray caster (mesh_utils.py:25-93)
+# ------------------------------------------------------------------------------------------------
+def laplacian_smooth_implicit(verts, faces, lamb=2.0, iterations=5, volume_constraint=True):
+    """trimesh.smoothing.filter_laplacian(mesh, lamb, iterations, implicit_time_integration=True)
+    as save_mesh calls it (mesh_utils.py:44-45), restated from trimesh's published algorithm
+    (trimesh is absent here: unpinned): umbrella operator L with equal weights (row i = 1/deg(i) on
+    the neighbours of i), every iteration solves (I + lamb (I - L)) V' = V (sparse LU, factorised
+    once), then rescales V' so that the enclosed volume stays what it was before the filter.
+    verts (N,3) float64, faces (M,3) int -> (N,3) float64."""
+    import scipy.sparse as sp
+    from scipy.sparse.linalg import splu
+    v = np.array(verts, np.float64)
+    f = np.asarray(faces, np.int64)
+    n = v.shape[0]
+    e = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+    e = np.unique(np.concatenate([e, e[:, ::-1]], 0), axis=0)              # undirected, unique
+    deg = np.bincount(e[:, 0], minlength=n).astype(np.float64)
+    w = 1.0 / deg[e[:, 0]]
+    L = sp.coo_matrix((w, (e[:, 0], e[:, 1])), shape=(n, n)).tocsc()
+    A = (sp.identity(n, format="csc") + lamb * (sp.identity(n, format="csc") - L)).tocsc()
+    lu = splu(A)
+
+    def volume(p):
+        a, b, c = p[f[:, 0]], p[f[:, 1]], p[f[:, 2]]
+        return float(np.einsum("ij,ij->i", a, np.cross(b, c)).sum() / 6.0)
+
+    vol0 = volume(v) if volume_constraint else 0.0
+    for _ in range(int(iterations)):
+        v = lu.solve(v)
+        if volume_constraint:
+            vol = volume(v)
+            if vol != 0.0 and vol0 / vol > 0.0:
+                v *= (vol0 / vol) ** (1.0 / 3.0)
+    return v
+
+
+def shear_transformation(v):
+    """mesh_utils.py:76-93: principal axis of the (y, z) coordinates by SVD of their scatter matrix,
+    then z += a * y with a = -v[1,0] / v[0,0] (the figure is sheared upright).  In place on a copy."""
+    v = np.array(v, np.float64)
+    d = v[:, 1:3]
+    nd = d - d.mean(0)
+    H = nd.T @ nd
+    vec, val, _ = np.linalg.svd(H)
+    vec = vec[:, val.argsort()[::-1]]
+    a = -vec[1, 0] / vec[0, 0]
+    v[:, 2] += a * v[:, 1]
+    return v
+
+
+def nearest_vertex_colors(old_verts, new_verts, colors):
+    """mesh_utils.py:50-53 (no colour back-projection): colour of the nearest vertex of the mesh
+    before smoothing, for every vertex after it."""
+    from scipy.spatial import cKDTree
+    _, idx = cKDTree(np.asarray(old_verts, np.float64)).query(np.asarray(new_verts, np.float64), k=1)
+    return np.asarray(colors)[idx]
+
+
+def save_obj(path, verts, faces, colors=None, ortho_scale=1.35, smoothing=False, shearing=False):
+    """save_mesh (mesh_utils.py:25-73): halve, swap to the front-facing convention (x right, y up,
+    z front), [Laplacian smoothing + nearest-vertex colour transfer], [shear], ortho_scale, OBJ with
+    per-vertex colours (trimesh's export of `vertex_colors`: `v x y z r g b`, faces 1-based).
+    The two bracketed steps are opt-in (the reference's config has them on); thinning and colour
+    back-projection need a ray caster (mesh_raycast / igl / pytorch3d) and are out of scope."""
     v = verts.detach().cpu().numpy().astype(np.float64) * 0.5
-    out = np.zeros_like(v)
-    out[:, 0], out[:, 1], out[:, 2] = v[:, 0], v[:, 2], -v[:, 1]
-    out *= ortho_scale
-    f = faces.detach().cpu().numpy().astype(np.int64) + 1
+    old = np.zeros_like(v)
+    old[:, 0], old[:, 1], old[:, 2] = v[:, 0], v[:, 2], -v[:, 1]
+    fz = faces.detach().cpu().numpy().astype(np.int64)
+    c = None if colors is None else colors.detach().float().cpu().numpy()
+    out = old
+    if smoothing and len(fz):
+        out = laplacian_smooth_implicit(old, fz, lamb=2.0, iterations=5)
+        if c is not None:
+            c = nearest_vertex_colors(old, out, c)
+    if shearing and len(out):
+        out = shear_transformation(out)
+    out = out * ortho_scale
+    f = fz + 1
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
     with open(path, "w") as fh:
-        if colors is not None:
-            c = colors.detach().float().cpu().numpy()
+        if c is not None:
             for p, q in zip(out, c):
                 fh.write("v %.8f %.8f %.8f %.6f %.6f %.6f\n" % (p[0], p[1], p[2], q[0], q[1], q[2]))
         else:

@@ -151,3 +151,39 @@ def test_helper_and_obj_writer(tmp_path):
     assert nv == mesh["verts"].shape[0] and nf == mesh["faces"].shape[0]
     first_face = [int(t) for t in [l for l in lines if l.startswith("f ")][0].split()[1:]]
     assert first_face == (mesh["faces"][0] + 1).tolist()
+
+
+def test_mesh_post_processing_matches_reference_save_mesh(tmp_path):
+    """save_obj(smoothing, shearing) against the REFERENCE's own save_mesh / shear_transformation
+    (tests/golden/mesh_post_reference.npz, generated by make_mesh_post_golden.py from
+    instant_nsr/utils/mesh_utils.py with a stand-in for trimesh): axis convention, implicit
+    Laplacian filter, nearest-vertex colour transfer, shear, ortho scale, OBJ layout."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mesh_post_reference.npz"))
+    np.testing.assert_allclose(M.shear_transformation(z["verts"]), z["sheared"], rtol=0, atol=1e-12)
+    path = M.save_obj(str(tmp_path / "m.obj"), torch.from_numpy(z["verts"]), torch.from_numpy(z["faces"]),
+                      torch.from_numpy(z["colors"]), ortho_scale=1.35, smoothing=True, shearing=True)
+    vs, fs = [], []
+    for line in open(path):
+        t = line.split()
+        if t[0] == "v":
+            vs.append([float(x) for x in t[1:]])
+        elif t[0] == "f":
+            fs.append([int(x) for x in t[1:]])
+    vs, fs = np.array(vs), np.array(fs)
+    assert np.array_equal(fs - 1, z["out_f"])                                  # INT
+    np.testing.assert_allclose(vs[:, :3], z["out_v"], rtol=0, atol=2e-8)       # %.8f in the file
+    np.testing.assert_allclose(vs[:, 3:], z["out_c"], rtol=0, atol=1e-6)
+    # the filter keeps the enclosed volume and the shear removes the lean of the figure
+    sm = M.laplacian_smooth_implicit(z["verts"], z["faces"])
+    vol = lambda p: np.einsum("ij,ij->i", p[z["faces"][:, 0]], np.cross(p[z["faces"][:, 1]], p[z["faces"][:, 2]])).sum() / 6
+    assert abs(vol(sm) / vol(z["verts"]) - 1) < 1e-12
+    sh = M.shear_transformation(np.stack([z["verts"][:, 0], z["verts"][:, 2], -z["verts"][:, 1]], 1))
+    yz = sh[:, 1:3] - sh[:, 1:3].mean(0)
+    assert abs((yz[:, 0] * yz[:, 1]).sum()) < abs((z["verts"][:, 2] * -z["verts"][:, 1]).sum())
+    # default switches: the plain writer of before
+    p2 = M.save_obj(str(tmp_path / "n.obj"), torch.from_numpy(z["verts"]), torch.from_numpy(z["faces"]))
+    first = open(p2).readline().split()
+    np.testing.assert_allclose([float(x) for x in first[1:4]],
+                               np.array([z["verts"][0, 0], z["verts"][0, 2], -z["verts"][0, 1]]) * 0.5 * 1.35,
+                               atol=1e-8)
