@@ -6,19 +6,21 @@
 # Staged for the next visit:
 #   dinbatch  -DDSU_DIN_BATCH   k1: the 16 derivative factors of a hidden tile first, then its 16 dIn
 #             MFMAs back to back (no VALU issue slots between MFMAs on the one accumulator)
+#   texdin2   -DDSU_TEX_DIN_2ACC  texture backward: dIn into two alternating accumulators
 #   l0int     -DDSU_L0_INTERLEAVED  k1: layer 0 with the two hidden tiles alternating per k-pair (pre-round-2 order)
 #   din2acc   -DDSU_DIN_2ACC    k1: even / odd hidden units into two dIn accumulators (VALU between MFMAs
 #             on different accumulators); summation order differs: check the gradient tests
 set -u
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd "$R"
-VARIANTS="default dinbatch din2acc l0int"
+VARIANTS="default dinbatch din2acc l0int texdin2"
 case "${1:-}" in
   build)
     python -m drawingspinup_amd.build
     python -m drawingspinup_amd.build --variant dinbatch -DDSU_DIN_BATCH
     python -m drawingspinup_amd.build --variant din2acc -DDSU_DIN_2ACC
     python -m drawingspinup_amd.build --variant l0int -DDSU_L0_INTERLEAVED
+    python -m drawingspinup_amd.build --variant texdin2 -DDSU_TEX_DIN_2ACC
     ;;
   run)
     mkdir -p gpurun_out/ab
