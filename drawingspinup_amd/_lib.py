@@ -85,7 +85,7 @@ _PROTOS = {
     "dsu_table_adamw": [P, P, P, P, P, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, P],
     "dsu_table_decay": [P, P, c_i64, c_f32, P],
     "dsu_adamw_multi": [P, c_i32, c_f32, c_f32, c_f32, c_f32, P],
-    "dsu_smooth_iterate": [P, c_i64, P, C.c_double, c_i32, P, P, P],
+    "dsu_smooth_iterate": [P, c_i64, P, P, C.c_double, c_i32, P, P, P],
     "dsu_smooth_energy": [P, c_i64, P, P, P, P],
     "dsu_smooth_energy_partials": [],
     "dsu_spatial_sort": [P, c_i64, c_f32, c_i32, P, P, P, c_i64, P],

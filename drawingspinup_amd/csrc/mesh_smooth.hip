@@ -2,12 +2,13 @@
 // mcubes.smooth (MarchingCubeHelper.forward, instant_nsr/models/geometry.py:57-58) on the
 // compacted band voxels (gfx950, float64 as PyMCubes).
 //
-// Unknowns: the nv voxels with |signed distance| < band radius, compacted in x-major order.
+// Unknowns: the nv voxels with |signed distance| <= band radius, compacted in x-major order.
 // nbr[6][nv] (int32): slot of the -/+ neighbour along x, y, z, or -1 when that neighbour is
 // outside the band (or the volume): it then folds onto the diagonal of the 1-D second difference
 //     (F_a v)(i) = cd_a(i) v(i) + v(n-_a(i)) + v(n+_a(i)),   cd_a = -2 + [no n-] + [no n+].
 // Energy |F v|^2, Q = sum_a F_a^T F_a.  One iteration (PyMCubes: weight 0.5, projection onto the
-// side constraints) is two passes over the band:
+// per-voxel bounds lower[i] <= x <= upper[i]: the initial distance on the voxel's own side, 0 for
+// the voxels next to the surface, +-inf on the other side) is two passes over the band:
 //     y_a = F_a x                                    (smooth_rows_kernel,   3 nv doubles out)
 //     x  <- clamp(w * (-(Q x - d x) / d) + (1 - w) x)  with Q x = sum_a F_a^T y_a, d = diag Q
 //                                                    (smooth_update_kernel)
@@ -58,7 +59,8 @@ __device__ __forceinline__ void q_and_diag(const int32_t* __restrict__ nbr, int6
 __global__ __launch_bounds__(256) void smooth_update_kernel(const int32_t* __restrict__ nbr,
                                                             int64_t nv,
                                                             const double* __restrict__ y,
-                                                            const uint8_t* __restrict__ inside,
+                                                            const double* __restrict__ lower,
+                                                            const double* __restrict__ upper,
                                                             double weight, double* __restrict__ x) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv;
        i += (int64_t)gridDim.x * blockDim.x) {
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void smooth_update_kernel(const int32_t* __res
     const double xi = x[i];
     const double x1 = -(1.0 / d) * (q - d * xi);                 // -D^-1 R x
     double xn = weight * x1 + (1.0 - weight) * xi;
-    xn = inside[i] ? fmax(xn, 0.0) : fmin(xn, 0.0);              // stay on your side of the surface
+    xn = fmin(fmax(xn, lower[i]), upper[i]);                     // np.maximum(x, lower); np.minimum(x, upper)
     x[i] = xn;
   }
 }
@@ -100,15 +102,15 @@ extern "C" {
 
 int32_t dsu_smooth_energy_partials(void) { return EN_BLOCKS; }
 
-int dsu_smooth_iterate(const int32_t* nbr, int64_t nv, const uint8_t* inside, double weight,
-                       int32_t iters, double* x, double* y, void* stream) {
-  if (nv < 0 || iters < 0 || (nv && (!nbr || !inside || !x || !y))) return DSU_EINVAL;
+int dsu_smooth_iterate(const int32_t* nbr, int64_t nv, const double* lower, const double* upper,
+                       double weight, int32_t iters, double* x, double* y, void* stream) {
+  if (nv < 0 || iters < 0 || (nv && (!nbr || !lower || !upper || !x || !y))) return DSU_EINVAL;
   if (nv == 0 || iters == 0) return DSU_OK;
   hipStream_t s = (hipStream_t)stream;
   const int blocks = dsu_capped_blocks(nv, 256, 8192);
   for (int it = 0; it < iters; ++it) {
     smooth_rows_kernel<<<dim3(blocks), dim3(256), 0, s>>>(nbr, nv, x, y);
-    smooth_update_kernel<<<dim3(blocks), dim3(256), 0, s>>>(nbr, nv, y, inside, weight, x);
+    smooth_update_kernel<<<dim3(blocks), dim3(256), 0, s>>>(nbr, nv, y, lower, upper, weight, x);
   }
   DSU_CHECK_LAUNCH();
   return DSU_OK;

@@ -13,19 +13,24 @@ in the snapshot: PARITY UNPINNED for those two packages).  What is restated, and
   * `mcubes.smooth(binary)` -> `smooth_constrained` (the method PyMCubes picks for arrays of at most
     512^3 voxels): the constrained higher-order smoothing of Lempitsky, "Surface extraction from
     binary volumes with higher-order smoothness" (CVPR 2010), as PyMCubes implements it: signed
-    Euclidean distance transform (+-0.5 at the boundary voxels), variables = the band |d| < 4,
+    Euclidean distance transform (+-0.5 at the boundary voxels), variables = the band |d| <= 4,
     energy |F x|^2 with F the stacked 1-D second differences along the three axes (a neighbour
     outside the band folds onto the diagonal), weighted-Jacobi iterations (weight 0.5) with the
-    projection x >= lower, x <= upper that keeps every voxel on its side of the surface, energy
-    test every 10 iterations (relative improvement), float64.
+    projection x >= lower, x <= upper where a voxel's bound on its own side is its INITIAL
+    distance (`lower = where(x0 > 0, x0, -inf)`, `upper = where(x0 < 0, x0, inf)`), relaxed to 0
+    for the voxels next to the surface (`|x0| < 1`): only those may move towards the zero level,
+    every other voxel may only move away from it; energy test every 10 iterations (relative
+    improvement), float64.
   * `mcubes.marching_cubes(volume, iso)`: x-major / y / z-minor sweep over the cubes, a corner is
-    "below" when value < iso, every grid edge owns ONE vertex (created by the first cube of the
+    "below" when value <= iso (marchingcubes.h: `if(v[m] <= isovalue) cubeindex |= 1<<m`; the
+    projection above leaves many voxels at exactly 0.0, so the rule matters), every grid edge owns ONE vertex (created by the first cube of the
     sweep that touches it: edges 6, 5, 10 of a cube, the remaining nine only on the low faces of
     the volume), vertices numbered in creation order, position by linear interpolation along the
-    edge in float64, triangles cube by cube in table order.  Vertex numbering therefore depends
-    only on the volume; the per-cube triangulation table is GENERATED here (see `_build_tables`)
-    because no copy of the classic 256-row table exists in this image: same vertices, same
-    numbering, same surface, but triangle order / fan inside a cube need not equal PyMCubes'.
+    edge in float64, triangles cube by cube in table order.  The per-cube triangulation is the
+    classic 256-configuration table PyMCubes compiles in (nsr/mc_table.py), so vertex AND face
+    arrays are the ones `mcubes.marching_cubes` returns for the same volume.  `_build_tables`
+    (a generator of a topologically equivalent table from first principles) is kept as a
+    cross-check of that table only: tests compare the polygon loops of all 256 rows.
   * `cv2.resize(front_mask, (res, res), INTER_CUBIC)`: OpenCV's bicubic kernel (a = -0.75),
     half-pixel centres, replicated border, rounded and saturated to uint8.
 
@@ -167,8 +172,12 @@ def _build_tables():
     return edge_table, tri_table
 
 
+@functools.lru_cache(maxsize=None)
 def tables():
-    return _build_tables()
+    """(edge_table (256,) int32, tri_table (256, 16) int8): the classic table (nsr/mc_table.py);
+    the edge masks follow from the corner states."""
+    from .mc_table import triangle_table
+    return _build_tables()[0], triangle_table()
 
 
 # ------------------------------------------------------------------------------------------------
@@ -185,7 +194,7 @@ def marching_cubes(volume, isovalue=0.0):
     et, tt = tables()
     edge_table = torch.from_numpy(et).to(dev)
     tri_table = torch.from_numpy(tt.astype(np.int64)).to(dev)
-    below = v < isovalue
+    below = v <= isovalue                                          # marchingcubes.h: `<=`
     cube = torch.zeros((X - 1, Y - 1, Z - 1), dtype=torch.int64, device=dev)
     for m, (dx, dy, dz) in enumerate(CORNERS):
         cube += below[dx:X - 1 + dx, dy:Y - 1 + dy, dz:Z - 1 + dz].to(torch.int64) << m
@@ -338,7 +347,7 @@ def smooth_constrained(binary, max_iters=250, rel_tol=1e-6, band_radius=4.0, wei
     b = binary.bool()
     dev = b.device
     dist = signed_distance_band(b, band_radius + 1.0)
-    band = dist.abs() < band_radius
+    band = dist.abs() <= band_radius
     pos = torch.nonzero(band)
     nv = pos.shape[0]
     if nv == 0:
@@ -357,21 +366,26 @@ def smooth_constrained(binary, max_iters=250, rel_tol=1e-6, band_radius=4.0, wei
             nbr_slots.append(torch.where(ok, n, torch.full_like(n, -1)))
     del slot
     x = dist[band]
-    inside = b[band]
+    # PyMCubes' bounds: own-side bound = the initial distance, 0 next to the surface
+    ninf, pinf = float("-inf"), float("inf")
+    lower = torch.where(x > 0, x, torch.full_like(x, ninf))
+    upper = torch.where(x < 0, x, torch.full_like(x, pinf))
+    lower = torch.where(lower.abs() < 1, torch.zeros_like(x), lower)
+    upper = torch.where(upper.abs() < 1, torch.zeros_like(x), upper)
     check_each = 10
     cum_rel_tol = 1 - (1 - rel_tol) ** check_each
     if b.is_cuda:
         # the iteration itself: csrc/mesh_smooth.hip (two passes over the band per iteration)
         from .. import ops
         nbr_t = torch.stack(nbr_slots).contiguous()
-        inside_u8 = inside.to(torch.uint8).contiguous()
+        lower, upper = lower.contiguous(), upper.contiguous()
         x = x.contiguous()
         ybuf = torch.empty(3 * nv, dtype=torch.float64, device=dev)
         energy_now = float(ops.smooth_energy(nbr_t, x, ybuf))
         done = 0
         while done < max_iters:
             step = min(check_each, max_iters - done)
-            ops.smooth_iterate(nbr_t, inside_u8, x, ybuf, weight, step)
+            ops.smooth_iterate(nbr_t, lower, upper, x, ybuf, weight, step)
             done += step
             if step == check_each:
                 energy_before = energy_now
@@ -385,9 +399,6 @@ def smooth_constrained(binary, max_iters=250, rel_tol=1e-6, band_radius=4.0, wei
     nbr = [[nbr_slots[2 * a + k].clamp(min=0).long() for k in range(2)] for a in range(3)]
     has = [[(nbr_slots[2 * a + k] >= 0).to(torch.float64) for k in range(2)] for a in range(3)]
     cdiag = [-2.0 + (1 - has[a][0]) + (1 - has[a][1]) for a in range(3)]
-    ninf, pinf = float("-inf"), float("inf")
-    lower = torch.where(inside, torch.zeros_like(x), torch.full_like(x, ninf))
-    upper = torch.where(inside, torch.full_like(x, pinf), torch.zeros_like(x))
 
     def apply_q(v):
         out = torch.zeros_like(v)

@@ -198,11 +198,12 @@ def table_decay(p, img_f16, start, n, factor):
 
 
 # ------------------------------------------------------------------ export: mcubes.smooth
-def smooth_iterate(nbr, inside, x, y, weight, iters):
-    """`iters` projected weighted-Jacobi iterations on the band voxels, in place on x (f64)."""
+def smooth_iterate(nbr, lower, upper, x, y, weight, iters):
+    """`iters` projected weighted-Jacobi iterations on the band voxels, in place on x (f64);
+    lower / upper: per-voxel bounds (f64, +-inf = none)."""
     nv = x.shape[0]
-    check(lib().dsu_smooth_iterate(ptr(nbr, torch.int32), nv, ptr(inside, torch.uint8),
-                                   float(weight), int(iters), ptr(x, torch.float64),
+    check(lib().dsu_smooth_iterate(ptr(nbr, torch.int32), nv, ptr(lower, torch.float64),
+                                   ptr(upper, torch.float64), float(weight), int(iters), ptr(x, torch.float64),
                                    ptr(y, torch.float64), stream()), "dsu_smooth_iterate")
     return x
 

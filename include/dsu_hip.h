@@ -588,14 +588,15 @@ int dsu_adamw_multi(const dsu_adamw_tensor* tensors, int32_t count, float beta1,
 /* mcubes.smooth on the export's binary volume (MarchingCubeHelper.forward,
  * instant_nsr/models/geometry.py:57-58 -> PyMCubes' constrained smoothing): the weighted-Jacobi
  * iteration on the compacted band voxels, float64.  nbr (6, nv) int32: slot of the -x,+x,-y,+y,
- * -z,+z neighbour or -1 (outside the band: folds onto the diagonal); inside (nv) u8: the voxel's
- * class (1: x >= 0 is enforced, 0: x <= 0); x (nv) in/out; y caller-owned scratch of 3*nv doubles.
+ * -z,+z neighbour or -1 (outside the band: folds onto the diagonal); lower / upper (nv) f64: the
+ * per-voxel bounds of PyMCubes' projection (`np.maximum(x, lower)` then `np.minimum(x, upper)`;
+ * +-infinity = unbounded); x (nv) in/out; y caller-owned scratch of 3*nv doubles.
  * dsu_smooth_iterate runs `iters` iterations x <- proj(w * (-D^-1 R x) + (1 - w) x);
  * dsu_smooth_energy writes dsu_smooth_energy_partials() partial sums of x . Q x (the caller adds
  * them in order and halves: the energy of the stopping test). */
 int32_t dsu_smooth_energy_partials(void);
-int dsu_smooth_iterate(const int32_t* nbr, int64_t nv, const uint8_t* inside, double weight,
-                       int32_t iters, double* x, double* y, void* stream);
+int dsu_smooth_iterate(const int32_t* nbr, int64_t nv, const double* lower, const double* upper,
+                       double weight, int32_t iters, double* x, double* y, void* stream);
 int dsu_smooth_energy(const int32_t* nbr, int64_t nv, const double* x, double* y,
                       double* partials, void* stream);
 

@@ -7,11 +7,17 @@ tests or golden meshes.  Restated from the published implementation (mcubes/src/
 serial x-major sweep, `shared_indices` de-duplication, vertex creation order 6, 5, 10 then the
 boundary edges, `mc_isovalue_interpolation`; mcubes/smoothing.py: `signed_distance_function`,
 `_buildq3d`, `_jacobi`, `smooth_constrained`) as serial Python / scipy code, independent of the
-tensor formulation in drawingspinup_amd/nsr/mesh.py.  The per-cube triangulation table is an INPUT
-(the classic 256-row table is not available in this image; the product generates one, and
-tests/test_mesh_host.py checks its topological properties before using it here).
+tensor formulation in drawingspinup_amd/nsr/mesh.py.  The per-cube triangulation is the classic
+256-row table held under oracle/ (mc_classic_table.py: the product's copy is never imported here).
+
+Points a second reader and this restatement agree on, from the published source:
+`if(v[m] <= isovalue) cubeindex |= 1<<m`; band = |d| <= band_radius; bounds
+`upper = where(x < 0, x, inf)`, `lower = where(x > 0, x, -inf)`, then both set to 0 where their
+magnitude is below 1.
 """
 import numpy as np
+
+from . import mc_classic_table as _classic
 
 CORNERS = ((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0), (0, 0, 1), (1, 0, 1), (1, 1, 1), (0, 1, 1))
 EDGES = ((0, 1), (1, 2), (2, 3), (3, 0), (4, 5), (5, 6), (6, 7), (7, 4), (0, 4), (1, 5), (2, 6), (3, 7))
@@ -23,8 +29,13 @@ def _interp(iso, f1, f2, x1, x2):
     return (x2 - x1) * (iso - f1) / (f2 - f1) + x1
 
 
-def marching_cubes(volume, iso, edge_table, tri_table):
-    """Serial sweep: for i, for j, for k (k fastest).  Returns (verts (N,3) f64, faces (M,3) i64)."""
+def marching_cubes(volume, iso, edge_table=None, tri_table=None):
+    """Serial sweep: for i, for j, for k (k fastest).  Returns (verts (N,3) f64, faces (M,3) i64).
+    Tables default to the oracle's own classic table."""
+    if edge_table is None:
+        edge_table = _classic.EDGE_TABLE
+    if tri_table is None:
+        tri_table = _classic.TRIANGLE_TABLE
     f = np.asarray(volume, np.float64)
     X, Y, Z = f.shape
     verts, faces = [], []
@@ -41,33 +52,34 @@ def marching_cubes(volume, iso, edge_table, tri_table):
         axis = [d for d in range(3) if a_pt[d] != b_pt[d]][0]
         return lo + (axis,)
 
-    for i in range(X - 1):
-        for j in range(Y - 1):
-            for k in range(Z - 1):
-                pts = [(i + dx, j + dy, k + dz) for dx, dy, dz in CORNERS]
-                cubeindex = 0
-                for m in range(8):
-                    if f[pts[m]] < iso:
-                        cubeindex |= 1 << m
-                edges = int(edge_table[cubeindex])
-                if edges == 0:
-                    continue
-                idx = [-1] * 12
-                # the three edges no earlier cube has seen, then the rest (created on the low faces
-                # of the volume, looked up otherwise)
-                for e in (6, 5, 10, 0, 1, 2, 3, 4, 7, 8, 9, 11):
-                    if not edges >> e & 1:
-                        continue
-                    a, b = EDGES[e]
-                    kk = key(pts[a], pts[b])
-                    if kk not in shared:
-                        shared[kk] = vertex(pts[a], pts[b])
-                    idx[e] = shared[kk]
-                row = tri_table[cubeindex]
-                m = 0
-                while m < len(row) and row[m] != -1:
-                    faces.append((idx[row[m]], idx[row[m + 1]], idx[row[m + 2]]))
-                    m += 3
+    # cube index of every cube at once (the same `v[m] <= isovalue` test per corner), then the serial
+    # sweep over the cubes that are cut, in the sweep's order: argwhere is lexicographic in (i, j, k),
+    # i.e. for i / for j / for k with k fastest.  Skipping uncut cubes changes nothing: they create
+    # no vertices and no triangles.
+    below = f <= iso
+    cube = np.zeros((X - 1, Y - 1, Z - 1), np.int64)
+    for m, (dx, dy, dz) in enumerate(CORNERS):
+        cube |= below[dx:X - 1 + dx, dy:Y - 1 + dy, dz:Z - 1 + dz].astype(np.int64) << m
+    for i, j, k in np.argwhere((cube != 0) & (cube != 255)).tolist():
+        pts = [(i + dx, j + dy, k + dz) for dx, dy, dz in CORNERS]
+        cubeindex = int(cube[i, j, k])
+        edges = int(edge_table[cubeindex])
+        idx = [-1] * 12
+        # the three edges no earlier cube has seen, then the rest (created on the low faces
+        # of the volume, looked up otherwise)
+        for e in (6, 5, 10, 0, 1, 2, 3, 4, 7, 8, 9, 11):
+            if not edges >> e & 1:
+                continue
+            a, b = EDGES[e]
+            kk = key(pts[a], pts[b])
+            if kk not in shared:
+                shared[kk] = vertex(pts[a], pts[b])
+            idx[e] = shared[kk]
+        row = tri_table[cubeindex]
+        m = 0
+        while m < len(row) and row[m] != -1:
+            faces.append((idx[row[m]], idx[row[m + 1]], idx[row[m + 2]]))
+            m += 3
     return (np.asarray(verts, np.float64).reshape(-1, 3), np.asarray(faces, np.int64).reshape(-1, 3))
 
 
@@ -126,13 +138,15 @@ def _jacobi(Q, x0, lower, upper, max_iters=10, rel_tol=1e-6, weight=0.5):
 def smooth_constrained(binary, max_iters=250, rel_tol=1e-6, band_radius=4.0):
     b = np.asarray(binary) > 0
     dist = signed_distance_function(b)
-    band = np.abs(dist) < band_radius
+    band = np.abs(dist) <= band_radius
     vi = np.full(b.shape, -1, np.int64)
     vi[band] = np.arange(int(band.sum()))
     Q = _buildq3d(vi)
     x0 = dist[band]
-    lower = np.where(b[band], 0.0, -np.inf)
-    upper = np.where(b[band], np.inf, 0.0)
+    upper = np.where(x0 < 0, x0, np.inf)
+    lower = np.where(x0 > 0, x0, -np.inf)
+    upper[np.abs(upper) < 1] = 0
+    lower[np.abs(lower) < 1] = 0
     x = _jacobi(Q, x0, lower, upper, max_iters, rel_tol)
     out = dist.copy()
     out[band] = x

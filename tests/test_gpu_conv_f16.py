@@ -89,6 +89,7 @@ def test_conv_f16_split_k_heuristic():
 # ---------------------------------------------------------------------------------------------
 # The UNet's linear layers on the same MFMA kernel (dsu_gemm_f16_fwd / dsu_gemm_geglu_fwd)
 # ---------------------------------------------------------------------------------------------
+@gpu
 @pytest.mark.parametrize("M,K,N", [(12 * 1024, 320, 320), (12 * 256, 640, 640), (12 * 16, 1280, 1280),
                                    (12, 768, 1280), (12, 1280, 320), (37, 16, 1280), (12 * 64, 1280, 1280)])
 def test_linear_f16_matches_torch(dev, M, K, N):
@@ -108,6 +109,7 @@ def test_linear_f16_matches_torch(dev, M, K, N):
             torch.testing.assert_close(got.cpu().float(), ref, rtol=2e-3, atol=4e-3)
 
 
+@gpu
 @pytest.mark.parametrize("B,T,K,N", [(12, 1024, 320, 320), (12, 16, 1280, 1280), (3, 100, 640, 648)])
 def test_linear_f16_transposed_output_is_v_transposed(dev, B, T, K, N):
     g = torch.Generator().manual_seed(B + T + K)
@@ -119,6 +121,7 @@ def test_linear_f16_transposed_output_is_v_transposed(dev, B, T, K, N):
     torch.testing.assert_close(got, ref, rtol=2e-3, atol=4e-3)
 
 
+@gpu
 @pytest.mark.parametrize("M,C", [(12 * 1024, 320), (12 * 64, 1280), (19, 640), (130, 328)])
 def test_linear_geglu_matches_unfused_reference(dev, M, C):
     """diffusers GEGLU: proj -> chunk(2) -> a * gelu(g), the projection rounded to f16 first."""

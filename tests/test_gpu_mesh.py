@@ -26,11 +26,37 @@ def test_device_smoothing_matches_scipy_restatement(dev, iters):
     np.testing.assert_allclose(got[near], ref[near], rtol=0, atol=1e-9)
     assert np.all(got[b.numpy()] >= 0) and np.all(got[~b.numpy()] <= 0)
     # INT: faces of the smoothed field bit-exact vs the serial sweep on the oracle's field
-    et, tt = M.tables()
     v, f = M.marching_cubes(torch.from_numpy(got).to(dev), 0.0)
-    rv, rf = R.marching_cubes(ref, 0.0, et, tt)
+    rv, rf = R.marching_cubes(ref, 0.0)                            # the oracle's own classic table
     assert np.array_equal(f.cpu().numpy(), rf)
     np.testing.assert_allclose(v.cpu().numpy(), rv, rtol=0, atol=1e-7)
+
+
+def _field(n, seed):
+    """A smooth field with structure at several scales and a few thousand values that are EXACTLY
+    the iso value (what the projection of mcubes.smooth produces): the `<=` corner rule decides."""
+    c = torch.linspace(-1, 1, n, dtype=torch.float64)
+    x, y, z = torch.meshgrid(c, c, c, indexing="ij")
+    g = torch.Generator().manual_seed(seed)
+    ph = torch.rand(6, generator=g, dtype=torch.float64) * 6.28
+    vol = 0.55 - torch.sqrt((x / 0.8) ** 2 + (y / 0.6) ** 2 + (z / 0.7) ** 2) \
+        + 0.08 * torch.sin(9 * x + ph[0]) * torch.sin(7 * y + ph[1]) * torch.sin(8 * z + ph[2]) \
+        + 0.03 * torch.sin(23 * x + ph[3]) * torch.sin(19 * y + ph[4]) * torch.sin(21 * z + ph[5])
+    vol = torch.where(vol.abs() < 2e-3, torch.zeros_like(vol), vol)
+    return vol
+
+
+@pytest.mark.parametrize("n,seed", [(128, 0), (256, 1)])
+def test_marching_cubes_at_export_scale_matches_the_independent_oracle(dev, n, seed):
+    """INT parity at >= 128^3: vertex numbering and face index arrays of the device program equal
+    the serial sweep with the ORACLE's copy of the classic table (bit for bit), vertices too."""
+    vol = _field(n, seed)
+    assert int((vol == 0).sum()) > 500
+    v, f = M.marching_cubes(vol.to(dev), 0.0)
+    rv, rf = R.marching_cubes(vol.numpy(), 0.0)
+    assert rf.shape[0] > 20000
+    assert np.array_equal(f.cpu().numpy(), rf)
+    assert np.array_equal(v.cpu().numpy(), rv)
 
 
 def test_device_smoothing_equals_the_tensor_program_at_export_scale(dev):

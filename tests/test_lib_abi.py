@@ -147,8 +147,8 @@ def test_round2_entry_points_validate_before_launching():
     assert lib.dsu_adamw_multi(None, _lib.ADAMW_MAX_TENSORS + 1, 0.9, 0.99, 1e-15, 0.01, None) == -1
     # export smoothing
     assert lib.dsu_smooth_energy_partials() == 1024
-    assert lib.dsu_smooth_iterate(None, 5, None, 0.5, 10, None, None, None) == -1
-    assert lib.dsu_smooth_iterate(None, 0, None, 0.5, 10, None, None, None) == 0
+    assert lib.dsu_smooth_iterate(None, 5, None, None, 0.5, 10, None, None, None) == -1
+    assert lib.dsu_smooth_iterate(None, 0, None, None, 0.5, 10, None, None, None) == 0
     # TELEA: host function, runs here
     import numpy as np
     img = np.full((5, 6, 3), 9, np.uint8)

@@ -8,27 +8,61 @@ from drawingspinup_amd.nsr import mesh as M
 from oracle import mcubes_ref as R
 
 
-def test_generated_tables_are_a_valid_crack_free_triangulation():
+def _boundary(row):
+    """Directed boundary segments (edge a -> edge b) of a row's triangles; asserts that no directed
+    segment occurs twice (consistent orientation) and interior segments are shared by two triangles."""
+    seg = {}
+    for t in range(0, len(row), 3):
+        tri = row[t:t + 3]
+        assert len(set(tri)) == 3
+        for a, b in ((tri[0], tri[1]), (tri[1], tri[2]), (tri[2], tri[0])):
+            seg[(a, b)] = seg.get((a, b), 0) + 1
+    assert all(n == 1 for n in seg.values())
+    return {(a, b) for (a, b) in seg if (b, a) not in seg}
+
+
+def test_classic_table_is_a_valid_crack_free_triangulation_and_both_copies_agree():
+    """The 256-row table PyMCubes compiles in, as held by the product (nsr/mc_table.py) and,
+    separately, by the oracle (oracle/mc_classic_table.py)."""
+    from oracle import mc_classic_table as C
     et, tt = M.tables()
-    assert et[0] == 0 and et[255] == 0 and tt.shape[0] == 256
+    assert tt.shape == (256, 16) and np.array_equal(tt, np.array(C.TRIANGLE_TABLE, np.int8))
+    assert np.array_equal(et, np.array(C.EDGE_TABLE, np.int32))
+    assert M.EDGES == C.EDGES and M.CORNERS == C.CORNERS
+    # Bourke's published edge masks, spot values
+    assert [et[1], et[2], et[3], et[128], et[255]] == [0x109, 0x203, 0x30a, 0x8c0, 0]
+    gen_et, gen_tt = M._build_tables()                          # first-principles generator
+    face_segments = {}
     for c in range(256):
         row = [int(v) for v in tt[c] if v >= 0]
-        assert len(row) % 3 == 0
-        used = set(row)
+        assert len(row) % 3 == 0 and len(row) <= 15
         crossed = {e for e in range(12) if et[c] >> e & 1}
-        assert used == crossed                                   # every crossed edge carries the surface
-        # inside the cube each polygon edge that is NOT on a cube face is shared by two triangles;
-        # segments on cube faces appear once (they are matched by the neighbouring cube)
-        seg = {}
-        for t in range(0, len(row), 3):
-            tri = row[t:t + 3]
-            assert len(set(tri)) == 3
-            for a, b in ((tri[0], tri[1]), (tri[1], tri[2]), (tri[2], tri[0])):
-                seg[(a, b)] = seg.get((a, b), 0) + 1
-        for (a, b), n in seg.items():
-            assert n == 1                                         # consistent orientation: no directed edge twice
-        # complement symmetry of the edge masks
+        assert set(row) == crossed                               # every crossed edge carries the surface
+        bnd = _boundary(row)
+        # boundary segments run inside cube faces, one in and one out per crossed edge: closed loops
+        assert all(M._coplanar(a, b) for a, b in bnd)
+        assert sorted(a for a, _ in bnd) == sorted(crossed) == sorted(b for _, b in bnd)
+        # same polygon loops, same orientation, same triangle count as the generated table:
+        # only the fan inside a polygon (and the order of the triangles) is the table's choice
+        gen_row = [int(v) for v in gen_tt[c] if v >= 0]
+        assert bnd == _boundary(gen_row) and len(gen_row) == len(row)
         assert et[c] == et[255 - c]
+        # the segments on a cube face depend on that face's four corner states only
+        for f in M.FACES:
+            state = tuple(c >> m & 1 for m in f)
+            on_face = frozenset((a, b) for a, b in bnd
+                                if set(M.EDGES[a]) <= set(f) and set(M.EDGES[b]) <= set(f))
+            assert face_segments.setdefault((f, state), on_face) == on_face
+
+
+def test_classic_table_known_rows():
+    """Rows anyone can check against the published table by eye."""
+    _, tt = M.tables()
+    row = lambda c: [int(v) for v in tt[c] if v >= 0]
+    assert row(0) == [] and row(255) == []
+    assert row(1) == [0, 8, 3] and row(2) == [0, 1, 9] and row(3) == [1, 8, 3, 9, 8, 1]
+    assert row(15) == [9, 8, 10, 10, 8, 11] and row(254) == [0, 3, 8] and row(128) == [7, 6, 11]
+    assert row(85) == [1, 2, 5, 5, 2, 6, 3, 0, 4, 3, 4, 7]
 
 
 def _closed_and_oriented(faces):
@@ -47,24 +81,31 @@ def test_marching_cubes_matches_serial_sweep_bit_exactly(seed, shape):
     shell = torch.ones_like(vol, dtype=torch.bool)
     shell[1:-1, 1:-1, 1:-1] = False
     vol = torch.where(shell, vol.abs() + 0.1, vol)                  # nothing below iso on the shell
-    et, tt = M.tables()
     v, f = M.marching_cubes(vol, 0.02)
-    rv, rf = R.marching_cubes(vol.numpy(), 0.02, et, tt)
+    rv, rf = R.marching_cubes(vol.numpy(), 0.02)               # the oracle's own table
     assert np.array_equal(f.numpy(), rf)                            # INT: face index arrays
     assert np.array_equal(v.numpy(), rv)                            # same float64 interpolation
     assert _closed_and_oriented(rf.tolist())                        # positive shell: a closed surface
 
 
+def test_marching_cubes_128_cubed_with_exact_iso_values_matches_serial_sweep():
+    """The export-scale case of tests/test_gpu_mesh.py on the host tensors (same program)."""
+    from test_gpu_mesh import _field
+    vol = _field(128, 0)
+    v, f = M.marching_cubes(vol, 0.0)
+    rv, rf = R.marching_cubes(vol.numpy(), 0.0)
+    assert rf.shape[0] > 20000 and np.array_equal(f.numpy(), rf) and np.array_equal(v.numpy(), rv)
+
+
 def test_marching_cubes_open_boundary_and_degenerate_values():
     """Surfaces that leave the volume (boundary-created vertices on the low faces) and equal corner
     values (the (x1+x2)/2 branch is unreachable for a crossed edge; exact-iso corners count as
-    not below)."""
+    below: marchingcubes.h tests `<=`)."""
     g = torch.Generator().manual_seed(5)
     vol = torch.randn(7, 6, 8, generator=g, dtype=torch.float64)
     vol[2, 3, 4] = 0.0
-    et, tt = M.tables()
     v, f = M.marching_cubes(vol, 0.0)
-    rv, rf = R.marching_cubes(vol.numpy(), 0.0, et, tt)
+    rv, rf = R.marching_cubes(vol.numpy(), 0.0)
     assert np.array_equal(f.numpy(), rf) and np.array_equal(v.numpy(), rv)
     empty_v, empty_f = M.marching_cubes(torch.ones(4, 4, 4), 0.0)
     assert empty_v.shape == (0, 3) and empty_f.shape == (0, 3)
@@ -110,12 +151,16 @@ def test_smooth_constrained_matches_scipy_restatement():
     np.testing.assert_allclose(got[near], ref[near], rtol=0, atol=1e-9)
     # beyond the band the product caps the distance (the zero level set never sees those values)
     assert np.array_equal(np.sign(got[~near]), np.sign(ref[~near])) and np.all(np.abs(got[~near]) > 4.5)
-    # the constraint: every voxel stays on its side of the surface
+    # the constraints: every voxel stays on its side of the surface, and only the voxels next to
+    # it (|d0| < 1) may move towards it
     assert np.all(got[b.numpy()] >= 0) and np.all(got[~b.numpy()] <= 0)
+    d0 = R.signed_distance_function(b.numpy())
+    inner = near & (np.abs(d0) >= 1)
+    assert np.all(np.abs(got[inner]) >= np.abs(d0[inner]) - 1e-12)
+    assert np.any(np.abs(got[near & (np.abs(d0) < 1)]) < 0.5 - 1e-6)
     # and the mesh of the smoothed field, faces bit-exact vs the serial sweep on the oracle's field
-    et, tt = M.tables()
     v, f = M.marching_cubes(torch.from_numpy(got), 0.0)
-    rv, rf = R.marching_cubes(ref, 0.0, et, tt)
+    rv, rf = R.marching_cubes(ref, 0.0)
     assert np.array_equal(f.numpy(), rf)
     np.testing.assert_allclose(v.numpy(), rv, rtol=0, atol=1e-7)
 
