@@ -62,9 +62,23 @@ def parse(argv=None):
 # libdsu_hip launches there).  Each family carries its algorithmic work per launch.
 # ------------------------------------------------------------------------------------------------
 class KernelTimer:
+    """The NSR step is sequenced inside the library (dsu_nsr_driver_step), so its two geometry
+    families are timed there, with HIP events on the stream the kernels run on
+    (dsu_nsr_driver_timing); the families launched from Python are wrapped here."""
+
     def __init__(self):
-        self.enabled = False
+        self._enabled = False
         self.fam = {}
+
+    @property
+    def enabled(self):
+        return self._enabled
+
+    @enabled.setter
+    def enabled(self, on):
+        from drawingspinup_amd.nsr import system as nsr_system
+        self._enabled = bool(on)
+        nsr_system.native_timing["enabled"] = bool(on)
 
     def _wrap(self, module, name, family, work):
         orig = getattr(module, name)
@@ -108,10 +122,15 @@ class KernelTimer:
         # re-binding the attribute on `ops` is enough
 
     def summary(self):
+        from drawingspinup_amd.nsr import system as nsr_system
         rows = []
-        for name, f in self.fam.items():
-            ms = sum(s.elapsed_time(e) for s, e in f["events"])
-            n = len(f["events"])
+        merged = {name: [len(f["events"]), sum(s.elapsed_time(e) for s, e in f["events"]), f["work"]]
+                  for name, f in self.fam.items()}
+        for name, (n, ms, work) in nsr_system.native_timing["totals"].items():
+            t = merged.setdefault(name, [0, 0.0, 0.0])
+            t[0] += n; t[1] += ms; t[2] += work
+        for name, (n, ms, work) in merged.items():
+            f = {"work": work}
             if not n or ms <= 0:
                 continue
             hbm = name.startswith("sdf_")

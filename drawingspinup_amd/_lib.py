@@ -60,6 +60,37 @@ class AdamwTensor(C.Structure):
 
 ADAMW_MAX_TENSORS = 24
 
+
+class NsrDriverCfg(C.Structure):                     # dsu_nsr_driver_cfg
+    _fields_ = [("grid", HashGridCfg), ("radius", c_f32), ("render_step_size", c_f32),
+                ("cap_points", c_i32), ("cap_rays", c_i32), ("n_random", c_i32),
+                ("sort_bits", c_i32), ("dynamic_ray_sampling", c_i32),
+                ("train_num_samples", c_i32),
+                ("c2w", c_vp), ("origins", c_vp), ("directions", c_vp), ("images", c_vp),
+                ("normals", c_vp), ("masks", c_vp), ("view_weights", c_vp),
+                ("V", c_i32), ("H", c_i32), ("W", c_i32), ("image_channels", c_i32),
+                ("w0_v", c_vp), ("w0_g", c_vp), ("b0", c_vp), ("w1_v", c_vp), ("w1_g", c_vp),
+                ("b1", c_vp), ("tex", c_vp * 6), ("variance", c_vp),
+                ("ray_loss", RayLossCfg),
+                ("lambda_eikonal", c_f32), ("lambda_sparsity", c_f32), ("sparsity_scale", c_f32),
+                ("lambda_smooth", c_f32),
+                ("beta1", c_f32), ("beta2", c_f32), ("adam_eps", c_f32), ("weight_decay", c_f32),
+                ("seed", C.c_uint64), ("workspace", c_vp), ("workspace_bytes", c_i64)]
+
+
+class NsrStepArgs(C.Structure):                      # dsu_nsr_step_args
+    _fields_ = [("step", c_i64), ("n_rays", c_i32), ("prefetch_next", c_i32),
+                ("active_levels", c_u32), ("eps", c_f32), ("cos_anneal_ratio", c_f32),
+                ("lr_geometry", c_f32), ("lr_texture", c_f32), ("lr_variance", c_f32),
+                ("adam_step", c_i32), ("randomized", c_i32), ("refresh_effective", c_i32),
+                ("occ_res", c_i32), ("occ_binary", c_vp), ("table_img", c_vp),
+                ("table_grad", c_vp),
+                ("inj_index", c_vp), ("inj_x", c_vp), ("inj_y", c_vp), ("inj_jitter", c_vp),
+                ("inj_pts_random", c_vp), ("inj_perturb", c_vp),
+                ("out_n_samples", c_i32), ("out_max_count", c_i32), ("out_next_n_rays", c_i32),
+                ("reserved", c_i32)]
+
+
 _PROTOS = {
     "dsu_abi_version": [],
     "dsu_hashgrid_make_levels": [C.POINTER(HashGridCfg), C.POINTER(HashGridLevels)],
@@ -88,6 +119,16 @@ _PROTOS = {
     "dsu_smooth_iterate": [P, c_i64, P, P, C.c_double, c_i32, P, P, P],
     "dsu_smooth_energy": [P, c_i64, P, P, P, P],
     "dsu_smooth_energy_partials": [],
+    "dsu_nsr_draws": [C.c_uint64, c_i64, c_i32, c_i32, c_i32, c_i32, P, P, P, P, c_i32, P, P, P],
+    "dsu_nsr_driver_workspace_bytes": [C.POINTER(NsrDriverCfg)],
+    "dsu_nsr_driver_create": [C.POINTER(NsrDriverCfg), C.POINTER(c_vp)],
+    "dsu_nsr_driver_destroy": [c_vp],
+    "dsu_nsr_driver_step": [c_vp, C.POINTER(NsrStepArgs), P],
+    "dsu_nsr_driver_terms": [c_vp],
+    "dsu_nsr_driver_sync": [c_vp],
+    "dsu_nsr_driver_timing": [c_vp, c_i32],
+    "dsu_nsr_driver_timing_read": [c_vp, c_i32, C.POINTER(c_i64), C.POINTER(C.c_double),
+                                   C.POINTER(C.c_double)],
     "dsu_spatial_sort": [P, c_i64, c_f32, c_i32, P, P, P, c_i64, P],
     "dsu_spatial_sort_workspace_bytes": [c_i64, c_i32],
     "dsu_ray_aabb": [P, P, c_i64, P, P, c_f32, P, P, P],
@@ -156,6 +197,9 @@ _PROTOS = {
                        P, P, c_i32, P, P, P],
 }
 
+# return types that are neither an error code nor a byte count
+_RESTYPES = {"dsu_nsr_driver_destroy": None, "dsu_nsr_driver_terms": c_vp}
+
 _lib = None
 
 
@@ -176,7 +220,7 @@ def lib():
         h.dsu_strerror.argtypes = [C.c_int]
         for name, args in _PROTOS.items():
             fn = getattr(h, name)  # AttributeError here = header/library mismatch
-            fn.restype = C.c_int64 if name.endswith("_bytes") else C.c_int
+            fn.restype = _RESTYPES.get(name, C.c_int64 if name.endswith("_bytes") else C.c_int)
             fn.argtypes = args
         _lib = h
     return _lib

@@ -1,0 +1,621 @@
+// Native driver of one NSR optimisation step (gfx950 host code + three small kernels).
+//
+// OrthoNeuSSystem.training_step (2_charactor_reconstructor/instant_nsr/systems/neus_ortho.py:79-169)
+// over NeuSModelTextureMLP.forward_ (instant_nsr/models/neus.py:114-196), preprocess_data
+// (neus_ortho.py:26-77) and the AdamW step of configs/neuralangelo-ortho-wmask.yaml:96-127 as ONE
+// call of the C ABI.  The kernels are the library's own (dsu_sdf_fd_*_sorted, dsu_texture_*,
+// dsu_neus_composite_*, dsu_ray_*, dsu_*_losses ...); what this file adds is the host sequencing
+// that used to be ~1.4 ms of Python per step — as long as a step's device time — plus
+//   * nsr_draw_kernel: the step's random draws (view / pixel triples, stratified jitter, the 2048
+//     regulariser points and their perturbation: neus_ortho.py:31-41, neus.py:155-160) from a
+//     counter-based Philox4x32-10 stream: one launch instead of six torch RNG launches;
+//   * small_update_kernel: weight-norm backward (network_utils.py:130-131), grad of the variance
+//     scalar, torch.optim.AdamW for the 13 small tensors of the three parameter groups, weight-norm
+//     forward and inv_s = exp(10 variance) for the NEXT step, and the reset of the small gradient
+//     accumulators: one single-workgroup launch instead of ~12 torch launches.
+//
+// Streams: the step's kernels run on `main`; the next step's draws, ray batch, march, packing and
+// Morton sort run on a driver-owned side stream behind the geometry forward (they depend on the
+// occupancy grid and the RNG, not on the parameters), and hand the sample total to the host
+// through pinned memory.  All device memory is the caller's: one workspace carved here.
+#include "common.h"
+
+#include <math.h>
+#include <string.h>
+
+#include <vector>
+
+namespace {
+
+constexpr int N_GEO = 64 * 23 + 64 + 13 * 64 + 13;            // effective-weight gradients of the SDF MLP
+constexpr int N_TEX = 64 * 16 + 64 + 64 * 64 + 64 + 3 * 64 + 3;
+constexpr int N_SMALL = (64 * 23 + 64 + 64) + (13 * 64 + 13 + 13) + N_TEX + 1;   // optimizer elements
+
+// ------------------------------------------------------------------------------------------------
+// Philox4x32-10 (Salmon et al., SC'11): counter (index, stream, step lo, step hi), key = seed
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint4 philox(uint4 c, uint2 k) {
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    const uint32_t hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+    const uint32_t hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+    c = make_uint4(hi1 ^ c.y ^ k.x, lo1, hi0 ^ c.w ^ k.y, lo0);
+    k.x += 0x9E3779B9u;
+    k.y += 0xBB67AE85u;
+  }
+  return c;
+}
+__device__ __forceinline__ float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(256) void nsr_draw_kernel(uint64_t seed, int64_t step, int32_t n_rays,
+                                                       int32_t V, int32_t H, int32_t W,
+                                                       int64_t* __restrict__ index,
+                                                       int64_t* __restrict__ px,
+                                                       int64_t* __restrict__ py,
+                                                       float* __restrict__ jitter, int32_t n_random,
+                                                       float* __restrict__ pts_random,
+                                                       float* __restrict__ perturb) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
+  const uint32_t s0 = (uint32_t)step, s1 = (uint32_t)((uint64_t)step >> 32);
+  if (i < n_rays) {
+    const uint4 r = philox(make_uint4((uint32_t)i, 0u, s0, s1), key);
+    index[i] = (int64_t)(r.x % (uint32_t)V);          // torch.randint(0, n_views)
+    px[i] = (int64_t)(r.y % (uint32_t)W);
+    py[i] = (int64_t)(r.z % (uint32_t)H);
+    jitter[i] = u01(r.w);
+  }
+  if (i < n_random) {
+    const uint4 a = philox(make_uint4((uint32_t)i, 1u, s0, s1), key);
+    const uint4 b = philox(make_uint4((uint32_t)i, 2u, s0, s1), key);
+    pts_random[3 * i] = u01(a.x) * 2.0f - 1.0f;         // torch.rand([2048, 3]) * 2 - 1
+    pts_random[3 * i + 1] = u01(a.y) * 2.0f - 1.0f;
+    pts_random[3 * i + 2] = u01(a.z) * 2.0f - 1.0f;
+    // torch.randn_like: Box-Muller on (0, 1] uniforms
+    const float u1 = 1.0f - u01(b.x), u2 = u01(b.y), u3 = 1.0f - u01(b.z), u4 = u01(b.w);
+    const float r1 = sqrtf(-2.0f * logf(u1)), r2 = sqrtf(-2.0f * logf(u3));
+    perturb[3 * i] = r1 * cosf(6.28318530717958648f * u2);
+    perturb[3 * i + 1] = r1 * sinf(6.28318530717958648f * u2);
+    perturb[3 * i + 2] = r2 * cosf(6.28318530717958648f * u4);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight-norm backward + AdamW of the small tensors + weight-norm forward for the next step
+// ------------------------------------------------------------------------------------------------
+struct SmallArgs {
+  // parameters
+  float *w0_v, *w0_g, *b0, *w1_v, *w1_g, *b1;
+  float* tex[6];
+  float* variance;
+  // gradients: effective-weight gradients of the SDF MLP [g_w0 | g_b0 | g_w1 | g_b1], texture
+  // [w0 b0 w1 b1 w2 b2], d loss / d inv_s — one contiguous block, zeroed here after use
+  float* g_geo;
+  float* g_tex;
+  float* d_inv;
+  // optimizer moments, N_SMALL floats each, tensor order: w0_v w0_g b0 w1_v w1_g b1 tex[0..5] variance
+  float *m, *v;
+  // outputs for the next step
+  float *w0_eff, *w1_eff, *inv_s;
+  float lr_geo, lr_tex, lr_var, beta1, beta2, eps, wd, bc1, bc2_sqrt;
+  int32_t update;   // 0: forward part only (first call)
+};
+
+__device__ __forceinline__ void adamw_elem(float& x, float g, float& m, float& v, float lr,
+                                           const SmallArgs& a) {
+  const float omb1 = (float)(1.0 - (double)a.beta1), omb2 = (float)(1.0 - (double)a.beta2);
+  x -= lr * a.wd * x;
+  m = m + (g - m) * omb1;
+  v = a.beta2 * v + omb2 * g * g;
+  const float denom = sqrtf(v) / a.bc2_sqrt + a.eps;
+  x -= (lr / a.bc1) * m / denom;
+}
+
+__global__ __launch_bounds__(1024) void small_update_kernel(SmallArgs a) {
+  __shared__ float gv0[64 * 23], gg0[64], gv1[13 * 64], gg1[13];
+  const int t = threadIdx.x;
+  if (a.update) {
+    // ---- torch._weight_norm_interface_backward (dim 0): rows 0..63 of layer 0, 64..76 of layer 1
+    if (t < 77) {
+      const bool l0 = t < 64;
+      const int r = l0 ? t : t - 64, cols = l0 ? 23 : 64;
+      const float* vrow = (l0 ? a.w0_v : a.w1_v) + r * cols;
+      const float* grow = (l0 ? a.g_geo : a.g_geo + 64 * 23 + 64) + r * cols;
+      const float g = l0 ? a.w0_g[r] : a.w1_g[r];
+      float nn = 0.0f, dot = 0.0f;
+      for (int c = 0; c < cols; ++c) {
+        nn += vrow[c] * vrow[c];
+        dot += grow[c] * vrow[c];
+      }
+      const float norm = sqrtf(nn);
+      float* gv = l0 ? gv0 + r * 23 : gv1 + r * 64;
+      for (int c = 0; c < cols; ++c) gv[c] = (g / norm) * (grow[c] - vrow[c] * dot / (norm * norm));
+      (l0 ? gg0 : gg1)[r] = dot / norm;
+    }
+    __syncthreads();
+    // ---- AdamW, tensor by tensor (moments laid out in the same order)
+    int off = 0;
+    auto upd = [&](float* p, const float* g, int n, float lr) {
+      for (int i = t; i < n; i += 1024) {
+        float x = p[i], m = a.m[off + i], v = a.v[off + i];
+        adamw_elem(x, g[i], m, v, lr, a);
+        p[i] = x; a.m[off + i] = m; a.v[off + i] = v;
+      }
+      off += n;
+    };
+    upd(a.w0_v, gv0, 64 * 23, a.lr_geo);
+    upd(a.w0_g, gg0, 64, a.lr_geo);
+    upd(a.b0, a.g_geo + 64 * 23, 64, a.lr_geo);
+    upd(a.w1_v, gv1, 13 * 64, a.lr_geo);
+    upd(a.w1_g, gg1, 13, a.lr_geo);
+    upd(a.b1, a.g_geo + 64 * 23 + 64 + 13 * 64, 13, a.lr_geo);
+    const int tn[6] = {64 * 16, 64, 64 * 64, 64, 3 * 64, 3};
+    int go = 0;
+    for (int k = 0; k < 6; ++k) {
+      upd(a.tex[k], a.g_tex + go, tn[k], a.lr_tex);
+      go += tn[k];
+    }
+    if (t == 0) {
+      // d inv_s / d variance = 10 exp(10 variance)
+      float x = a.variance[0], m = a.m[off], v = a.v[off];
+      const float g = a.d_inv[0] * expf(x * 10.0f) * 10.0f;
+      adamw_elem(x, g, m, v, a.lr_var, a);
+      a.variance[0] = x; a.m[off] = m; a.v[off] = v;
+    }
+    __syncthreads();
+    // ---- the accumulators of the next step start from zero
+    for (int i = t; i < N_GEO; i += 1024) a.g_geo[i] = 0.0f;
+    for (int i = t; i < N_TEX; i += 1024) a.g_tex[i] = 0.0f;
+    if (t == 0) a.d_inv[0] = 0.0f;
+    __threadfence_block();
+    __syncthreads();
+  }
+  // ---- torch._weight_norm (dim 0): w = g * v / |v|_row, and inv_s = exp(10 variance)
+  if (t < 77) {
+    const bool l0 = t < 64;
+    const int r = l0 ? t : t - 64, cols = l0 ? 23 : 64;
+    const float* vrow = (l0 ? a.w0_v : a.w1_v) + r * cols;
+    const float g = l0 ? a.w0_g[r] : a.w1_g[r];
+    float nn = 0.0f;
+    for (int c = 0; c < cols; ++c) nn += vrow[c] * vrow[c];
+    const float s = g / sqrtf(nn);
+    float* out = (l0 ? a.w0_eff : a.w1_eff) + r * cols;
+    for (int c = 0; c < cols; ++c) out[c] = vrow[c] * s;
+  }
+  if (t == 128) a.inv_s[0] = expf(a.variance[0] * 10.0f);
+}
+
+// ------------------------------------------------------------------------------------------------
+// workspace layout
+// ------------------------------------------------------------------------------------------------
+struct Carve {
+  char* base;
+  int64_t off = 0;
+  template <typename T>
+  T* take(int64_t count) {
+    off = (off + 255) / 256 * 256;
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * (int64_t)sizeof(T);
+    return p;
+  }
+};
+
+struct Prefetch {   // everything one step's sample set consists of (two sets, by step parity)
+  int64_t *index, *px, *py;
+  float *jitter, *rays, *rgb, *normal, *mask, *cosines, *vw, *tmin, *tmax;
+  int32_t *counts, *offsets, *stats;
+  float *rays_o, *rays_d;
+  float *pts_random, *perturb;
+  float *points, *t_starts, *t_ends, *sorted;
+  int32_t* perm;
+  void* sort_ws;
+};
+
+struct Layout {
+  Prefetch pf[2];
+  float *scratch_ts, *scratch_te;
+  float *a_sdf, *a_grad, *a_feat;
+  void* enc_cache;
+  float *normal, *tex_in, *rgb, *alpha, *w, *comp, *d_comp, *terms;
+  float *d_sdf_all, *d_grad_all, *d_feat_all, *d_normal, *d_rgb, *d_tex_in;
+  void *tex_ws, *sdf_ws;
+  float *g_geo, *g_tex, *d_inv;      // contiguous: zeroed as one block
+  float *w0_eff, *w1_eff, *inv_s, *adam_m, *adam_v;
+  int64_t tex_ws_bytes, sdf_ws_bytes, sort_ws_bytes, enc_cache_bytes, total;
+};
+
+int32_t march_row_capacity(float radius, float step) {
+  const double diag = sqrt(3.0 * (2.0 * radius) * (2.0 * radius));
+  return (int32_t)(diag / step) + 8;
+}
+
+int carve(const dsu_nsr_driver_cfg& c, char* base, Layout& L) {
+  Carve k{base};
+  const int64_t R = c.cap_rays, N = c.cap_points, nr = c.n_random, rows = N + 2 * nr;
+  const int32_t rowcap = march_row_capacity(c.radius, c.render_step_size);
+  L.sort_ws_bytes = c.sort_bits ? dsu_spatial_sort_workspace_bytes(rows, c.sort_bits) : 0;
+  L.tex_ws_bytes = dsu_texture_bwd_workspace_bytes(N);
+  L.sdf_ws_bytes = dsu_sdf_fd_bwd_workspace_bytes(&c.grid, rows);
+  L.enc_cache_bytes = dsu_sdf_fd_enc_cache_bytes(rows, c.grid.n_levels);
+  if (L.sort_ws_bytes < 0 || L.tex_ws_bytes < 0 || L.sdf_ws_bytes < 0 || L.enc_cache_bytes < 0)
+    return DSU_EINVAL;
+  for (int p = 0; p < 2; ++p) {
+    Prefetch& f = L.pf[p];
+    f.index = k.take<int64_t>(R); f.px = k.take<int64_t>(R); f.py = k.take<int64_t>(R);
+    f.jitter = k.take<float>(R); f.rays = k.take<float>(R * 6); f.rgb = k.take<float>(R * 4);
+    f.normal = k.take<float>(R * 3); f.mask = k.take<float>(R); f.cosines = k.take<float>(R);
+    f.vw = k.take<float>(R); f.tmin = k.take<float>(R); f.tmax = k.take<float>(R);
+    f.counts = k.take<int32_t>(R); f.offsets = k.take<int32_t>(R); f.stats = k.take<int32_t>(4);
+    f.rays_o = k.take<float>(R * 3); f.rays_d = k.take<float>(R * 3);
+    f.pts_random = k.take<float>(nr * 3); f.perturb = k.take<float>(nr * 3);
+    f.points = k.take<float>(rows * 3); f.t_starts = k.take<float>(N); f.t_ends = k.take<float>(N);
+    f.sorted = k.take<float>(rows * 3); f.perm = k.take<int32_t>(rows);
+    f.sort_ws = k.take<char>(L.sort_ws_bytes > 4 ? L.sort_ws_bytes : 4);
+  }
+  L.scratch_ts = k.take<float>(R * (int64_t)rowcap);
+  L.scratch_te = k.take<float>(R * (int64_t)rowcap);
+  L.a_sdf = k.take<float>(rows); L.a_grad = k.take<float>(rows * 3); L.a_feat = k.take<float>(rows * 13);
+  L.enc_cache = k.take<char>(L.enc_cache_bytes);
+  L.normal = k.take<float>(N * 3); L.tex_in = k.take<float>(N * 16); L.rgb = k.take<float>(N * 3);
+  L.alpha = k.take<float>(N); L.w = k.take<float>(N);
+  L.comp = k.take<float>(R * 8); L.d_comp = k.take<float>(R * 8); L.terms = k.take<float>(8);
+  L.d_sdf_all = k.take<float>(rows); L.d_grad_all = k.take<float>(rows * 3);
+  L.d_feat_all = k.take<float>(rows * 13);
+  L.d_normal = k.take<float>(N * 3); L.d_rgb = k.take<float>(N * 3); L.d_tex_in = k.take<float>(N * 16);
+  L.tex_ws = k.take<char>(L.tex_ws_bytes > 4 ? L.tex_ws_bytes : 4);
+  L.sdf_ws = k.take<char>(L.sdf_ws_bytes > 4 ? L.sdf_ws_bytes : 4);
+  L.g_geo = k.take<float>(N_GEO + N_TEX + 1);
+  L.g_tex = L.g_geo ? L.g_geo + N_GEO : nullptr;
+  L.d_inv = L.g_geo ? L.g_geo + N_GEO + N_TEX : nullptr;
+  L.w0_eff = k.take<float>(64 * 23); L.w1_eff = k.take<float>(13 * 64); L.inv_s = k.take<float>(4);
+  L.adam_m = k.take<float>(N_SMALL); L.adam_v = k.take<float>(N_SMALL);
+  L.total = (k.off + 255) / 256 * 256;
+  return DSU_OK;
+}
+
+bool cfg_ok(const dsu_nsr_driver_cfg& c) {
+  return c.cap_points > 0 && c.cap_rays > 0 && c.cap_rays <= DSU_RAY_LOSS_MAX_RAYS && c.n_random > 0 &&
+         c.radius > 0.0f && c.render_step_size > 0.0f && c.image_channels >= 1 && c.image_channels <= 4 &&
+         (c.sort_bits == 0 || (c.sort_bits >= 4 && c.sort_bits <= 7)) && c.grid.n_levels <= DSU_MAX_LEVELS;
+}
+
+}  // namespace
+
+struct dsu_nsr_driver {
+  dsu_nsr_driver_cfg cfg;
+  Layout L;
+  hipStream_t side = nullptr;
+  hipEvent_t ready[2] = {nullptr, nullptr};   // side stream: samples of parity p packed, stats copied
+  hipEvent_t consumed = nullptr;              // main stream: this step no longer needs the march scratch
+  int32_t* host_stats = nullptr;              // pinned, 2 x int32[2]
+  bool have_prefetch = false;
+  int64_t pf_step = -1;
+  int32_t pf_rays = 0;
+  bool initialised = false;                   // effective weights / inv_s / zeroed accumulators
+  float aabb[6];
+  int32_t rowcap;
+  // optional HIP-event timing of the two geometry families (bench.py's roofline object)
+  bool timing = false;
+  std::vector<hipEvent_t> ev[2];              // family 0: geometry forward, 1: geometry backward
+  double work[2] = {0.0, 0.0};                // algorithmic bytes of the timed launches
+};
+
+#define DSU_TRY(expr)            \
+  do {                           \
+    const int rc__ = (expr);     \
+    if (rc__ != DSU_OK) return rc__; \
+  } while (0)
+#define DSU_HIP(expr)            \
+  do {                           \
+    if ((expr) != hipSuccess) return DSU_ELAUNCH; \
+  } while (0)
+
+namespace {
+
+// draws + ray batch + ray/box + single-pass march + offsets scan + packing + random tail + Morton
+// sort of the sample set of `step` into prefetch set `p`, on stream `s`; the two stats words
+// (total, max count) go to pinned memory.
+int enqueue_samples(dsu_nsr_driver* d, int p, int64_t step, int32_t n_rays,
+                    const dsu_nsr_step_args& a, bool injected, hipStream_t s) {
+  const dsu_nsr_driver_cfg& c = d->cfg;
+  Prefetch& f = d->L.pf[p];
+  const int64_t* index = f.index; const int64_t* px = f.px; const int64_t* py = f.py;
+  const float* jitter = f.jitter; const float* pts_random = f.pts_random;
+  const float* perturb = f.perturb;
+  const bool need_draw = !injected || !a.inj_index || !a.inj_x || !a.inj_y || !a.inj_pts_random ||
+                         !a.inj_perturb || (a.randomized && !a.inj_jitter);
+  if (need_draw)
+    DSU_TRY(dsu_nsr_draws(c.seed, step, n_rays, c.V, c.H, c.W, f.index, f.px, f.py, f.jitter,
+                          c.n_random, f.pts_random, f.perturb, s));
+  if (injected) {
+    if (a.inj_index) index = a.inj_index;
+    if (a.inj_x) px = a.inj_x;
+    if (a.inj_y) py = a.inj_y;
+    if (a.inj_jitter) jitter = a.inj_jitter;
+    if (a.inj_pts_random) pts_random = a.inj_pts_random;
+    if (a.inj_perturb) perturb = a.inj_perturb;
+  }
+  DSU_TRY(dsu_ortho_ray_batch(index, px, py, n_rays, c.c2w, c.origins, c.directions, c.images,
+                              c.image_channels, c.normals, c.masks, c.view_weights, c.H, c.W,
+                              f.rays, f.rgb, f.normal, f.mask, f.cosines, f.vw, s));
+  // rays (n,6) -> contiguous origins / directions for the marcher and the compositing kernels
+  DSU_HIP(hipMemcpy2DAsync(f.rays_o, 12, f.rays, 24, 12, n_rays, hipMemcpyDeviceToDevice, s));
+  DSU_HIP(hipMemcpy2DAsync(f.rays_d, 12, f.rays + 3, 24, 12, n_rays, hipMemcpyDeviceToDevice, s));
+  DSU_TRY(dsu_ray_aabb(f.rays_o, f.rays_d, n_rays, d->aabb, a.randomized ? jitter : nullptr,
+                       c.render_step_size, f.tmin, f.tmax, s));
+  DSU_TRY(dsu_ray_march_scratch(f.rays_o, f.rays_d, f.tmin, f.tmax, n_rays, d->aabb, a.occ_binary,
+                                a.occ_binary ? a.occ_res : 0, c.render_step_size, d->rowcap,
+                                f.counts, d->L.scratch_ts, d->L.scratch_te, s));
+  DSU_TRY(dsu_ray_offsets(f.counts, n_rays, f.offsets, f.stats, s));
+  DSU_TRY(dsu_ray_compact_points_cap(d->L.scratch_ts, d->L.scratch_te, d->rowcap, f.offsets,
+                                     f.counts, n_rays, f.rays_o, f.rays_d, f.t_starts, f.t_ends,
+                                     f.points, c.cap_points, s));
+  DSU_TRY(dsu_points_tail(f.points, (int64_t)c.cap_points + 2 * c.n_random, f.stats, pts_random,
+                          perturb, c.n_random, 1e-2f, s));
+  if (c.sort_bits)
+    DSU_TRY(dsu_spatial_sort_dev(f.points, (int64_t)c.cap_points + 2 * c.n_random, f.stats,
+                                 2 * c.n_random, c.radius, c.sort_bits, f.perm, f.sorted,
+                                 f.sort_ws, d->L.sort_ws_bytes, s));
+  DSU_HIP(hipMemcpyAsync(d->host_stats + 2 * p, f.stats, 2 * sizeof(int32_t),
+                         hipMemcpyDeviceToHost, s));
+  return DSU_OK;
+}
+
+// start/stop events around a timed family (no-ops unless timing is on)
+int mark(dsu_nsr_driver* d, int family, hipStream_t s) {
+  if (!d->timing) return DSU_OK;
+  hipEvent_t e;
+  DSU_HIP(hipEventCreate(&e));
+  DSU_HIP(hipEventRecord(e, s));
+  d->ev[family].push_back(e);
+  return DSU_OK;
+}
+
+int launch_small_update(dsu_nsr_driver* d, const dsu_nsr_step_args* a, int update, hipStream_t s) {
+  const dsu_nsr_driver_cfg& c = d->cfg;
+  SmallArgs sa;
+  sa.w0_v = c.w0_v; sa.w0_g = c.w0_g; sa.b0 = c.b0; sa.w1_v = c.w1_v; sa.w1_g = c.w1_g; sa.b1 = c.b1;
+  for (int k = 0; k < 6; ++k) sa.tex[k] = c.tex[k];
+  sa.variance = c.variance;
+  sa.g_geo = d->L.g_geo; sa.g_tex = d->L.g_tex; sa.d_inv = d->L.d_inv;
+  sa.m = d->L.adam_m; sa.v = d->L.adam_v;
+  sa.w0_eff = d->L.w0_eff; sa.w1_eff = d->L.w1_eff; sa.inv_s = d->L.inv_s;
+  sa.beta1 = c.beta1; sa.beta2 = c.beta2; sa.eps = c.adam_eps; sa.wd = c.weight_decay;
+  sa.update = update;
+  sa.lr_geo = sa.lr_tex = sa.lr_var = 0.0f;
+  sa.bc1 = sa.bc2_sqrt = 1.0f;
+  if (update) {
+    sa.lr_geo = a->lr_geometry; sa.lr_tex = a->lr_texture; sa.lr_var = a->lr_variance;
+    sa.bc1 = (float)(1.0 - pow((double)c.beta1, (double)a->adam_step));
+    sa.bc2_sqrt = (float)sqrt(1.0 - pow((double)c.beta2, (double)a->adam_step));
+  }
+  small_update_kernel<<<dim3(1), dim3(1024), 0, s>>>(sa);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int dsu_nsr_draws(uint64_t seed, int64_t step, int32_t n_rays, int32_t V, int32_t H, int32_t W,
+                  int64_t* index, int64_t* x, int64_t* y, float* jitter, int32_t n_random,
+                  float* pts_random, float* perturb, void* stream) {
+  if (n_rays < 0 || n_random < 0 || V < 1 || H < 1 || W < 1 ||
+      (n_rays && (!index || !x || !y || !jitter)) || (n_random && (!pts_random || !perturb)))
+    return DSU_EINVAL;
+  const int n = n_rays > n_random ? n_rays : n_random;
+  if (n == 0) return DSU_OK;
+  nsr_draw_kernel<<<dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream>>>(
+      seed, step, n_rays, V, H, W, index, x, y, jitter, n_random, pts_random, perturb);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int64_t dsu_nsr_driver_workspace_bytes(const dsu_nsr_driver_cfg* cfg) {
+  if (!cfg || !cfg_ok(*cfg)) return DSU_EINVAL;
+  Layout L;
+  if (carve(*cfg, nullptr, L) != DSU_OK) return DSU_EINVAL;
+  return L.total;
+}
+
+int dsu_nsr_driver_create(const dsu_nsr_driver_cfg* cfg, dsu_nsr_driver** out) {
+  if (!cfg || !out || !cfg_ok(*cfg) || !cfg->workspace) return DSU_EINVAL;
+  const void* need[] = {cfg->c2w, cfg->origins, cfg->directions, cfg->images, cfg->normals,
+                        cfg->masks, cfg->view_weights, cfg->w0_v, cfg->w0_g, cfg->b0, cfg->w1_v,
+                        cfg->w1_g, cfg->b1, cfg->variance, cfg->tex[0], cfg->tex[1], cfg->tex[2],
+                        cfg->tex[3], cfg->tex[4], cfg->tex[5]};
+  for (const void* p : need)
+    if (!p) return DSU_EINVAL;
+  dsu_nsr_driver* d = new dsu_nsr_driver();
+  d->cfg = *cfg;
+  if (carve(*cfg, (char*)cfg->workspace, d->L) != DSU_OK || d->L.total > cfg->workspace_bytes) {
+    delete d;
+    return DSU_EINVAL;
+  }
+  for (int k = 0; k < 3; ++k) {
+    d->aabb[k] = -cfg->radius;
+    d->aabb[3 + k] = cfg->radius;
+  }
+  d->rowcap = march_row_capacity(cfg->radius, cfg->render_step_size);
+  int lo = 0, hi = 0;
+  bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+            hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, hi) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&d->ready[0], hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&d->ready[1], hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&d->consumed, hipEventDisableTiming) == hipSuccess &&
+       hipHostMalloc((void**)&d->host_stats, 4 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
+  if (!ok) {
+    dsu_nsr_driver_destroy(d);
+    return DSU_ELAUNCH;
+  }
+  *out = d;
+  return DSU_OK;
+}
+
+void dsu_nsr_driver_destroy(dsu_nsr_driver* d) {
+  if (!d) return;
+  if (d->side) {
+    (void)hipStreamSynchronize(d->side);
+    (void)hipStreamDestroy(d->side);
+  }
+  for (int p = 0; p < 2; ++p)
+    if (d->ready[p]) (void)hipEventDestroy(d->ready[p]);
+  if (d->consumed) (void)hipEventDestroy(d->consumed);
+  if (d->host_stats) (void)hipHostFree(d->host_stats);
+  for (int f = 0; f < 2; ++f)
+    for (hipEvent_t e : d->ev[f]) (void)hipEventDestroy(e);
+  delete d;
+}
+
+const float* dsu_nsr_driver_terms(const dsu_nsr_driver* d) { return d ? d->L.terms : nullptr; }
+
+int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stream) {
+  if (!d || !a || a->n_rays <= 0 || a->n_rays > d->cfg.cap_rays || !a->table_img || !a->table_grad ||
+      a->active_levels == 0 || a->active_levels > d->cfg.grid.n_levels || a->adam_step < 1)
+    return DSU_EINVAL;
+  const dsu_nsr_driver_cfg& c = d->cfg;
+  Layout& L = d->L;
+  hipStream_t s = (hipStream_t)main_stream;
+  const int p = (int)(a->step & 1);
+  Prefetch& f = L.pf[p];
+  if (!d->initialised) {
+    // zeroed accumulators and optimizer moments
+    DSU_HIP(hipMemsetAsync(L.g_geo, 0, (N_GEO + N_TEX + 1) * sizeof(float), s));
+    DSU_HIP(hipMemsetAsync(L.adam_m, 0, N_SMALL * sizeof(float), s));
+    DSU_HIP(hipMemsetAsync(L.adam_v, 0, N_SMALL * sizeof(float), s));
+  }
+  if (!d->initialised || a->refresh_effective) {
+    DSU_TRY(launch_small_update(d, a, 0, s));       // effective weights and inv_s
+    d->initialised = true;
+  }
+  // ---- this step's samples: prefetched by the previous call, or produced now
+  const bool injected = a->inj_index || a->inj_x || a->inj_y || a->inj_jitter || a->inj_pts_random ||
+                        a->inj_perturb;
+  if (d->have_prefetch && d->pf_step == a->step && d->pf_rays == a->n_rays && !injected) {
+    // the host waits: no device-side cross-queue barrier on the main stream is needed afterwards
+    DSU_HIP(hipEventSynchronize(d->ready[p]));
+  } else {
+    if (d->have_prefetch) DSU_HIP(hipStreamSynchronize(d->side));   // stale: let it drain
+    DSU_TRY(enqueue_samples(d, p, a->step, a->n_rays, *a, injected, s));
+    DSU_HIP(hipStreamSynchronize(s));
+  }
+  d->have_prefetch = false;
+  const int32_t total = d->host_stats[2 * p], cmax = d->host_stats[2 * p + 1];
+  a->out_n_samples = total;
+  a->out_max_count = cmax;
+  if (total > c.cap_points || cmax > d->rowcap) return DSU_EUNSUP;
+  const int64_t n_s = total, n_r = c.n_random, n_all = n_s + 2 * n_r;
+  // dynamic ray count of the next step (neus_ortho.py:88-92)
+  int32_t next_rays = a->n_rays;
+  if (c.dynamic_ray_sampling && n_s > 0) {
+    const int tr = (int)((double)a->n_rays * ((double)c.train_num_samples / (double)n_s));
+    const int nr2 = (int)((double)a->n_rays * 0.9 + (double)tr * 0.1);
+    next_rays = nr2 < c.cap_rays ? nr2 : c.cap_rays;
+    if (next_rays < 1) next_rays = 1;
+  }
+  a->out_next_n_rays = next_rays;
+  // the march scratch may be overwritten by the next prefetch once the packing above has run:
+  // with a prefetched set it already has (same stream); otherwise it was enqueued on main
+  DSU_HIP(hipEventRecord(d->consumed, s));
+
+  const float* pts = c.sort_bits ? f.sorted : f.points;
+  const int32_t* perm = c.sort_bits ? f.perm : nullptr;
+  dsu_sdf_mlp mlp{L.w0_eff, c.b0, L.w1_eff, c.b1};
+  // ---- forward
+  const double alg_bytes = (double)n_all * (7.0 * a->active_levels * 8 * 4 + 12 + 72);
+  DSU_TRY(mark(d, 0, s));
+  DSU_TRY(dsu_sdf_fd_fwd_sorted(&c.grid, a->table_img, &mlp, pts, perm, n_all, c.radius, a->eps,
+                                a->active_levels, L.a_sdf, L.a_grad, L.a_feat, nullptr, L.enc_cache, s));
+  DSU_TRY(mark(d, 0, s));
+  if (d->timing) d->work[0] += alg_bytes;
+  if (a->prefetch_next) {
+    // behind the geometry forward: the march has the rest of this step to finish
+    DSU_HIP(hipStreamWaitEvent(d->side, d->consumed, 0));
+    dsu_nsr_step_args na = *a;
+    na.inj_index = na.inj_x = na.inj_y = nullptr;
+    na.inj_jitter = na.inj_pts_random = na.inj_perturb = nullptr;
+    DSU_TRY(enqueue_samples(d, p ^ 1, a->step + 1, next_rays, na, false, d->side));
+    DSU_HIP(hipEventRecord(d->ready[p ^ 1], d->side));
+    d->have_prefetch = true;
+    d->pf_step = a->step + 1;
+    d->pf_rays = next_rays;
+  }
+  if (n_s > 0) {
+    DSU_TRY(dsu_shade_prep_fwd(L.a_grad, L.a_feat, n_s, L.normal, L.tex_in, s));
+    dsu_tex_mlp tex{c.tex[0], c.tex[1], c.tex[2], c.tex[3], c.tex[4], c.tex[5]};
+    DSU_TRY(dsu_texture_fwd(&tex, L.tex_in, n_s, L.rgb, s));
+    DSU_TRY(dsu_neus_composite_fwd(L.a_sdf, L.normal, L.rgb, f.rays_d, f.t_starts, f.t_ends,
+                                   f.offsets, f.counts, a->n_rays, L.inv_s, a->cos_anneal_ratio,
+                                   L.alpha, L.w, L.comp, s));
+  } else {
+    DSU_HIP(hipMemsetAsync(L.comp, 0, (size_t)a->n_rays * 8 * sizeof(float), s));
+  }
+  DSU_TRY(dsu_ray_losses(L.comp, f.rgb, f.normal, f.mask, f.cosines, f.vw, a->n_rays, &c.ray_loss,
+                         L.terms, L.d_comp, s));
+  // ---- backward
+  DSU_HIP(hipMemsetAsync(L.d_feat_all + n_s * 13, 0, (size_t)(2 * n_r) * 13 * sizeof(float), s));
+  if (n_s > 0) {
+    DSU_TRY(dsu_neus_composite_bwd(L.a_sdf, L.normal, L.rgb, f.rays_d, f.t_starts, f.t_ends,
+                                   f.offsets, f.counts, a->n_rays, L.inv_s, a->cos_anneal_ratio,
+                                   L.alpha, L.w, L.d_comp, nullptr, L.d_sdf_all, L.d_normal, L.d_rgb,
+                                   L.d_inv, s));
+    dsu_tex_mlp tex{c.tex[0], c.tex[1], c.tex[2], c.tex[3], c.tex[4], c.tex[5]};
+    float* gt = L.g_tex;
+    DSU_TRY(dsu_texture_bwd(&tex, L.tex_in, L.rgb, L.d_rgb, n_s, L.d_tex_in, gt, gt + 1024,
+                            gt + 1088, gt + 5184, gt + 5248, gt + 5440, L.tex_ws, L.tex_ws_bytes, s));
+    DSU_TRY(dsu_shade_prep_bwd(L.a_grad, L.d_normal, L.d_tex_in, n_s, L.d_grad_all, L.d_feat_all, s));
+  }
+  DSU_TRY(dsu_sample_losses(L.a_sdf, L.a_grad, n_s, n_r, c.lambda_eikonal, c.lambda_sparsity,
+                            c.sparsity_scale, c.lambda_smooth, 1, L.d_sdf_all, L.d_grad_all,
+                            L.terms + 4, s));
+  float* gg = L.g_geo;
+  DSU_TRY(mark(d, 1, s));
+  DSU_TRY(dsu_sdf_fd_bwd_sorted(&c.grid, a->table_img, &mlp, pts, perm, n_all, c.radius, a->eps,
+                                a->active_levels, L.d_sdf_all, L.d_grad_all, L.d_feat_all, nullptr,
+                                a->table_grad, gg, gg + 64 * 23, gg + 64 * 23 + 64,
+                                gg + 64 * 23 + 64 + 13 * 64, L.sdf_ws, L.sdf_ws_bytes, L.enc_cache, s));
+  DSU_TRY(mark(d, 1, s));
+  if (d->timing) d->work[1] += alg_bytes;
+  // ---- optimizer step of the small tensors (the hash table's is the caller's dsu_table_adamw)
+  DSU_TRY(launch_small_update(d, a, 1, s));
+  return DSU_OK;
+}
+
+int dsu_nsr_driver_timing(dsu_nsr_driver* d, int32_t enable) {
+  if (!d) return DSU_EINVAL;
+  for (int f = 0; f < 2; ++f) {
+    for (hipEvent_t e : d->ev[f]) (void)hipEventDestroy(e);
+    d->ev[f].clear();
+    d->work[f] = 0.0;
+  }
+  d->timing = enable != 0;
+  return DSU_OK;
+}
+
+int dsu_nsr_driver_timing_read(dsu_nsr_driver* d, int32_t family, int64_t* launches,
+                               double* total_ms, double* alg_bytes) {
+  if (!d || family < 0 || family > 1 || !launches || !total_ms || !alg_bytes) return DSU_EINVAL;
+  const std::vector<hipEvent_t>& ev = d->ev[family];
+  double ms = 0.0;
+  const size_t pairs = ev.size() / 2;
+  for (size_t i = 0; i < pairs; ++i) {
+    DSU_HIP(hipEventSynchronize(ev[2 * i + 1]));
+    float t = 0.0f;
+    DSU_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1]));
+    ms += t;
+  }
+  *launches = (int64_t)pairs;
+  *total_ms = ms;
+  *alg_bytes = d->work[family];
+  return DSU_OK;
+}
+
+int dsu_nsr_driver_sync(dsu_nsr_driver* d) {
+  if (!d) return DSU_EINVAL;
+  DSU_HIP(hipStreamSynchronize(d->side));
+  d->have_prefetch = false;
+  return DSU_OK;
+}
+
+}  // extern "C"

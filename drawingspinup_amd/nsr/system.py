@@ -334,6 +334,115 @@ class SmallAdamW:
         ops.adamw_multi(entries, b1, b2, self.eps, self.wd)
 
 
+# HIP-event timing of the native driver's geometry launches (bench.py's roofline object): bench.py
+# flips "enabled"; finished drivers add their (launches, ms, algorithmic bytes) to "totals".
+native_timing = {"enabled": False, "totals": {}}
+
+
+class NativeStepDriver:
+    """The optimisation step sequenced by the library itself (csrc/nsr_driver.hip,
+    `dsu_nsr_driver_step`): per step the interpreter fills a dozen scalars and makes ONE call; the
+    ~20 launches of the step, the side-stream prefetch of the next step's samples, the random
+    draws (Philox) and the small tensors' weight-norm / AdamW run from C.  Same kernels and the
+    same order as `OrthoNeuSSystem.training_step_fused`; the hash table's AdamW (level
+    bookkeeping) and the occupancy refresh of every 16th step stay with the caller."""
+
+    def __init__(self, system):
+        import ctypes as C
+        from .. import _lib
+        self.C, self._lib = C, _lib
+        m, ds, dev = system.model, system.dataset, system.device
+        geo = m.geometry
+        lin0, lin1 = [l for l in geo.network.layers if isinstance(l, torch.nn.Linear)]
+        if not (hasattr(lin0, "weight_g") and m.texture.fused_ok and m.fused_shading):
+            raise ops.DsuError("the native step driver is built for the reference networks "
+                               "(weight-normed SDF MLP, 16-64-64-3 texture MLP)")
+        tensors = (ds.all_c2w, ds.origins, ds.directions, ds.all_images, ds.all_normals_world,
+                   ds.all_masks, ds.view_weights)
+        if not all(t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda for t in tensors):
+            raise ops.DsuError("the native step driver needs the dataset resident as contiguous f32")
+        L, oc, mc = system.config.loss, system.config.optimizer, m.config
+        c = _lib.NsrDriverCfg()
+        c.grid = geo.hashgrid.cfg.c()
+        c.radius, c.render_step_size = float(geo.radius), float(m.render_step_size)
+        c.cap_points, c.cap_rays = _PACK_CAPACITY, int(mc.max_train_num_rays)
+        c.n_random, c.sort_bits = 2048, _SPATIAL_SORT_BITS
+        c.dynamic_ray_sampling = int(bool(mc.dynamic_ray_sampling))
+        c.train_num_samples = int(system.train_num_samples)
+        for name, t in zip(("c2w", "origins", "directions", "images", "normals", "masks",
+                            "view_weights"), tensors):
+            setattr(c, name, t.data_ptr())
+        c.V, c.H, c.W, c.image_channels = (int(v) for v in ds.all_images.shape)
+        self.params = [lin0.weight_v, lin0.weight_g, lin0.bias, lin1.weight_v, lin1.weight_g,
+                       lin1.bias, *m.texture.fused_params(), m.variance.variance]
+        assert all(p.is_contiguous() and p.dtype == torch.float32 for p in self.params)
+        for name, p_ in zip(("w0_v", "w0_g", "b0", "w1_v", "w1_g", "b1"), self.params[:6]):
+            setattr(c, name, p_.data_ptr())
+        for k, p_ in enumerate(self.params[6:12]):
+            c.tex[k] = p_.data_ptr()
+        c.variance = self.params[12].data_ptr()
+        c.ray_loss = _lib.RayLossCfg(
+            float(L.rgb_p_ratio), float(L.normal_p_ratio), float(L.mask_p_ratio),
+            float(L.lambda_rgb_mse), float(L.lambda_rgb_l1 or 0.0), float(L.lambda_normal),
+            float(L.lambda_mask if ds.has_mask else 0.0), int(bool(L.geo_aware)), 0)
+        c.lambda_eikonal, c.lambda_sparsity = float(L.lambda_eikonal), float(L.lambda_sparsity)
+        c.sparsity_scale = float(L.sparsity_scale)
+        c.lambda_smooth = float(L.lambda_3d_normal_smooth) if L.lambda_3d_normal_smooth > 0 else 0.0
+        c.beta1, c.beta2 = float(oc.betas[0]), float(oc.betas[1])
+        c.adam_eps, c.weight_decay = float(oc.eps), 0.01
+        c.seed = int(torch.initial_seed()) & 0xFFFFFFFFFFFFFFFF
+        need = int(_lib.lib().dsu_nsr_driver_workspace_bytes(C.byref(c)))
+        if need < 0:
+            ops.check(need, "dsu_nsr_driver_workspace_bytes")
+        self.workspace = torch.empty(need, dtype=torch.uint8, device=dev)
+        c.workspace, c.workspace_bytes = self.workspace.data_ptr(), need
+        self.cfg = c
+        self.keep = tensors                                   # the driver holds raw pointers
+        h = C.c_void_p()
+        ops.check(_lib.lib().dsu_nsr_driver_create(C.byref(c), C.byref(h)), "dsu_nsr_driver_create")
+        self.handle = h
+        self.args = _lib.NsrStepArgs()
+        self.adam_step = 0
+        self.param_versions = [p._version for p in self.params]
+        off = int(_lib.lib().dsu_nsr_driver_terms(h)) - self.workspace.data_ptr()
+        self.terms = self.workspace[off:off + 32].view(torch.float32)
+        self.timing_on = False
+        self.dataset = ds
+
+    def set_timing(self, on):
+        if on != self.timing_on:
+            if self.timing_on:
+                self.flush_timing()
+            ops.check(self._lib.lib().dsu_nsr_driver_timing(self.handle, int(on)),
+                      "dsu_nsr_driver_timing")
+            self.timing_on = on
+
+    def flush_timing(self):
+        """Add what has been timed so far to native_timing["totals"] and start over."""
+        if not self.timing_on:
+            return
+        C = self.C
+        for fam, name in ((0, "sdf_fd_fwd"), (1, "sdf_fd_bwd")):
+            n, ms, work = C.c_int64(), C.c_double(), C.c_double()
+            ops.check(self._lib.lib().dsu_nsr_driver_timing_read(
+                self.handle, fam, C.byref(n), C.byref(ms), C.byref(work)), "dsu_nsr_driver_timing_read")
+            t = native_timing["totals"].setdefault(name, [0, 0.0, 0.0])
+            t[0] += n.value; t[1] += ms.value; t[2] += work.value
+        ops.check(self._lib.lib().dsu_nsr_driver_timing(self.handle, 1), "dsu_nsr_driver_timing")
+
+    def close(self):
+        if self.handle is not None:
+            self.flush_timing()
+            self._lib.lib().dsu_nsr_driver_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class OrthoNeuSSystem:
     def __init__(self, model_config=None, system_config=None, device="cuda", seed=123456):
         torch.manual_seed(seed)
@@ -376,7 +485,10 @@ class OrthoNeuSSystem:
         # "fused": forward and backward of a step driven kernel by kernel (no autograd graph
         # except for the texture MLP and the tiny weight-norm / variance chains);
         # "autograd": the op-by-op step through torch.autograd (cross-check, same numbers)
-        self.step_mode = os.environ.get("DSU_STEP", "fused")
+        # "native": the step sequenced by the library (NativeStepDriver) whenever no draws are
+        # injected; "fused": the same kernels sequenced from here
+        self.step_mode = os.environ.get("DSU_STEP", "native")
+        self._native, self._python_steps = None, 0
         self.use_prefetch = os.environ.get("DSU_PREFETCH", "1") != "0" and self.device.type == "cuda"
         self.fused_batch = os.environ.get("DSU_FUSED_BATCH", "1") != "0"
         self._side, self._prefetched = None, None
@@ -503,10 +615,92 @@ class OrthoNeuSSystem:
         self.table_opt.step(int(active_levels), lr)
 
     def training_step(self, inject=None):
-        if self.step_mode == "fused" and self.model.fused_shading \
-                and self.train_num_rays <= ops.RAY_LOSS_MAX_RAYS:
+        fusable = self.model.fused_shading and self.train_num_rays <= ops.RAY_LOSS_MAX_RAYS
+        native_ok = (self.step_mode == "native" and fusable and self.device.type == "cuda"
+                     and self.table_opt is not None and self.use_prefetch
+                     and self.model.config.max_train_num_rays <= ops.RAY_LOSS_MAX_RAYS)
+        # The two sequencings keep separate optimizer moments for the small tensors, so a system
+        # stays on the one it started with: native when its first step draws its own rays,
+        # Python-sequenced when the first step comes with injected draws (tests of that path).
+        if native_ok and (self._native is not None
+                          or (self._python_steps == 0 and not (inject and "batch" in inject)
+                              and (not inject or os.environ.get("DSU_STEP") == "native"))):
+            return self.training_step_native(inject)
+        self._python_steps += 1
+        if self.step_mode in ("fused", "native") and fusable:
             return self.training_step_fused(inject)
         return self.training_step_autograd(inject)
+
+    def training_step_native(self, inject=None):
+        """One optimisation step through `dsu_nsr_driver_step` (see NativeStepDriver)."""
+        import ctypes as C
+        m = self.model
+        geo, enc = m.geometry, m.geometry.hashgrid
+        m.train()
+        m.update_step(0, self.global_step)             # level / eps schedule, occupancy refresh
+        drv = self._native
+        if drv is None or drv.dataset is not self.dataset:
+            if drv is not None:
+                drv.close()
+            drv = self._native = NativeStepDriver(self)
+        drv.set_timing(bool(native_timing["enabled"]))
+        a = drv.args
+        inject = inject or {}
+        if "batch" in inject:
+            raise ValueError("the native step takes injected draws (index, x, y, ...), not a ray batch")
+        keep = []
+        for field, key, dt in (("inj_index", "index", torch.int64), ("inj_x", "x", torch.int64),
+                               ("inj_y", "y", torch.int64), ("inj_jitter", "jitter", torch.float32),
+                               ("inj_pts_random", "pts_random", torch.float32),
+                               ("inj_perturb", "perturb", torch.float32)):
+            t = inject.get(key)
+            if t is not None:
+                t = t.to(self.device, dt).contiguous()
+                keep.append(t)
+            setattr(a, field, None if t is None else t.data_ptr())
+        nxt = self.global_step + 1
+        a.step, a.n_rays = self.global_step, int(self.train_num_rays)
+        a.prefetch_next = int(not inject and not (m.config.grid_prune and nxt % 16 == 0))
+        a.active_levels, a.eps = int(geo.active_levels), float(geo._finite_difference_eps)
+        a.cos_anneal_ratio = float(m.cos_anneal_ratio)
+        self._set_lr()
+        lrs = {g.get("name"): g["lr"] for g in self.optimizer.param_groups}
+        a.lr_geometry, a.lr_texture, a.lr_variance = lrs["geometry"], lrs["texture"], lrs["variance"]
+        a.adam_step = drv.adam_step + 1
+        a.randomized = int(bool(m.randomized))
+        versions = [p._version for p in drv.params]    # load_state_dict & co. bump these
+        a.refresh_effective = int(versions != drv.param_versions)
+        drv.param_versions = versions
+        if m.config.grid_prune:
+            occ = m.occupancy_grid.binary_u8()
+            a.occ_binary, a.occ_res = occ.data_ptr(), m.occupancy_grid.res
+        else:
+            a.occ_binary, a.occ_res = None, 0
+        topt = self.table_opt
+        if topt.img is None or enc._shadow is not topt.img or not enc._shadow_locked:
+            topt.img = enc.lock_shadow()
+        a.table_img, a.table_grad = topt.img.data_ptr(), topt.grad.data_ptr()
+        rc = drv._lib.lib().dsu_nsr_driver_step(drv.handle, C.byref(a), ops.stream())
+        if rc != 0:
+            raise ops.DsuError(f"dsu_nsr_driver_step failed ({rc}): {a.out_n_samples} samples, "
+                               f"longest ray {a.out_max_count} (capacity {_PACK_CAPACITY})")
+        drv.adam_step += 1
+        n_rays = int(self.train_num_rays)
+        if m.config.dynamic_ray_sampling:
+            self.train_num_rays = int(a.out_next_n_rays)
+        self._step_table(geo.active_levels)
+        self.global_step += 1
+        t = drv.terms
+        L = self.config.loss
+        terms = {"rgb_mse": t[0]}
+        if L.lambda_rgb_l1:
+            terms["rgb_l1"] = t[1]
+        terms.update({"normal": t[2], "mask": t[3], "eikonal": t[4], "sparsity": t[5]})
+        if L.lambda_3d_normal_smooth > 0:
+            terms["normal_smooth"] = t[6]
+        self.last = {"loss": _LazyLoss(t[0:4], t[4:7]), "n_samples": int(a.out_n_samples),
+                     "n_rays": n_rays, **terms}
+        return self.last
 
     # ------------------------------------------------------------- ray batch + march (prefetchable)
     def _march_begin(self, inject=None):
@@ -514,7 +708,9 @@ class OrthoNeuSSystem:
         CURRENT stream; nothing waits for the device."""
         m = self.model
         inject = inject or {}
-        batch = self.preprocess_data(inject.get("index"), inject.get("x"), inject.get("y"))
+        # tests may hand over a whole ray batch (rays, rgb, normal, mask, cosines, view_weights)
+        batch = inject.get("batch") or \
+            self.preprocess_data(inject.get("index"), inject.get("x"), inject.get("y"))
         rays = batch["rays"]
         rays_o, rays_d = rays[:, 0:3].contiguous(), rays[:, 3:6].contiguous()
         jitter = inject.get("jitter")
@@ -810,6 +1006,8 @@ class OrthoNeuSSystem:
                       f"rays {r['n_rays']} samples {r['n_samples']}", flush=True)
         if self.table_opt is not None:
             self.table_opt.finalize()          # masked levels: apply their accumulated decay
+        if self._native is not None:
+            self._native.flush_timing()
 
     # ----------------------------------------------------------------- export
     @torch.no_grad()

@@ -585,6 +585,102 @@ typedef struct {
 int dsu_adamw_multi(const dsu_adamw_tensor* tensors, int32_t count, float beta1, float beta2,
                     float eps, float weight_decay, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Native driver of ONE NSR optimisation step: OrthoNeuSSystem.training_step
+ * (2_charactor_reconstructor/instant_nsr/systems/neus_ortho.py:79-169) over
+ * NeuSModelTextureMLP.forward_ (instant_nsr/models/neus.py:114-196), the ray batch of
+ * preprocess_data (neus_ortho.py:26-77) and the AdamW update of the SDF-MLP / texture-MLP /
+ * variance groups (configs/neuralangelo-ortho-wmask.yaml:96-127) sequenced by the library
+ * itself: the host-side cost of a step is ~20 kernel launches issued from C instead of ~1.4 ms
+ * of interpreter work (as long as the step's device time).  The hash table's own update stays the
+ * caller's dsu_table_adamw (level bookkeeping), the occupancy-grid refresh of every 16th step
+ * the caller's too (dsu_sdf_fwd + dsu_occgrid_*).
+ *
+ * All device memory is the caller's: parameters, dataset tensors and ONE workspace of
+ * dsu_nsr_driver_workspace_bytes(cfg) bytes.  The driver object owns a side stream, three
+ * events and 16 bytes of pinned host memory (the next step's rays are drawn, marched, packed
+ * and Morton-sorted on the side stream while this step's backward runs; the sample total
+ * reaches the host through the pinned words).  Random draws: counter-based Philox4x32-10 keyed
+ * by (seed, step) — reproducible, independent of the step's timing; tests inject their own.
+ * ---------------------------------------------------------------------------------- */
+typedef struct dsu_nsr_driver dsu_nsr_driver;
+typedef struct dsu_nsr_driver_cfg {
+  dsu_hashgrid_cfg grid;
+  float radius;              /* model.radius (1.0) */
+  float render_step_size;    /* 1.732 * 2 * radius / num_samples_per_ray (neus.py:59) */
+  int32_t cap_points;        /* capacity of the packed sample buffers (2^19: 2x the target) */
+  int32_t cap_rays;          /* max_train_num_rays (8192), <= DSU_RAY_LOSS_MAX_RAYS */
+  int32_t n_random;          /* 2048 regulariser points (neus.py:155) */
+  int32_t sort_bits;         /* Morton bits per axis for the evaluation order (0 = ray-major) */
+  int32_t dynamic_ray_sampling; /* neus_ortho.py:88-92 */
+  int32_t train_num_samples; /* train_num_rays * num_samples_per_ray (2^18) */
+  /* resident dataset (datasets/ortho.py:99-151), f32 contiguous */
+  const float *c2w, *origins, *directions, *images, *normals, *masks, *view_weights;
+  int32_t V, H, W, image_channels;
+  /* parameters (f32, device): SDF MLP with weight norm (network_utils.py:113-138), texture MLP,
+   * variance scalar; updated in place */
+  float *w0_v, *w0_g, *b0, *w1_v, *w1_g, *b1;
+  float* tex[6];
+  float* variance;
+  /* losses and optimizer (neuralangelo-ortho-wmask.yaml:86-127) */
+  dsu_ray_loss_cfg ray_loss;
+  float lambda_eikonal, lambda_sparsity, sparsity_scale, lambda_smooth;
+  float beta1, beta2, adam_eps, weight_decay;
+  uint64_t seed;
+  void* workspace;
+  int64_t workspace_bytes;
+} dsu_nsr_driver_cfg;
+
+typedef struct dsu_nsr_step_args {
+  int64_t step;              /* global step: RNG counter and buffer parity */
+  int32_t n_rays;            /* rays of this step */
+  int32_t prefetch_next;     /* 1: enqueue step+1's samples on the side stream */
+  uint32_t active_levels;    /* ProgressiveBandHashGrid.current_level */
+  float eps;                 /* finite-difference step (geometry.py:196-215) */
+  float cos_anneal_ratio;
+  float lr_geometry, lr_texture, lr_variance;
+  int32_t adam_step;         /* 1-based count of small-tensor updates (bias corrections) */
+  int32_t randomized;        /* stratified jitter on (model.randomized) */
+  int32_t refresh_effective; /* 1: parameters were written from outside since the last step */
+  int32_t occ_res;
+  const uint8_t* occ_binary; /* current occupancy grid (NULL = no pruning) */
+  const void* table_img;     /* f16 image of the hash table */
+  float* table_grad;         /* (entries,2) f32, accumulated into */
+  /* injected draws for THIS step (tests; any NULL = the driver's own draw) */
+  const int64_t *inj_index, *inj_x, *inj_y;
+  const float *inj_jitter, *inj_pts_random, *inj_perturb;
+  /* outputs (host) */
+  int32_t out_n_samples, out_max_count, out_next_n_rays, reserved;
+} dsu_nsr_step_args;
+
+/* The random draws of step `step` (neus_ortho.py:31-41: view / pixel triples of the ray batch;
+ * nerfacc's stratified jitter; neus.py:155-160: n_random points in [-1,1)^3 and their N(0,1)
+ * perturbation) from Philox4x32-10 with key `seed` and counter (element, stream, step): the
+ * same (seed, step) gives the same draws whatever ran before.  index in [0,V), x in [0,W), y in
+ * [0,H) as int64 (what dsu_ortho_ray_batch takes), jitter in [0,1). */
+int dsu_nsr_draws(uint64_t seed, int64_t step, int32_t n_rays, int32_t V, int32_t H, int32_t W,
+                  int64_t* index, int64_t* x, int64_t* y, float* jitter, int32_t n_random,
+                  float* pts_random, float* perturb, void* stream);
+int64_t dsu_nsr_driver_workspace_bytes(const dsu_nsr_driver_cfg* cfg);
+int dsu_nsr_driver_create(const dsu_nsr_driver_cfg* cfg, dsu_nsr_driver** out);
+void dsu_nsr_driver_destroy(dsu_nsr_driver* d);
+/* One step on `main_stream`.  DSU_EUNSUP: the step produced more samples than cap_points (or a
+ * ray more than the march scratch row holds); out_n_samples / out_max_count say how many. */
+int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* args, void* main_stream);
+/* Device pointer to the 7 loss terms of the last step: rgb_mse, rgb_l1, normal, mask, eikonal,
+ * sparsity, normal_smooth (each already multiplied by its lambda). */
+const float* dsu_nsr_driver_terms(const dsu_nsr_driver* d);
+/* HIP-event timing of the two geometry launches of a step (family 0: dsu_sdf_fd_fwd_sorted,
+ * 1: dsu_sdf_fd_bwd_sorted) on the stream they run on: enable (resets) / disable, then read the
+ * number of timed launches, their summed duration and their algorithmic bytes
+ * (points x (7 x active_levels x 8 x 4 + 84)). */
+int dsu_nsr_driver_timing(dsu_nsr_driver* d, int32_t enable);
+int dsu_nsr_driver_timing_read(dsu_nsr_driver* d, int32_t family, int64_t* launches,
+                               double* total_ms, double* alg_bytes);
+/* Wait for the side stream and drop a pending prefetch (before the caller changes the ray count,
+ * the dataset or the occupancy grid behind the driver's back). */
+int dsu_nsr_driver_sync(dsu_nsr_driver* d);
+
 /* mcubes.smooth on the export's binary volume (MarchingCubeHelper.forward,
  * instant_nsr/models/geometry.py:57-58 -> PyMCubes' constrained smoothing): the weighted-Jacobi
  * iteration on the compacted band voxels, float64.  nbr (6, nv) int32: slot of the -x,+x,-y,+y,

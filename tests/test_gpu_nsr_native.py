@@ -1,0 +1,142 @@
+"""The NSR optimisation step sequenced by the library (csrc/nsr_driver.hip, dsu_nsr_driver_step)
+against the same step sequenced from Python (OrthoNeuSSystem.training_step_fused, itself pinned to
+the reference's training_step by tests/test_gpu_nsr_reference_step.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from drawingspinup_amd import _lib, ops
+from drawingspinup_amd.nsr.system import OrthoData, OrthoNeuSSystem
+
+pytestmark = pytest.mark.gpu
+
+
+def _draws(dev, seed, step, n_rays, n_random, V=6, H=300, W=500):
+    i64 = lambda: torch.empty(n_rays, dtype=torch.int64, device=dev)
+    idx, x, y = i64(), i64(), i64()
+    jit = torch.empty(n_rays, device=dev)
+    pr, pe = torch.empty(n_random, 3, device=dev), torch.empty(n_random, 3, device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    ops.check(_lib.lib().dsu_nsr_draws(seed, step, n_rays, V, H, W, p(idx), p(x), p(y), p(jit),
+                                       n_random, p(pr), p(pe), ops.stream()), "dsu_nsr_draws")
+    return idx, x, y, jit, pr, pe
+
+
+def test_philox_draws_have_the_right_ranges_and_moments(dev):
+    n = 1 << 16
+    idx, x, y, jit, pr, pe = _draws(dev, 1234, 7, n, n)
+    assert int(idx.min()) == 0 and int(idx.max()) == 5
+    assert int(x.min()) == 0 and int(x.max()) == 499 and int(y.min()) == 0 and int(y.max()) == 299
+    np.testing.assert_allclose(np.bincount(idx.cpu().numpy(), minlength=6) / n, 1 / 6, atol=0.01)
+    assert 0.0 <= float(jit.min()) and float(jit.max()) < 1.0
+    assert abs(float(jit.mean()) - 0.5) < 0.01 and abs(float(jit.var()) - 1 / 12) < 0.003
+    assert -1.0 <= float(pr.min()) and float(pr.max()) < 1.0
+    assert abs(float(pr.mean())) < 0.01 and abs(float(pr.var()) - 1 / 3) < 0.01
+    assert abs(float(pe.mean())) < 0.01 and abs(float(pe.var()) - 1.0) < 0.02
+    assert abs(float((pe ** 4).mean()) - 3.0) < 0.15                     # normal kurtosis
+    c = np.corrcoef(pe.cpu().numpy().T)
+    assert np.abs(c - np.eye(3)).max() < 0.02                              # independent components
+    assert abs(float(torch.corrcoef(torch.stack([x.float(), y.float()]))[0, 1])) < 0.02
+    # same (seed, step) -> same draws; another step or seed -> different ones
+    again = _draws(dev, 1234, 7, n, n)
+    assert all(torch.equal(a, b) for a, b in zip((idx, x, y, jit, pr, pe), again))
+    assert not torch.equal(_draws(dev, 1234, 8, n, n)[3], jit)
+    assert not torch.equal(_draws(dev, 1235, 7, n, n)[3], jit)
+    # a prefix of the rays does not depend on how many are drawn
+    assert torch.equal(_draws(dev, 1234, 7, 100, 10)[3], jit[:100])
+
+
+def _system(dev, seed, mode):
+    ds = OrthoData.synthetic_sphere(256, device=dev)
+    sysm = OrthoNeuSSystem(device=dev, seed=seed)
+    sysm.dataset = ds
+    sysm.step_mode = mode
+    return sysm, ds
+
+
+def _inject(ds, n, seed, dev):
+    g = torch.Generator().manual_seed(seed)
+    return {"index": torch.randint(0, len(ds.all_masks), (n,), generator=g).to(dev),
+            "x": torch.randint(0, ds.w, (n,), generator=g).to(dev),
+            "y": torch.randint(0, ds.h, (n,), generator=g).to(dev),
+            "jitter": torch.rand(n, generator=g).to(dev),
+            "pts_random": (torch.rand(2048, 3, generator=g) * 2 - 1).to(dev),
+            "perturb": torch.randn(2048, 3, generator=g).to(dev)}
+
+
+def test_native_step_follows_the_python_sequenced_step(dev):
+    """Same parameters, same injected draws, real learning rates: after every one of 6 steps the
+    sample count, the ray count of the next step, the seven loss terms and (at the end) every
+    parameter and the hash table agree.  Differences: summation order of atomics and of the
+    weight-norm reductions only."""
+    a, ds = _system(dev, 5, "fused")
+    b, _ = _system(dev, 5, "native")
+    b.model.load_state_dict(a.model.state_dict())
+    for s in range(6):
+        inj = _inject(ds, int(a.train_num_rays), 100 + s, dev)
+        ra = a.training_step_fused(dict(inj))
+        rb = b.training_step_native(dict(inj))
+        assert ra["n_samples"] == rb["n_samples"] and ra["n_rays"] == rb["n_rays"]
+        assert a.train_num_rays == b.train_num_rays
+        for k in ("rgb_mse", "normal", "mask", "eikonal", "sparsity", "normal_smooth"):
+            va, vb = float(ra[k]), float(rb[k])
+            assert abs(va - vb) <= 2e-4 * max(abs(va), 1e-3), (s, k, va, vb)
+        assert abs(float(ra["loss"]) - float(rb["loss"])) < 2e-4 * abs(float(ra["loss"]))
+    assert b._native is not None and b._native.adam_step == 6
+    pa, pb = dict(a.model.named_parameters()), dict(b.model.named_parameters())
+    for n in pa:
+        x, y = pa[n].detach().float(), pb[n].detach().float()
+        scale = float(x.abs().max()) + 1e-12
+        assert float((x - y).abs().max()) / scale < 2e-3, n
+    ea, eb = a.model.geometry.hashgrid, b.model.geometry.hashgrid
+    assert torch.equal(eb.table_f16(), eb.params.detach().half())          # image follows the master
+    moved = (ea.params.detach() - b.model.geometry.hashgrid.params.detach()).abs().max()
+    assert float(moved) < 2e-4                                              # lr 1e-3 x 6 steps of Adam
+
+
+def test_native_training_converges_with_prefetch_and_refresh(dev):
+    """The default path: own Philox draws, the next step's samples prefetched on the side stream,
+    occupancy refresh every 16 steps (no prefetch across it), level switch not reached.  The loss
+    falls as it does on the Python-sequenced path and the reconstructed volume is the sphere."""
+    sysm, ds = _system(dev, 3, "native")
+    losses, counts = [], []
+    for s in range(150):
+        r = sysm.training_step()
+        counts.append((r["n_samples"], r["n_rays"]))
+        if s % 10 == 4:
+            losses.append(float(r["loss"]))
+    assert sysm._native is not None and sysm._python_steps == 0
+    assert np.isfinite(losses).all() and losses[-1] < 0.6 * losses[0]
+    assert all(0 < n <= (1 << 19) for n, _ in counts)
+    assert counts[-1][1] > counts[0][1]                       # dynamic ray count grew (neus_ortho.py:88-92)
+    ref, _ = _system(dev, 3, "fused")
+    for s in range(150):
+        rr = ref.training_step_fused()
+    assert abs(losses[-1] - float(rr["loss"])) < 0.35 * float(rr["loss"])
+    coarse, fine, vmin, vmax = sysm.export_levels(128)
+    vol = float((coarse <= 0).float().mean()) * 8.0
+    assert 0.3 < vol < 0.75                                    # sphere r = 0.5: 0.524
+    # two systems with the same seed draw the same rays: the native path is reproducible
+    again, _ = _system(dev, 3, "native")
+    c2 = [(lambda r: (r["n_samples"], r["n_rays"]))(again.training_step()) for _ in range(15)]
+    assert c2 == counts[:15]
+
+
+def test_native_step_timing_counters(dev):
+    from drawingspinup_amd.nsr import system as S
+    sysm, _ = _system(dev, 9, "native")
+    S.native_timing["totals"].clear()
+    S.native_timing["enabled"] = True
+    try:
+        for _ in range(5):
+            sysm.training_step()
+        sysm._native.flush_timing()
+    finally:
+        S.native_timing["enabled"] = False
+    t = S.native_timing["totals"]
+    assert t["sdf_fd_bwd"][0] == 5 and t["sdf_fd_fwd"][0] == 5
+    assert 0.05 < t["sdf_fd_bwd"][1] / 5 < 5.0                 # ms per launch
+    assert t["sdf_fd_bwd"][2] > 5 * 200000 * (7 * 4 * 32 + 84) * 0.5
+    S.native_timing["totals"].clear()

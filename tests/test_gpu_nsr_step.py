@@ -341,6 +341,7 @@ def test_side_stream_packing_matches_main_stream_packing(dev):
         ds = OrthoData.synthetic_sphere(256, device=dev)
         sysm = OrthoNeuSSystem(device=dev, seed=11)
         sysm.dataset = ds
+        sysm.step_mode = "fused"                             # the Python-sequenced step is under test
         sysm.pack_on_side_stream = pack
         out = []
         for _ in range(40):
