@@ -59,7 +59,12 @@ class Encoding(nn.Module):
         call (one 15 us pass over 12.6 M entries)."""
         p = self.params
         if self._shadow_locked and self._shadow is not None and self._shadow.device == p.device:
-            return self._shadow          # maintained by the fused table optimizer (TableAdamW)
+            if self._shadow_version == p._version:
+                return self._shadow      # maintained by the fused table optimizer (TableAdamW)
+            # somebody wrote the master parameters through torch (load_state_dict, a checkpoint
+            # resume, a test fixture): the fused kernels write through raw pointers and never bump
+            # the version, so a bump means the image is stale.  Rebuild; the optimizer re-locks.
+            self._shadow_locked = False
         if (self._shadow is None or self.training or self._shadow_version != p._version
                 or self._shadow.device != p.device):
             self._shadow = p.detach().to(torch.float16).contiguous()

@@ -273,6 +273,14 @@ class TableAdamW:
                 ops.table_decay(self.enc.params.data, self.img, a, b - a, self.pending)
             self.active = upto
 
+    def activate(self, active_levels):
+        """Called when the level schedule moves, BEFORE the step's forward: a level that is
+        switched on enters its first forward / backward with its accumulated decay applied, as it
+        would under the dense optimizer."""
+        if self.img is None or self.enc._shadow is not self.img or not self.enc._shadow_locked:
+            self.img = self.enc.lock_shadow()
+        self._catch_up(max(active_levels, self.active))
+
     def step(self, active_levels, lr=None):
         lr = self.lr if lr is None else lr
         if self.img is None or self.enc._shadow is not self.img or not self.enc._shadow_locked:
@@ -462,6 +470,9 @@ class OrthoNeuSSystem:
         self.keep_table_grad = False
         if self.device.type == "cuda" and os.environ.get("DSU_TABLE_ADAM", "1") != "0":
             self.table_opt = TableAdamW(enc, dict(oc.params)["geometry"], tuple(oc.betas), oc.eps)
+            # whoever reads the parameters (checkpoint, export) sees the masked levels with their
+            # lazily accumulated weight decay applied
+            self.model.register_state_dict_pre_hook(lambda *a, **k: self.table_opt.finalize())
         groups = [{"params": [p for p in getattr(self.model, n).parameters()
                               if self.table_opt is None or p is not enc.params],
                    "name": n, "lr": lr}
@@ -677,8 +688,7 @@ class OrthoNeuSSystem:
         else:
             a.occ_binary, a.occ_res = None, 0
         topt = self.table_opt
-        if topt.img is None or enc._shadow is not topt.img or not enc._shadow_locked:
-            topt.img = enc.lock_shadow()
+        topt.activate(int(geo.active_levels))
         a.table_img, a.table_grad = topt.img.data_ptr(), topt.grad.data_ptr()
         rc = drv._lib.lib().dsu_nsr_driver_step(drv.handle, C.byref(a), ops.stream())
         if rc != 0:
@@ -803,6 +813,8 @@ class OrthoNeuSSystem:
         m.train()
         inject = inject or {}
         m.update_step(0, self.global_step)
+        if self.table_opt is not None:
+            self.table_opt.activate(int(geo.active_levels))
         prep = self._take_prefetch() if not inject else None
         if prep is None:
             prep = self._march_begin(inject)
@@ -1019,6 +1031,8 @@ class OrthoNeuSSystem:
         normal.  `front_mask`: (H,W) uint8 tensor, already rotated as ortho.py:155-156 does.
         Returns {verts (N,3) f64, faces (M,3) i64, vert_colors (N,3) or None, level, ...}."""
         from . import mesh as M
+        if self.table_opt is not None:
+            self.table_opt.finalize()          # loops that call training_step() directly never ran it
         self.model.eval()
         fine, coarse = M.isosurface(self.model, front_mask, resolution)
         fine["coarse_level"] = coarse["level"]
