@@ -112,6 +112,8 @@ _PROTOS = {
                               c_f32, c_u32, P, P, P, P, P, P],
     "dsu_sdf_fd_bwd_sorted": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, P, c_i64, c_f32,
                               c_f32, c_u32, P, P, P, P, P, P, P, P, P, P, c_i64, P, P],
+    "dsu_sdf_fd_bwd_sorted_mid": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, P, c_i64, c_f32,
+                                  c_f32, c_u32, P, P, P, P, P, P, P, P, P, P, c_i64, P, P, P],
     "dsu_inpaint_telea_u8c3": [P, P, c_i32, c_i32, c_i32, P],
     "dsu_table_adamw": [P, P, P, P, P, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, P],
     "dsu_table_decay": [P, P, c_i64, c_f32, P],

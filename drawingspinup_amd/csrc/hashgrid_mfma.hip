@@ -1083,20 +1083,46 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
       __builtin_amdgcn_wave_barrier();
       qn = 0;
     };
+    // Software pipeline over the flattened (chunk, evaluation) iterations: the dIn pair of the
+    // NEXT iteration and the position of the NEXT chunk are requested before this iteration's
+    // arithmetic.  As written first, every iteration issued its 8-byte load and waited for it at
+    // once (`global_load_dwordx2` + `s_waitcnt vmcnt(0)`): 7 x levels x chunks round trips to
+    // memory per wave at two waves per SIMD — 47 % of the kernel's wave cycles were spent parked
+    // (SQ_WAIT_ANY, profiles/round3_sq_nsr_pass1_start.txt).  Loads are unconditional from clamped
+    // addresses (no exec-mask region around them); invalid lanes zero the value instead.
+    const int64_t w0 = r0 + wave * 64;
+    const int64_t last = r1 - 1;
+    float pn[3];
+    float2 dn;
+    {
+      const int64_t i0 = w0 + lane < r1 ? w0 + lane : last;
+      pn[0] = pts[i0 * 3]; pn[1] = pts[i0 * 3 + 1]; pn[2] = pts[i0 * 3 + 2];
+      dn = dinbuf[(size_t)lev * n + i0];
+    }
 #pragma unroll 1
-    for (int64_t wbase = r0 + wave * 64; wbase < r1; wbase += blockDim.x) {   // wave-uniform trip count
+    for (int64_t wbase = w0; wbase < r1; wbase += blockDim.x) {   // wave-uniform trip count
       const int64_t i = wbase + lane;
       const bool valid = i < r1;
-      const int64_t ii = valid ? i : r1 - 1;
-      const float p[3] = {pts[ii * 3], pts[ii * 3 + 1], pts[ii * 3 + 2]};
+      const int64_t ii = valid ? i : last;
+      const float p[3] = {pn[0], pn[1], pn[2]};
+      const int64_t inext = i + blockDim.x < r1 ? i + blockDim.x : last;   // clamped: harmless re-read
 #pragma unroll 1
       for (int e = 0; e < 7; ++e) {
+        float2 d = dn;
+        if (e == 2) {   // wave-uniform: the next chunk's position, four iterations ahead of its use
+          pn[0] = pts[inext * 3]; pn[1] = pts[inext * 3 + 1]; pn[2] = pts[inext * 3 + 2];
+        }
+        {
+          const bool wrap = e == 6;
+          const int64_t in_ = wrap ? inext : ii;
+          dn = dinbuf[((size_t)(wrap ? 0 : e + 1) * active + lev) * n + in_];
+        }
+        d.x = valid ? d.x : 0.0f;
+        d.y = valid ? d.y : 0.0f;
         float q[3];
         fd_point(p, e, eps, radius, q);
         const float cx = contract(q[0], radius), cy = contract(q[1], radius),
                     cz = contract(q[2], radius);
-        float2 d = make_float2(0.0f, 0.0f);
-        if (valid) d = dinbuf[((size_t)e * active + lev) * n + i];
         const CellPos cp = cell_of(l_scale, cx, cy, cz);
         float v[16];
 #pragma unroll
@@ -1335,6 +1361,18 @@ int dsu_sdf_fd_bwd_sorted(const dsu_hashgrid_cfg* cfg, const void* table_f16, co
                    const float* d_feature, const float* d_laplace, float* grad_table,
                    float* g_w0, float* g_b0, float* g_w1, float* g_b1, void* workspace,
                    int64_t workspace_bytes, const void* enc_cache, void* stream) {
+  return dsu_sdf_fd_bwd_sorted_mid(cfg, table_f16, mlp, pts, perm, n, radius, eps, active_levels,
+                                   d_sdf, d_grad, d_feature, d_laplace, grad_table, g_w0, g_b0, g_w1,
+                                   g_b1, workspace, workspace_bytes, enc_cache, nullptr, stream);
+}
+
+int dsu_sdf_fd_bwd_sorted_mid(const dsu_hashgrid_cfg* cfg, const void* table_f16,
+                              const dsu_sdf_mlp* mlp, const float* pts, const int32_t* perm,
+                              int64_t n, float radius, float eps, uint32_t active_levels,
+                              const float* d_sdf, const float* d_grad, const float* d_feature,
+                              const float* d_laplace, float* grad_table, float* g_w0, float* g_b0,
+                              float* g_w1, float* g_b1, void* workspace, int64_t workspace_bytes,
+                              const void* enc_cache, void* mid_event, void* stream) {
   if (use_valu(false) && perm) return DSU_EUNSUP;
   if (use_valu(false))
     return dsu_sdf_fd_bwd_valu(cfg, table_f16, mlp, pts, n, radius, eps, active_levels, d_sdf,
@@ -1375,6 +1413,9 @@ int dsu_sdf_fd_bwd_sorted(const dsu_hashgrid_cfg* cfg, const void* table_f16, co
           (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
           d_grad, d_feature, d_laplace, grad_table, (float*)workspace, (const __half2*)enc_cache,
           dinbuf, perm, ablate);
+      // the MLP part holds every SIMD with one 458-register wave; what a caller wants to run
+      // beside the rest of the backward (two 96-register waves per SIMD) waits for this event
+      if (mid_event && hipEventRecord((hipEvent_t)mid_event, s) != hipSuccess) return DSU_ELAUNCH;
       k2<<<dim3(sblocks), dim3(SC_THREADS), shm2, s>>>(m, pts, n, radius, eps, active_levels,
                                                       dinbuf, grad_table);
       reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 63) / 64), dim3(1024), 0, s>>>(
@@ -1383,6 +1424,7 @@ int dsu_sdf_fd_bwd_sorted(const dsu_hashgrid_cfg* cfg, const void* table_f16, co
     DSU_CHECK_LAUNCH();
     return DSU_OK;
   }
+  if (mid_event && hipEventRecord((hipEvent_t)mid_event, s) != hipSuccess) return DSU_ELAUNCH;
   const size_t shm = (size_t)BWD_LDS_F * sizeof(float);
   DSU_DISPATCH_NL(cfg->n_levels, {
     auto k0 = enc_cache ? sdf_fd_bwd_mfma_kernel<NL, false, true>

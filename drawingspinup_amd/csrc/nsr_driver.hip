@@ -112,77 +112,130 @@ __device__ __forceinline__ void adamw_elem(float& x, float g, float& m, float& v
 }
 
 __global__ __launch_bounds__(1024) void small_update_kernel(SmallArgs a) {
-  __shared__ float gv0[64 * 23], gg0[64], gv1[13 * 64], gg1[13];
+  // Everything the kernel touches more than once sits in LDS: the first version walked the rows of
+  // the weight-norm reductions with dependent global loads from 77 threads (36 us per step for
+  // 8 k elements of work).
+  __shared__ float s_g[N_GEO];                       // [g_w0 | g_b0 | g_w1 | g_b1] effective-weight grads
+  __shared__ float s_v0[64 * 23], s_v1[13 * 64];     // weight_v (updated in place below)
+  __shared__ float s_gain[77], s_norm[77], s_dot[77];   // weight_g, |v|_row, <grad_w, v>_row
   const int t = threadIdx.x;
+  for (int i = t; i < 64 * 23; i += 1024) s_v0[i] = a.w0_v[i];
+  for (int i = t; i < 13 * 64; i += 1024) s_v1[i] = a.w1_v[i];
+  if (t < 77) s_gain[t] = t < 64 ? a.w0_g[t] : a.w1_g[t - 64];
+  if (a.update)
+    for (int i = t; i < N_GEO; i += 1024) s_g[i] = a.g_geo[i];
+  __syncthreads();
   if (a.update) {
     // ---- torch._weight_norm_interface_backward (dim 0): rows 0..63 of layer 0, 64..76 of layer 1
     if (t < 77) {
       const bool l0 = t < 64;
       const int r = l0 ? t : t - 64, cols = l0 ? 23 : 64;
-      const float* vrow = (l0 ? a.w0_v : a.w1_v) + r * cols;
-      const float* grow = (l0 ? a.g_geo : a.g_geo + 64 * 23 + 64) + r * cols;
-      const float g = l0 ? a.w0_g[r] : a.w1_g[r];
+      const float* vrow = (l0 ? s_v0 : s_v1) + r * cols;
+      const float* grow = (l0 ? s_g : s_g + 64 * 23 + 64) + r * cols;
       float nn = 0.0f, dot = 0.0f;
       for (int c = 0; c < cols; ++c) {
         nn += vrow[c] * vrow[c];
         dot += grow[c] * vrow[c];
       }
-      const float norm = sqrtf(nn);
-      float* gv = l0 ? gv0 + r * 23 : gv1 + r * 64;
-      for (int c = 0; c < cols; ++c) gv[c] = (g / norm) * (grow[c] - vrow[c] * dot / (norm * norm));
-      (l0 ? gg0 : gg1)[r] = dot / norm;
+      s_norm[t] = sqrtf(nn);
+      s_dot[t] = dot;
     }
     __syncthreads();
-    // ---- AdamW, tensor by tensor (moments laid out in the same order)
+    // ---- AdamW, tensor by tensor (moments laid out in the same order); updated weight_v /
+    // weight_g also go back to LDS for the forward part
     int off = 0;
-    auto upd = [&](float* p, const float* g, int n, float lr) {
-      for (int i = t; i < n; i += 1024) {
-        float x = p[i], m = a.m[off + i], v = a.v[off + i];
-        adamw_elem(x, g[i], m, v, lr, a);
-        p[i] = x; a.m[off + i] = m; a.v[off + i] = v;
-      }
-      off += n;
-    };
-    upd(a.w0_v, gv0, 64 * 23, a.lr_geo);
-    upd(a.w0_g, gg0, 64, a.lr_geo);
-    upd(a.b0, a.g_geo + 64 * 23, 64, a.lr_geo);
-    upd(a.w1_v, gv1, 13 * 64, a.lr_geo);
-    upd(a.w1_g, gg1, 13, a.lr_geo);
-    upd(a.b1, a.g_geo + 64 * 23 + 64 + 13 * 64, 13, a.lr_geo);
+    for (int i = t; i < 64 * 23; i += 1024) {          // layer-0 weight_v
+      const int r = i / 23;
+      const float nrm = s_norm[r];
+      const float g = (s_gain[r] / nrm) * (s_g[i] - s_v0[i] * s_dot[r] / (nrm * nrm));
+      float x = s_v0[i], m = a.m[off + i], v = a.v[off + i];
+      adamw_elem(x, g, m, v, a.lr_geo, a);
+      a.w0_v[i] = x; a.m[off + i] = m; a.v[off + i] = v;
+      s_v0[i] = x;                                     // same thread reads / writes element i
+    }
+    off += 64 * 23;
+    float new_gain = 0.0f;
+    if (t < 64) {                                      // layer-0 weight_g
+      float x = s_gain[t], m = a.m[off + t], v = a.v[off + t];
+      adamw_elem(x, s_dot[t] / s_norm[t], m, v, a.lr_geo, a);
+      a.w0_g[t] = x; a.m[off + t] = m; a.v[off + t] = v;
+      new_gain = x;
+    }
+    off += 64;
+    if (t < 64) {                                      // layer-0 bias
+      float x = a.b0[t], m = a.m[off + t], v = a.v[off + t];
+      adamw_elem(x, s_g[64 * 23 + t], m, v, a.lr_geo, a);
+      a.b0[t] = x; a.m[off + t] = m; a.v[off + t] = v;
+    }
+    off += 64;
+    for (int i = t; i < 13 * 64; i += 1024) {          // layer-1 weight_v
+      const int r = i / 64;
+      const float nrm = s_norm[64 + r];
+      const float g = (s_gain[64 + r] / nrm) *
+                      (s_g[64 * 23 + 64 + i] - s_v1[i] * s_dot[64 + r] / (nrm * nrm));
+      float x = s_v1[i], m = a.m[off + i], v = a.v[off + i];
+      adamw_elem(x, g, m, v, a.lr_geo, a);
+      a.w1_v[i] = x; a.m[off + i] = m; a.v[off + i] = v;
+      s_v1[i] = x;
+    }
+    off += 13 * 64;
+    float new_gain1 = 0.0f;
+    if (t < 13) {                                      // layer-1 weight_g
+      float x = s_gain[64 + t], m = a.m[off + t], v = a.v[off + t];
+      adamw_elem(x, s_dot[64 + t] / s_norm[64 + t], m, v, a.lr_geo, a);
+      a.w1_g[t] = x; a.m[off + t] = m; a.v[off + t] = v;
+      new_gain1 = x;
+    }
+    off += 13;
+    if (t < 13) {                                      // layer-1 bias
+      float x = a.b1[t], m = a.m[off + t], v = a.v[off + t];
+      adamw_elem(x, s_g[64 * 23 + 64 + 13 * 64 + t], m, v, a.lr_geo, a);
+      a.b1[t] = x; a.m[off + t] = m; a.v[off + t] = v;
+    }
+    off += 13;
     const int tn[6] = {64 * 16, 64, 64 * 64, 64, 3 * 64, 3};
     int go = 0;
-    for (int k = 0; k < 6; ++k) {
-      upd(a.tex[k], a.g_tex + go, tn[k], a.lr_tex);
+    for (int k = 0; k < 6; ++k) {                      // texture MLP
+      float* p = a.tex[k];
+      for (int i = t; i < tn[k]; i += 1024) {
+        float x = p[i], m = a.m[off + i], v = a.v[off + i];
+        adamw_elem(x, a.g_tex[go + i], m, v, a.lr_tex, a);
+        p[i] = x; a.m[off + i] = m; a.v[off + i] = v;
+      }
+      off += tn[k];
       go += tn[k];
     }
-    if (t == 0) {
+    if (t == 1023) {
       // d inv_s / d variance = 10 exp(10 variance)
       float x = a.variance[0], m = a.m[off], v = a.v[off];
       const float g = a.d_inv[0] * expf(x * 10.0f) * 10.0f;
       adamw_elem(x, g, m, v, a.lr_var, a);
       a.variance[0] = x; a.m[off] = m; a.v[off] = v;
+      a.inv_s[0] = expf(x * 10.0f);
+      a.d_inv[0] = 0.0f;
     }
-    __syncthreads();
+    __syncthreads();                                   // every read of s_gain / g_tex is done
+    if (t < 64) s_gain[t] = new_gain;
+    if (t < 13) s_gain[64 + t] = new_gain1;
     // ---- the accumulators of the next step start from zero
     for (int i = t; i < N_GEO; i += 1024) a.g_geo[i] = 0.0f;
     for (int i = t; i < N_TEX; i += 1024) a.g_tex[i] = 0.0f;
-    if (t == 0) a.d_inv[0] = 0.0f;
-    __threadfence_block();
     __syncthreads();
+  } else if (t == 1023) {
+    a.inv_s[0] = expf(a.variance[0] * 10.0f);
   }
-  // ---- torch._weight_norm (dim 0): w = g * v / |v|_row, and inv_s = exp(10 variance)
+  // ---- torch._weight_norm (dim 0): w = g * v / |v|_row
   if (t < 77) {
     const bool l0 = t < 64;
     const int r = l0 ? t : t - 64, cols = l0 ? 23 : 64;
-    const float* vrow = (l0 ? a.w0_v : a.w1_v) + r * cols;
-    const float g = l0 ? a.w0_g[r] : a.w1_g[r];
+    const float* vrow = (l0 ? s_v0 : s_v1) + r * cols;
     float nn = 0.0f;
     for (int c = 0; c < cols; ++c) nn += vrow[c] * vrow[c];
-    const float s = g / sqrtf(nn);
-    float* out = (l0 ? a.w0_eff : a.w1_eff) + r * cols;
-    for (int c = 0; c < cols; ++c) out[c] = vrow[c] * s;
+    s_norm[t] = s_gain[t] / sqrtf(nn);
   }
-  if (t == 128) a.inv_s[0] = expf(a.variance[0] * 10.0f);
+  __syncthreads();
+  for (int i = t; i < 64 * 23; i += 1024) a.w0_eff[i] = s_v0[i] * s_norm[i / 23];
+  for (int i = t; i < 13 * 64; i += 1024) a.w1_eff[i] = s_v1[i] * s_norm[64 + i / 64];
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -200,7 +253,7 @@ struct Carve {
   }
 };
 
-struct Prefetch {   // everything one step's sample set consists of (two sets, by step parity)
+struct Prefetch {   // everything one step's sample set consists of (three sets, by step % 3)
   int64_t *index, *px, *py;
   float *jitter, *rays, *rgb, *normal, *mask, *cosines, *vw, *tmin, *tmax;
   int32_t *counts, *offsets, *stats;
@@ -212,7 +265,7 @@ struct Prefetch {   // everything one step's sample set consists of (two sets, b
 };
 
 struct Layout {
-  Prefetch pf[2];
+  Prefetch pf[3];
   float *scratch_ts, *scratch_te;
   float *a_sdf, *a_grad, *a_feat;
   void* enc_cache;
@@ -239,7 +292,7 @@ int carve(const dsu_nsr_driver_cfg& c, char* base, Layout& L) {
   L.enc_cache_bytes = dsu_sdf_fd_enc_cache_bytes(rows, c.grid.n_levels);
   if (L.sort_ws_bytes < 0 || L.tex_ws_bytes < 0 || L.sdf_ws_bytes < 0 || L.enc_cache_bytes < 0)
     return DSU_EINVAL;
-  for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < 3; ++p) {
     Prefetch& f = L.pf[p];
     f.index = k.take<int64_t>(R); f.px = k.take<int64_t>(R); f.py = k.take<int64_t>(R);
     f.jitter = k.take<float>(R); f.rays = k.take<float>(R * 6); f.rgb = k.take<float>(R * 4);
@@ -284,13 +337,17 @@ bool cfg_ok(const dsu_nsr_driver_cfg& c) {
 struct dsu_nsr_driver {
   dsu_nsr_driver_cfg cfg;
   Layout L;
+  // Sample sets are produced one step ahead of their use and consumed one step behind the host:
+  // while the device runs step t-1 the host (in call t) already holds step t's set and issues
+  // step t+1's — three sets in flight, indexed by step % 3.
   hipStream_t side = nullptr;
-  hipEvent_t ready[2] = {nullptr, nullptr};   // side stream: samples of parity p packed, stats copied
-  hipEvent_t consumed = nullptr;              // main stream: this step no longer needs the march scratch
-  int32_t* host_stats = nullptr;              // pinned, 2 x int32[2]
-  bool have_prefetch = false;
-  int64_t pf_step = -1;
-  int32_t pf_rays = 0;
+  hipEvent_t ready[3] = {nullptr, nullptr, nullptr};   // side: set packed, stats copied to the host
+  hipEvent_t freed[3] = {nullptr, nullptr, nullptr};   // main: the step that used the set has been queued
+  hipEvent_t gate = nullptr;                           // main: MLP part of the latest backward done
+  int32_t* host_stats = nullptr;                       // pinned, 3 x int32[2]
+  bool pf_valid[3] = {false, false, false};
+  int64_t pf_step[3] = {-1, -1, -1};
+  int32_t pf_rays[3] = {0, 0, 0};
   bool initialised = false;                   // effective weights / inv_s / zeroed accumulators
   float aabb[6];
   int32_t rowcap;
@@ -441,10 +498,11 @@ int dsu_nsr_driver_create(const dsu_nsr_driver_cfg* cfg, dsu_nsr_driver** out) {
   int lo = 0, hi = 0;
   bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
             hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, hi) == hipSuccess;
-  ok = ok && hipEventCreateWithFlags(&d->ready[0], hipEventDisableTiming) == hipSuccess &&
-       hipEventCreateWithFlags(&d->ready[1], hipEventDisableTiming) == hipSuccess &&
-       hipEventCreateWithFlags(&d->consumed, hipEventDisableTiming) == hipSuccess &&
-       hipHostMalloc((void**)&d->host_stats, 4 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
+  for (int p = 0; p < 3; ++p)
+    ok = ok && hipEventCreateWithFlags(&d->ready[p], hipEventDisableTiming) == hipSuccess &&
+         hipEventCreateWithFlags(&d->freed[p], hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&d->gate, hipEventDisableTiming) == hipSuccess &&
+       hipHostMalloc((void**)&d->host_stats, 6 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
   if (!ok) {
     dsu_nsr_driver_destroy(d);
     return DSU_ELAUNCH;
@@ -459,9 +517,11 @@ void dsu_nsr_driver_destroy(dsu_nsr_driver* d) {
     (void)hipStreamSynchronize(d->side);
     (void)hipStreamDestroy(d->side);
   }
-  for (int p = 0; p < 2; ++p)
+  for (int p = 0; p < 3; ++p) {
     if (d->ready[p]) (void)hipEventDestroy(d->ready[p]);
-  if (d->consumed) (void)hipEventDestroy(d->consumed);
+    if (d->freed[p]) (void)hipEventDestroy(d->freed[p]);
+  }
+  if (d->gate) (void)hipEventDestroy(d->gate);
   if (d->host_stats) (void)hipHostFree(d->host_stats);
   for (int f = 0; f < 2; ++f)
     for (hipEvent_t e : d->ev[f]) (void)hipEventDestroy(e);
@@ -477,7 +537,7 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
   const dsu_nsr_driver_cfg& c = d->cfg;
   Layout& L = d->L;
   hipStream_t s = (hipStream_t)main_stream;
-  const int p = (int)(a->step & 1);
+  const int p = (int)(a->step % 3);
   Prefetch& f = L.pf[p];
   if (!d->initialised) {
     // zeroed accumulators and optimizer moments
@@ -492,15 +552,19 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
   // ---- this step's samples: prefetched by the previous call, or produced now
   const bool injected = a->inj_index || a->inj_x || a->inj_y || a->inj_jitter || a->inj_pts_random ||
                         a->inj_perturb;
-  if (d->have_prefetch && d->pf_step == a->step && d->pf_rays == a->n_rays && !injected) {
+  if (d->pf_valid[p] && d->pf_step[p] == a->step && d->pf_rays[p] == a->n_rays && !injected) {
     // the host waits: no device-side cross-queue barrier on the main stream is needed afterwards
     DSU_HIP(hipEventSynchronize(d->ready[p]));
   } else {
-    if (d->have_prefetch) DSU_HIP(hipStreamSynchronize(d->side));   // stale: let it drain
+    // nothing usable in flight (first step, a step behind an occupancy refresh, a ray count
+    // changed from outside, injected draws): let the side stream drain, then produce the set on
+    // the main stream and wait for its two stats words
+    DSU_HIP(hipStreamSynchronize(d->side));
+    for (int k = 0; k < 3; ++k) d->pf_valid[k] = false;
     DSU_TRY(enqueue_samples(d, p, a->step, a->n_rays, *a, injected, s));
     DSU_HIP(hipStreamSynchronize(s));
   }
-  d->have_prefetch = false;
+  d->pf_valid[p] = false;
   const int32_t total = d->host_stats[2 * p], cmax = d->host_stats[2 * p + 1];
   a->out_n_samples = total;
   a->out_max_count = cmax;
@@ -515,9 +579,28 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
     if (next_rays < 1) next_rays = 1;
   }
   a->out_next_n_rays = next_rays;
-  // the march scratch may be overwritten by the next prefetch once the packing above has run:
-  // with a prefetched set it already has (same stream); otherwise it was enqueued on main
-  DSU_HIP(hipEventRecord(d->consumed, s));
+  if (a->prefetch_next) {
+    // The next step's samples depend on the occupancy grid and the draws, not on the parameters.
+    // Their serial march (128 waves of ~100 registers for ~0.35 ms) cannot share a SIMD with the
+    // one-wave-per-SIMD kernels of a step (texture backward: 509 registers, MLP part of the
+    // geometry backward: 458) — started behind the geometry forward it delayed the texture
+    // backward's last workgroups by the march's remaining time (245 instead of 170 us, kernel
+    // trace).  It is therefore queued one step earlier, behind the MLP part of the backward the
+    // device is executing NOW (`gate`, recorded by the previous call): it then runs beside the
+    // table-gradient scatter, the optimizer kernels and the next geometry forward, which all
+    // leave registers free.  Set q was last read by step t-2.
+    const int q = (int)((a->step + 1) % 3);
+    DSU_HIP(hipStreamWaitEvent(d->side, d->gate, 0));
+    DSU_HIP(hipStreamWaitEvent(d->side, d->freed[q], 0));
+    dsu_nsr_step_args na = *a;
+    na.inj_index = na.inj_x = na.inj_y = nullptr;
+    na.inj_jitter = na.inj_pts_random = na.inj_perturb = nullptr;
+    DSU_TRY(enqueue_samples(d, q, a->step + 1, next_rays, na, false, d->side));
+    DSU_HIP(hipEventRecord(d->ready[q], d->side));
+    d->pf_valid[q] = true;
+    d->pf_step[q] = a->step + 1;
+    d->pf_rays[q] = next_rays;
+  }
 
   const float* pts = c.sort_bits ? f.sorted : f.points;
   const int32_t* perm = c.sort_bits ? f.perm : nullptr;
@@ -529,18 +612,6 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
                                 a->active_levels, L.a_sdf, L.a_grad, L.a_feat, nullptr, L.enc_cache, s));
   DSU_TRY(mark(d, 0, s));
   if (d->timing) d->work[0] += alg_bytes;
-  if (a->prefetch_next) {
-    // behind the geometry forward: the march has the rest of this step to finish
-    DSU_HIP(hipStreamWaitEvent(d->side, d->consumed, 0));
-    dsu_nsr_step_args na = *a;
-    na.inj_index = na.inj_x = na.inj_y = nullptr;
-    na.inj_jitter = na.inj_pts_random = na.inj_perturb = nullptr;
-    DSU_TRY(enqueue_samples(d, p ^ 1, a->step + 1, next_rays, na, false, d->side));
-    DSU_HIP(hipEventRecord(d->ready[p ^ 1], d->side));
-    d->have_prefetch = true;
-    d->pf_step = a->step + 1;
-    d->pf_rays = next_rays;
-  }
   if (n_s > 0) {
     DSU_TRY(dsu_shade_prep_fwd(L.a_grad, L.a_feat, n_s, L.normal, L.tex_in, s));
     dsu_tex_mlp tex{c.tex[0], c.tex[1], c.tex[2], c.tex[3], c.tex[4], c.tex[5]};
@@ -571,14 +642,16 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
                             L.terms + 4, s));
   float* gg = L.g_geo;
   DSU_TRY(mark(d, 1, s));
-  DSU_TRY(dsu_sdf_fd_bwd_sorted(&c.grid, a->table_img, &mlp, pts, perm, n_all, c.radius, a->eps,
+  DSU_TRY(dsu_sdf_fd_bwd_sorted_mid(&c.grid, a->table_img, &mlp, pts, perm, n_all, c.radius, a->eps,
                                 a->active_levels, L.d_sdf_all, L.d_grad_all, L.d_feat_all, nullptr,
                                 a->table_grad, gg, gg + 64 * 23, gg + 64 * 23 + 64,
-                                gg + 64 * 23 + 64 + 13 * 64, L.sdf_ws, L.sdf_ws_bytes, L.enc_cache, s));
+                                gg + 64 * 23 + 64 + 13 * 64, L.sdf_ws, L.sdf_ws_bytes, L.enc_cache,
+                                    d->gate, s));
   DSU_TRY(mark(d, 1, s));
   if (d->timing) d->work[1] += alg_bytes;
   // ---- optimizer step of the small tensors (the hash table's is the caller's dsu_table_adamw)
   DSU_TRY(launch_small_update(d, a, 1, s));
+  DSU_HIP(hipEventRecord(d->freed[p], s));          // set p may be refilled once this has run
   return DSU_OK;
 }
 
@@ -614,7 +687,7 @@ int dsu_nsr_driver_timing_read(dsu_nsr_driver* d, int32_t family, int64_t* launc
 int dsu_nsr_driver_sync(dsu_nsr_driver* d) {
   if (!d) return DSU_EINVAL;
   DSU_HIP(hipStreamSynchronize(d->side));
-  d->have_prefetch = false;
+  for (int k = 0; k < 3; ++k) d->pf_valid[k] = false;
   return DSU_OK;
 }
 

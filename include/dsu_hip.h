@@ -170,6 +170,18 @@ int dsu_sdf_fd_bwd_sorted(const dsu_hashgrid_cfg* cfg, const void* table_f16,
                           float* g_w1, float* g_b1, void* workspace, int64_t workspace_bytes,
                           const void* enc_cache, void* stream);
 
+/* dsu_sdf_fd_bwd_sorted with a hipEvent_t (as void*, may be NULL) recorded on `stream` between the
+ * two kernels of the backward: behind the MLP part, which occupies every SIMD with one
+ * 458-register wave, and in front of the table-gradient scatter, which leaves room.  Work a caller
+ * wants to overlap with the backward (the next step's ray march) waits for it. */
+int dsu_sdf_fd_bwd_sorted_mid(const dsu_hashgrid_cfg* cfg, const void* table_f16,
+                              const dsu_sdf_mlp* mlp, const float* pts_sorted, const int32_t* perm,
+                              int64_t n, float radius, float eps, uint32_t active_levels,
+                              const float* d_sdf, const float* d_grad, const float* d_feature,
+                              const float* d_laplace, float* grad_table, float* g_w0, float* g_b0,
+                              float* g_w1, float* g_b1, void* workspace, int64_t workspace_bytes,
+                              const void* enc_cache, void* mid_event, void* stream);
+
 /* Bytes of device scratch dsu_sdf_fd_bwd needs for n points (per-workgroup partial MLP
  * gradients, summed by a second kernel: deterministic, no same-address atomics).  <0 = error. */
 int64_t dsu_sdf_fd_bwd_workspace_bytes(const dsu_hashgrid_cfg* cfg, int64_t n);
