@@ -344,6 +344,8 @@ struct dsu_nsr_driver {
   hipEvent_t ready[3] = {nullptr, nullptr, nullptr};   // side: set packed, stats copied to the host
   hipEvent_t freed[3] = {nullptr, nullptr, nullptr};   // main: the step that used the set has been queued
   hipEvent_t gate = nullptr;                           // main: MLP part of the latest backward done
+  hipEvent_t fwd_done = nullptr;                       // main: this step's geometry forward done
+  bool side_high_priority = true, pack_behind_fwd = true;   // A/B switches (DSU_NSR_SIDE_PRIO / _PACK_GATE)
   int32_t* host_stats = nullptr;                       // pinned, 3 x int32[2]
   bool pf_valid[3] = {false, false, false};
   int64_t pf_step[3] = {-1, -1, -1};
@@ -369,16 +371,14 @@ struct dsu_nsr_driver {
 
 namespace {
 
-// draws + ray batch + ray/box + single-pass march + offsets scan + packing + random tail + Morton
-// sort of the sample set of `step` into prefetch set `p`, on stream `s`; the two stats words
-// (total, max count) go to pinned memory.
-int enqueue_samples(dsu_nsr_driver* d, int p, int64_t step, int32_t n_rays,
-                    const dsu_nsr_step_args& a, bool injected, hipStream_t s) {
+// draws + ray batch + ray/box + single-pass march of the sample set of `step` into prefetch set
+// `p`, on stream `s` ...
+int enqueue_march(dsu_nsr_driver* d, int p, int64_t step, int32_t n_rays,
+                  const dsu_nsr_step_args& a, bool injected, hipStream_t s) {
   const dsu_nsr_driver_cfg& c = d->cfg;
   Prefetch& f = d->L.pf[p];
   const int64_t* index = f.index; const int64_t* px = f.px; const int64_t* py = f.py;
-  const float* jitter = f.jitter; const float* pts_random = f.pts_random;
-  const float* perturb = f.perturb;
+  const float* jitter = f.jitter;
   const bool need_draw = !injected || !a.inj_index || !a.inj_x || !a.inj_y || !a.inj_pts_random ||
                          !a.inj_perturb || (a.randomized && !a.inj_jitter);
   if (need_draw)
@@ -389,8 +389,6 @@ int enqueue_samples(dsu_nsr_driver* d, int p, int64_t step, int32_t n_rays,
     if (a.inj_x) px = a.inj_x;
     if (a.inj_y) py = a.inj_y;
     if (a.inj_jitter) jitter = a.inj_jitter;
-    if (a.inj_pts_random) pts_random = a.inj_pts_random;
-    if (a.inj_perturb) perturb = a.inj_perturb;
   }
   DSU_TRY(dsu_ortho_ray_batch(index, px, py, n_rays, c.c2w, c.origins, c.directions, c.images,
                               c.image_channels, c.normals, c.masks, c.view_weights, c.H, c.W,
@@ -403,6 +401,17 @@ int enqueue_samples(dsu_nsr_driver* d, int p, int64_t step, int32_t n_rays,
   DSU_TRY(dsu_ray_march_scratch(f.rays_o, f.rays_d, f.tmin, f.tmax, n_rays, d->aabb, a.occ_binary,
                                 a.occ_binary ? a.occ_res : 0, c.render_step_size, d->rowcap,
                                 f.counts, d->L.scratch_ts, d->L.scratch_te, s));
+  return DSU_OK;
+}
+
+// ... and offsets scan + packing + random tail + Morton sort; the two stats words (total, max
+// count) go to pinned memory.
+int enqueue_pack(dsu_nsr_driver* d, int p, int32_t n_rays, const dsu_nsr_step_args& a,
+                 bool injected, hipStream_t s) {
+  const dsu_nsr_driver_cfg& c = d->cfg;
+  Prefetch& f = d->L.pf[p];
+  const float* pts_random = (injected && a.inj_pts_random) ? a.inj_pts_random : f.pts_random;
+  const float* perturb = (injected && a.inj_perturb) ? a.inj_perturb : f.perturb;
   DSU_TRY(dsu_ray_offsets(f.counts, n_rays, f.offsets, f.stats, s));
   DSU_TRY(dsu_ray_compact_points_cap(d->L.scratch_ts, d->L.scratch_te, d->rowcap, f.offsets,
                                      f.counts, n_rays, f.rays_o, f.rays_d, f.t_starts, f.t_ends,
@@ -416,6 +425,12 @@ int enqueue_samples(dsu_nsr_driver* d, int p, int64_t step, int32_t n_rays,
   DSU_HIP(hipMemcpyAsync(d->host_stats + 2 * p, f.stats, 2 * sizeof(int32_t),
                          hipMemcpyDeviceToHost, s));
   return DSU_OK;
+}
+
+int enqueue_samples(dsu_nsr_driver* d, int p, int64_t step, int32_t n_rays,
+                    const dsu_nsr_step_args& a, bool injected, hipStream_t s) {
+  DSU_TRY(enqueue_march(d, p, step, n_rays, a, injected, s));
+  return enqueue_pack(d, p, n_rays, a, injected, s);
 }
 
 // start/stop events around a timed family (no-ops unless timing is on)
@@ -496,12 +511,16 @@ int dsu_nsr_driver_create(const dsu_nsr_driver_cfg* cfg, dsu_nsr_driver** out) {
   }
   d->rowcap = march_row_capacity(cfg->radius, cfg->render_step_size);
   int lo = 0, hi = 0;
+  if (const char* e = getenv("DSU_NSR_SIDE_PRIO")) d->side_high_priority = atoi(e) != 0;
+  if (const char* e = getenv("DSU_NSR_PACK_GATE")) d->pack_behind_fwd = atoi(e) != 0;
   bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
-            hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking, hi) == hipSuccess;
+            hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking,
+                                        d->side_high_priority ? hi : lo) == hipSuccess;
   for (int p = 0; p < 3; ++p)
     ok = ok && hipEventCreateWithFlags(&d->ready[p], hipEventDisableTiming) == hipSuccess &&
          hipEventCreateWithFlags(&d->freed[p], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->gate, hipEventDisableTiming) == hipSuccess &&
+       hipEventCreateWithFlags(&d->fwd_done, hipEventDisableTiming) == hipSuccess &&
        hipHostMalloc((void**)&d->host_stats, 6 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
   if (!ok) {
     dsu_nsr_driver_destroy(d);
@@ -522,6 +541,7 @@ void dsu_nsr_driver_destroy(dsu_nsr_driver* d) {
     if (d->freed[p]) (void)hipEventDestroy(d->freed[p]);
   }
   if (d->gate) (void)hipEventDestroy(d->gate);
+  if (d->fwd_done) (void)hipEventDestroy(d->fwd_done);
   if (d->host_stats) (void)hipHostFree(d->host_stats);
   for (int f = 0; f < 2; ++f)
     for (hipEvent_t e : d->ev[f]) (void)hipEventDestroy(e);
@@ -595,8 +615,11 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
     dsu_nsr_step_args na = *a;
     na.inj_index = na.inj_x = na.inj_y = nullptr;
     na.inj_jitter = na.inj_pts_random = na.inj_perturb = nullptr;
-    DSU_TRY(enqueue_samples(d, q, a->step + 1, next_rays, na, false, d->side));
-    DSU_HIP(hipEventRecord(d->ready[q], d->side));
+    DSU_TRY(enqueue_march(d, q, a->step + 1, next_rays, na, false, d->side));
+    if (!d->pack_behind_fwd) {
+      DSU_TRY(enqueue_pack(d, q, next_rays, na, false, d->side));
+      DSU_HIP(hipEventRecord(d->ready[q], d->side));
+    }
     d->pf_valid[q] = true;
     d->pf_step[q] = a->step + 1;
     d->pf_rays[q] = next_rays;
@@ -612,6 +635,19 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
                                 a->active_levels, L.a_sdf, L.a_grad, L.a_feat, nullptr, L.enc_cache, s));
   DSU_TRY(mark(d, 0, s));
   if (d->timing) d->work[0] += alg_bytes;
+  if (a->prefetch_next && d->pack_behind_fwd) {
+    // The packing / sorting launches of the next set (a dozen short, chip-wide kernels) slowed the
+    // gather-bound geometry forward by a quarter when they ran beside it (kernel trace: 221 vs
+    // 175 us); behind it they share the chip with the small shading / loss kernels instead.
+    const int q = (int)((a->step + 1) % 3);
+    dsu_nsr_step_args na = *a;
+    na.inj_index = na.inj_x = na.inj_y = nullptr;
+    na.inj_jitter = na.inj_pts_random = na.inj_perturb = nullptr;
+    DSU_HIP(hipEventRecord(d->fwd_done, s));
+    DSU_HIP(hipStreamWaitEvent(d->side, d->fwd_done, 0));
+    DSU_TRY(enqueue_pack(d, q, next_rays, na, false, d->side));
+    DSU_HIP(hipEventRecord(d->ready[q], d->side));
+  }
   if (n_s > 0) {
     DSU_TRY(dsu_shade_prep_fwd(L.a_grad, L.a_feat, n_s, L.normal, L.tex_in, s));
     dsu_tex_mlp tex{c.tex[0], c.tex[1], c.tex[2], c.tex[3], c.tex[4], c.tex[5]};

@@ -626,8 +626,21 @@ static int march_sb() {
   }
   return v;
 }
-#define DSU_MARCH_ONE(M, O, P, S, nr, st, ...) \
-  ray_march_kernel<M, O, P, S><<<dsu_blocks_for(nr, 64), 64, 0, (hipStream_t)st>>>(__VA_ARGS__)
+// rays per workgroup (= lanes of the one wave that marches them): DSU_MARCH_THREADS=16|32|64.  A
+// wave executes the union of its rays' control paths round by round, so fewer rays per wave means
+// fewer rounds (and more, shorter waves)
+static int march_threads() {
+  static int v = 0;
+  if (!v) {
+    const char* e = getenv("DSU_MARCH_THREADS");
+    const int t = e ? atoi(e) : 64;
+    v = (t == 16 || t == 32) ? t : 64;
+  }
+  return v;
+}
+#define DSU_MARCH_ONE(M, O, P, S, nr, st, ...)                                              \
+  ray_march_kernel<M, O, P, S><<<dsu_blocks_for(nr, march_threads()), march_threads(), 0,   \
+                                 (hipStream_t)st>>>(__VA_ARGS__)
 #define DSU_LAUNCH_MARCH(M, nr, st, box, occp, ...)                                   \
   do {                                                                                \
     const bool p2_ = (box).pow2 != 0;                                                 \
