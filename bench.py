@@ -9,9 +9,10 @@ through the hot path on each rank (weak scaling, one drawing per GPU per step):
  -> 6-view x 2-domain diffusion (75 DDIM steps, UNet B=12, VAE encode/decode, CLIP embed)
  -> Instant-NSR reconstruction (3000 optimisation steps, 128^3 occupancy grid, 2 x 512^3 SDF export)
  -> 24-frame 512x512 stylisation (stage-1 GeneratorJ_RIC + stage-2 GeneratorJ per frame)
-on synthetic 512x512 drawings and random-init weights.  Not inside the timed region (stated in
-config.workload): the contour stage's CPU inpainting tail, CPU marching cubes / mesh
-post-processing, Blender rendering, PNG I/O.
+on synthetic 512x512 drawings and random-init weights.  Inside the timed region as well: the
+contour stage's TELEA inpainting tail (host code of the library) and the export's smoothing /
+marching cubes / vertex colours (device).  Not inside (stated in config.workload): mesh
+decimation / thinning of save_mesh, Blender rendering, PNG I/O.
 `--config nsr50k` (BASELINE configs[2] micro-benchmark): one step = one NSR optimisation
 iteration with 50 000 rays marched through a 128^3 occupancy grid (synthetic sphere).
 `--config frames` (BASELINE configs[3]): one step = 24 frames through stage 1 + stage 2, the
@@ -152,10 +153,9 @@ def cpu_baseline(nsr_steps, frames, mv_steps):
     path for its CUDA-only ops, so the baseline runs (a) this repository's restatements that are
     pinned to the reference's own classes by fixtures and execute the SAME torch CPU operators
     the reference's modules would (FFC-ResNet generator, GeneratorJ: nn.Conv2d / BatchNorm /
-    activations), (b) the float64 UNet oracle, (c) the numpy hash-grid oracle.  Each leg is a
-    bounded sample, extrapolated by the stated factor."""
-    import numpy as np
-    from oracle import hashgrid as oh, mv_ref as mr, style_net_ref as snr
+    activations), (b) the float64 UNet oracle, (c) the torch-CPU form of the hash-grid oracle
+    (all `cores` threads).  Each leg is a bounded sample, extrapolated by the stated factor."""
+    from oracle import mv_ref as mr, style_net_ref as snr
     # at most 32 threads: on the GPU box's 256 hardware threads torch's CPU convolutions ran 10-90x
     # SLOWER with one thread per hardware thread than with a few dozen (measured: one FFC-ResNet
     # forward 146 s at 256 threads vs 1.6 s at 8)
@@ -195,27 +195,27 @@ def cpu_baseline(nsr_steps, frames, mv_steps):
     t_unet = (time.time() - t) * 4.93
     legs["mv_s"] = mv_steps * t_unet
     del un, ref
-    # (c) NSR: 20 000 points x 7 evaluations through the numpy oracle; one optimisation step is
-    # ~1.86 M evaluations forward and the backward is charged at 2x the forward
-    lv = oh.make_levels()
-    tg = torch.Generator().manual_seed(0)
-    tab = ((torch.rand(lv["offsets"][10], 2, generator=tg) * 2 - 1) * 0.1).half().numpy()
-    rng = np.random.default_rng(0)
-    mlp = [rng.normal(size=s) * 0.2 for s in [(64, 23), (64,), (13, 64), (13,)]]
-    pts = (rng.random((20000, 3)) * 2 - 1).astype(np.float32)
-    t = time.time()
-    oh.sdf_fd(tab, mlp, pts, 1.0, 0.02, lv, 5)
-    t_eval = (time.time() - t) / (20000 * 7)
-    legs["nsr_s"] = nsr_steps * 1.86e6 * 3 * t_eval + 2 * 512 ** 3 * t_eval
+    # (c) NSR: the geometry network's share of one optimisation step (7 finite-difference
+    # evaluations per point, forward AND backward through autograd) on 40 000 points with the
+    # multi-threaded torch-CPU restatement (oracle/hashgrid_torch.py: index_select gathers +
+    # F.linear), scaled to the step's 262 144 + 4 096 points; marching, compositing,
+    # texture MLP and losses are not charged.  Export: 2 x 512^3 forward-only evaluations.
+    from oracle import hashgrid_torch as ht
+    n_pts = 40000
+    t_fwd, t_fb = ht.training_work_seconds(n_pts, active_levels=5, threads=cores)
+    step_pts = 262144 + 4096
+    legs["nsr_s"] = nsr_steps * t_fb * step_pts / n_pts + 2 * 512 ** 3 * t_fwd / (7 * n_pts)
     total = sum(legs.values())
     return {"value": 1.0 / total, "unit": "drawings/s", "cores": cores, "kind": "port",
             "seconds_per_drawing": total, "legs_seconds": legs,
             "sample": ("host cores, torch CPU / numpy: one 512^2 FFC-ResNet forward (%.2f s); one 512^2 "
                        "GeneratorJ frame (%.2f s) x %d frames x (272+149)/272 GMAC; one float64 oracle "
-                       "UNet forward at B=12 (16x16 latents, x4.93 by work to 32x32: %.1f s) x %d steps; 140 000 numpy hash-grid+MLP "
-                       "evaluations (single-threaded numpy, %.2e s each) x 1.86 M x 3 x %d steps + 2 x "
-                       "512^3 export evaluations"
-                       % (legs["contour_s"], t_g2, frames, t_unet, mv_steps, t_eval, nsr_steps))}
+                       "UNet forward at B=12 (16x16 latents, x4.93 by work to 32x32: %.1f s) x %d steps; "
+                       "geometry forward+backward (7 evaluations per point, torch CPU autograd, %d threads) "
+                       "of %d points (%.2f s) x 266 240 / %d x %d steps + 2 x 512^3 export evaluations "
+                       "at the forward rate"
+                       % (legs["contour_s"], t_g2, frames, t_unet, mv_steps, cores, n_pts, t_fb, n_pts,
+                          nsr_steps))}
 
 
 # ------------------------------------------------------------------------------------------------

@@ -14,6 +14,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
+from .entry.data import fill_holes
 from .mv.pipeline import build_random_pipeline
 from .nsr.system import OrthoData, OrthoNeuSSystem, VIEWS, inv_rt, rt_opengl2opencv, ideal_w2c
 from .style.generators import build_model
@@ -153,6 +154,7 @@ class DrawingPipeline:
         # predicted colour image (distance to the white background, entry/data.py
         # side_mask_from_prediction — the reference runs a CPU ONNX matting model there)
         side = (1.0 - col).amax(-1) > 12.0 / 255.0
+        side = torch.stack([fill_holes(m) for m in side])                  # a filled silhouette, as a matte is
         masks = torch.stack([alpha > 0.5, side[1], side[2], alpha.flip(1) > 0.5, side[4], side[5]])
         nrm = nrm * masks[..., None]
         front = torch.from_numpy(inv_rt(rt_opengl2opencv(ideal_w2c("front")))[:3, :3]).float().to(dev)

@@ -82,14 +82,44 @@ def add_gray(img):
     return Image.fromarray(a.astype(np.uint8))
 
 
+def fill_holes(fg):
+    """fg (H,W) bool tensor -> fg plus every background region that is NOT connected (4-neighbour)
+    to the image border, i.e. scipy.ndimage.binary_fill_holes.  Device-friendly flood fill: the
+    set of background pixels reachable from the border is grown along whole runs of a row, then of
+    a column, until it stops changing (a handful of sweeps for a character silhouette)."""
+    bg = ~fg
+    H, W = bg.shape
+    reach = torch.zeros_like(bg)
+    reach[0], reach[-1], reach[:, 0], reach[:, -1] = bg[0], bg[-1], bg[:, 0], bg[:, -1]
+
+    def sweep(r, b):                                     # along dim 1
+        n_rows, n = b.shape
+        run = torch.cumsum((~b).to(torch.int64), 1)      # run id: increments at every foreground pixel
+        key = run + torch.arange(n_rows, device=b.device)[:, None] * (n + 1)
+        hit = torch.zeros(n_rows * (n + 1), dtype=torch.bool, device=b.device)
+        hit[key[r & b]] = True
+        return hit[key] & b
+
+    for _ in range(4 * (H + W)):                         # bound; real shapes need < 10 rounds
+        new = sweep(reach, bg)
+        new = sweep(new.t().contiguous(), bg.t().contiguous()).t()
+        if bool((new == reach).all()):
+            break
+        reach = new
+    return ~reach
+
+
 def side_mask_from_prediction(image_pil, threshold=12):
     """Foreground matte of a predicted side view.  The reference runs the isnet-dis ONNX matting
     network on the predicted colour image (mv.py:105-150, a third-party CPU model whose weights
-    are not in the snapshot); the diffusion model renders its views on a white background, so the
-    stand-in here is the distance to white: 255 where any channel is more than `threshold` grey
-    levels below white.  `write_mv_outputs(..., matting_fn=...)` takes the real matting model."""
+    are not in the snapshot); it returns a FILLED silhouette.  The diffusion model renders its
+    views on a white background, so the stand-in here is: not-white pixels (any channel more than
+    `threshold` grey levels below white) plus everything they enclose — white or paper-coloured
+    interiors of a drawing are part of the character, not holes for the mask / opacity losses to
+    carve through the body.  `write_mv_outputs(..., matting_fn=...)` takes the real matting model."""
     a = np.array(image_pil.convert("RGB"), np.int16)
-    return Image.fromarray((((255 - a).max(-1) > threshold) * 255).astype(np.uint8), "L")
+    fg = torch.from_numpy((255 - a).max(-1) > threshold)
+    return Image.fromarray((fill_holes(fg).numpy() * 255).astype(np.uint8), "L")
 
 
 def tensor2pil(t):                      # mv.py:47-49

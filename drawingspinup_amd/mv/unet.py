@@ -174,20 +174,18 @@ def _seg_table(kind, B, num_views, device):
     return _SEG_CACHE[key]
 
 
-_QK_CACHE = {}
-
-
 def _qk_weight(attn):
     """to_q and to_k stacked (2C, C): ONE GEMM for both projections of a self-attention (the 768 ..
     3072-row projections fill 60-120 of 256 CUs each; Q and K are strided views of the result,
-    the attention kernel takes row strides).  Rebuilt when either parameter is written."""
+    the attention kernel takes row strides).  Kept ON the module (it dies with it; a module-level
+    dict keyed by id() leaked one 2C x C tensor per attention of every UNet ever built and could
+    hand a recycled id the previous model's weights); rebuilt when either parameter is written."""
     wq, wk = attn.to_q.weight, attn.to_k.weight
-    key = id(attn)
     tag = (wq._version, wk._version, wq.data_ptr(), wk.data_ptr())
-    hit = _QK_CACHE.get(key)
+    hit = attn.__dict__.get("_dsu_qk")
     if hit is None or hit[0] != tag:
         hit = (tag, torch.cat([wq.detach(), wk.detach()], 0).contiguous())
-        _QK_CACHE[key] = hit
+        attn.__dict__["_dsu_qk"] = hit            # plain attribute: not a buffer, not in state_dict
     return hit[1]
 
 

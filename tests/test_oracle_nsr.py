@@ -194,3 +194,23 @@ def test_sync_free_ranking_loss_equals_reference_form():
     ranking_loss_masked(e1, m, 0.7, None, "mean").backward()
     ranking_loss(e2[m], 0.7, None, "mean").backward()
     assert torch.equal(e1.grad, e2.grad)
+
+
+def test_torch_cpu_form_of_the_geometry_pass_agrees_with_the_numpy_oracle():
+    """oracle/hashgrid_torch.py (bench.py's multi-threaded cpu_baseline leg) computes what the
+    bit-faithful numpy oracle computes, to f16 rounding of the interpolated features."""
+    import torch
+    from oracle import hashgrid_torch as ht
+    lv = oh.make_levels()
+    g = torch.Generator().manual_seed(0)
+    tab = ((torch.rand(int(lv["offsets"][10]), 2, generator=g) * 2 - 1) * 0.1).half()
+    mlp = [torch.randn(*s, generator=g) * 0.2 for s in [(64, 23), (64,), (13, 64), (13,)]]
+    pts = torch.rand(300, 3, generator=g) * 2 - 1
+    for active in (4, 7, 10):
+        a = ht.sdf_fd(tab.float(), mlp, pts, 1.0, 0.02, lv, active)
+        b = oh.sdf_fd(tab.numpy(), [m.numpy() for m in mlp], pts.numpy(), 1.0, 0.02, lv, active)
+        np.testing.assert_allclose(a[0].numpy(), b[0], rtol=0, atol=2e-4)
+        np.testing.assert_allclose(a[2].numpy(), b[2], rtol=0, atol=3e-4)
+        np.testing.assert_allclose(a[1].numpy(), b[1], rtol=0, atol=2e-4 / 0.02)
+    fwd, both = ht.training_work_seconds(2000, 5)
+    assert 0 < fwd < both
