@@ -121,6 +121,15 @@ _PROTOS = {
     "dsu_smooth_iterate": [P, c_i64, P, P, C.c_double, c_i32, P, P, P],
     "dsu_smooth_energy": [P, c_i64, P, P, P, P],
     "dsu_smooth_energy_partials": [],
+    "dsu_zgrid_count": [P, c_i64, c_f32, c_f32, c_f32, c_i32, P, P],
+    "dsu_zgrid_fill": [P, c_i64, c_f32, c_f32, c_f32, c_i32, P, P, P, P],
+    "dsu_zray_cast": [P, P, c_i64, c_f32, c_f32, c_f32, c_i32, P, P, P, c_i64, c_i32, P, P, P, P, P,
+                      P, P],
+    "dsu_raster_mask": [P, c_i64, c_f32, c_i32, P, P],
+    "dsu_erode_ellipse_u8": [P, c_i32, c_i32, c_i32, P, P],
+    "dsu_point_bin_count": [P, c_i64, c_f32, c_f32, c_f32, c_i32, P, P],
+    "dsu_point_bin_fill": [P, c_i64, c_f32, c_f32, c_f32, c_i32, P, P, P, P],
+    "dsu_knn8_blend": [P, c_i64, P, P, c_i64, c_f32, c_f32, c_f32, c_i32, P, P, P, P],
     "dsu_nsr_draws": [C.c_uint64, c_i64, c_i32, c_i32, c_i32, c_i32, P, P, P, P, c_i32, P, P, P],
     "dsu_nsr_driver_workspace_bytes": [C.POINTER(NsrDriverCfg)],
     "dsu_nsr_driver_create": [C.POINTER(NsrDriverCfg), C.POINTER(c_vp)],

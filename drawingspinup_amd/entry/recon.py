@@ -1,9 +1,10 @@
 """`python recon.py --uid U [--all]` of the reference (2_charactor_reconstructor/recon.py:44-62):
 3000 optimisation steps, then the export (neus_ortho.py:183-200): 2 x 512^3 SDF volumes, constrained
 smoothing, front-mask cutting (char/mask.png rotated as ortho.py:155-156), marching cubes, vertex
-colours, written as <uid>/mesh/it3000-mc512-f50000_c.obj.  The CPU geometry steps of save_mesh
-(quadric decimation, thinning, Laplacian smoothing, colour back-projection, shear) are outside this
-path, hence no _r_s_cbp suffix."""
+colours, written as <uid>/mesh/it3000-mc512-f50000_c[_s][_cbp].obj.  Of save_mesh's steps, Laplacian
+smoothing (`--smoothing`, `_s`), colour back-projection (`--color_back_projection`, `_cbp`: device
+kernels, nsr/mesh_post.py) and shear (`--shearing`) are available; quadric decimation (`_r`) and
+the thinning deformation (`_t`) are not."""
 import argparse
 import json
 import os
@@ -30,6 +31,8 @@ def main(argv=None):
     # 50 000 faces first, which needs trimesh); smoothing adds the reference's `_s` to the save name
     ap.add_argument("--smoothing", action="store_true")
     ap.add_argument("--shearing", action="store_true")
+    # export.color_back_projection (coloring_utils.py:91-138) from <uid>/mv/{color,mask}/*.png
+    ap.add_argument("--color_back_projection", action="store_true")
     args = ap.parse_args(argv)
     rank, world, local = ddist.init()
     dev = torch.device("cuda", local)
@@ -48,9 +51,19 @@ def main(argv=None):
         out = os.path.join(args.data_root, uid, "mesh")
         os.makedirs(out, exist_ok=True)
         from ..nsr.mesh import save_obj
-        name = system.export_name(front is not None) + ("_s" if args.smoothing else "")   # neus_ortho.py:190-191
+        name = system.export_name(front is not None) + ("_s" if args.smoothing else "") \
+            + ("_cbp" if args.color_back_projection else "")                     # neus_ortho.py:190-195
+        cbp = None
+        if args.color_back_projection:
+            from PIL import Image
+            mv = os.path.join(args.data_root, uid, "mv")
+            big = lambda sub, view, mode: torch.from_numpy(np.array(
+                Image.open(os.path.join(mv, sub, view + ".png")).convert(mode)
+                .resize((2048, 2048), Image.LANCZOS))).to(dev)                   # coloring_utils.py:62,100
+            cbp = {"color_front": big("color", "front", "RGB"), "color_back": big("color", "back", "RGB"),
+                   "mask_front": big("mask", "front", "L")}
         save_obj(os.path.join(out, name + ".obj"), mesh["verts"], mesh["faces"], mesh["vert_colors"],
-                 smoothing=args.smoothing, shearing=args.shearing)
+                 smoothing=args.smoothing, shearing=args.shearing, color_back_projection=cbp)
         torch.save(system.model.state_dict(), os.path.join(out, f"it{system.global_step}.ckpt"))
         print(uid, flush=True)
 

@@ -594,12 +594,17 @@ def nearest_vertex_colors(old_verts, new_verts, colors):
     return np.asarray(colors)[idx]
 
 
-def save_obj(path, verts, faces, colors=None, ortho_scale=1.35, smoothing=False, shearing=False):
+def save_obj(path, verts, faces, colors=None, ortho_scale=1.35, smoothing=False, shearing=False,
+             color_back_projection=None):
     """save_mesh (mesh_utils.py:25-73): halve, swap to the front-facing convention (x right, y up,
-    z front), [Laplacian smoothing + nearest-vertex colour transfer], [shear], ortho_scale, OBJ with
-    per-vertex colours (trimesh's export of `vertex_colors`: `v x y z r g b`, faces 1-based).
-    The two bracketed steps are opt-in (the reference's config has them on); thinning and colour
-    back-projection need a ray caster (mesh_raycast / igl / pytorch3d) and are out of scope."""
+    z front), [Laplacian smoothing], [colour back-projection | nearest-vertex colour transfer],
+    [shear], ortho_scale, OBJ with per-vertex colours (trimesh's export of `vertex_colors`:
+    `v x y z r g b`, faces 1-based).  The bracketed steps are opt-in (the reference's config has
+    them on).  color_back_projection: dict(color_front, mask_front, color_back) of (res,res[,3])
+    uint8 device tensors — the LANCZOS-resized <uid>/mv PNGs — runs nsr/mesh_post.color_projection
+    (coloring_utils.py:91-138) on the device instead of the nearest-vertex transfer
+    (mesh_utils.py:48-53).  Thinning's harmonic deformation (igl) and decimation (trimesh) are
+    not part of this path; the thinning OFFSETS are (nsr/mesh_post.get_offset_mask)."""
     v = verts.detach().cpu().numpy().astype(np.float64) * 0.5
     old = np.zeros_like(v)
     old[:, 0], old[:, 1], old[:, 2] = v[:, 0], v[:, 2], -v[:, 1]
@@ -608,8 +613,15 @@ def save_obj(path, verts, faces, colors=None, ortho_scale=1.35, smoothing=False,
     out = old
     if smoothing and len(fz):
         out = laplacian_smooth_implicit(old, fz, lamb=2.0, iterations=5)
-        if c is not None:
+        if c is not None and color_back_projection is None:
             c = nearest_vertex_colors(old, out, c)
+    if color_back_projection is not None and len(fz):
+        from .mesh_post import color_projection
+        cbp = color_back_projection
+        dev = cbp["color_front"].device
+        c = color_projection(torch.from_numpy(np.ascontiguousarray(out)).to(dev),
+                             torch.from_numpy(fz).to(dev), cbp["color_front"], cbp["mask_front"],
+                             cbp["color_back"], res=cbp["color_front"].shape[0]).float().cpu().numpy()
     if shearing and len(out):
         out = shear_transformation(out)
     out = out * ortho_scale

@@ -996,3 +996,79 @@ def neus_composite_bwd(sdf, normal, rgb, rays_d, t_starts, t_ends, offsets, coun
                                        ptr(d_normal), ptr(d_rgb), ptr(d_inv), stream()),
           "dsu_neus_composite_bwd")
     return d_sdf, d_normal, d_rgb, d_inv
+
+
+# ------------------------------------------------------------------ export: mesh post-processing
+class ZGrid:
+    """Uniform xy grid over a triangle soup (tris (F,3,3) f32 on the device) for z-parallel ray
+    queries, or over a point set (xy (n,2)) for the k-nearest-neighbour search: counting sort by
+    cell (csrc/mesh_post.hip)."""
+
+    def __init__(self, data, lo, hi, points=False, cells_per_axis=None):
+        import math
+        dev = data.device
+        n = data.shape[0]
+        g = cells_per_axis or int(min(1024, max(8, math.sqrt(max(n, 1) / 2.0))))
+        span = max(float(hi[0] - lo[0]), float(hi[1] - lo[1]), 1e-9)
+        self.g, self.cell = g, span / g * (1.0 + 1e-6)
+        self.x0, self.y0 = float(lo[0]), float(lo[1])
+        count_fn = lib().dsu_point_bin_count if points else lib().dsu_zgrid_count
+        fill_fn = lib().dsu_point_bin_fill if points else lib().dsu_zgrid_fill
+        counts = torch.zeros(g * g, dtype=torch.int32, device=dev)
+        check(count_fn(ptr(data, torch.float32), n, self.x0, self.y0, self.cell, g, ptr(counts),
+                       stream()), "grid count")
+        self.offsets = torch.zeros(g * g + 1, dtype=torch.int32, device=dev)
+        self.offsets[1:] = torch.cumsum(counts, 0)
+        total = int(self.offsets[-1])
+        self.items = torch.empty(max(total, 1), dtype=torch.int32, device=dev)
+        cursor = torch.zeros(g * g, dtype=torch.int32, device=dev)
+        check(fill_fn(ptr(data, torch.float32), n, self.x0, self.y0, self.cell, g, ptr(self.offsets),
+                      ptr(cursor), ptr(self.items), stream()), "grid fill")
+        self.data = data
+
+    def args(self):
+        return (self.x0, self.y0, self.cell, self.g, ptr(self.offsets), ptr(self.items))
+
+
+def zray_cast(grid, faces_i32, origins, sign, self_vertex=None):
+    """mesh_raycast.raycast(origin, (0,0,sign), mesh) for all origins (n,3) f32: returns
+    (hit_count i32, t_near, face_near i32, t_far, face_far i32)."""
+    origins = _f32c(origins)
+    n = origins.shape[0]
+    dev = origins.device
+    cnt = torch.empty(n, dtype=torch.int32, device=dev)
+    fn, ff = torch.empty_like(cnt), torch.empty_like(cnt)
+    tn, tf = torch.empty(n, device=dev), torch.empty(n, device=dev)
+    x0, y0, cell, g, off, items = grid.args()
+    check(lib().dsu_zray_cast(ptr(grid.data, torch.float32), ptr(faces_i32, torch.int32),
+                              grid.data.shape[0], x0, y0, cell, g, off, items, ptr(origins), n,
+                              int(sign), ptr(self_vertex, torch.int32), ptr(cnt), ptr(tn), ptr(fn),
+                              ptr(tf), ptr(ff), stream()), "dsu_zray_cast")
+    return cnt, tn, fn, tf, ff
+
+
+def raster_mask(tris, scale, res):
+    mask = torch.zeros(res, res, dtype=torch.uint8, device=tris.device)
+    check(lib().dsu_raster_mask(ptr(tris, torch.float32), tris.shape[0], float(scale), int(res),
+                                ptr(mask), stream()), "dsu_raster_mask")
+    return mask
+
+
+def erode_ellipse_u8(mask, ksize):
+    out = torch.empty_like(mask)
+    check(lib().dsu_erode_ellipse_u8(ptr(mask, torch.uint8), mask.shape[0], mask.shape[1], int(ksize),
+                                     ptr(out), stream()), "dsu_erode_ellipse_u8")
+    return out
+
+
+def knn8_blend(query_xy, known_xy, known_rgb):
+    """interpolate_rgb: colours of the 8 nearest known points (xy distance), weights 1/(d+1e-6)."""
+    query_xy, known_xy, known_rgb = _f32c(query_xy), _f32c(known_xy), _f32c(known_rgb)
+    both = torch.cat([query_xy, known_xy], 0)
+    grid = ZGrid(known_xy, both.amin(0).tolist(), both.amax(0).tolist(), points=True)
+    out = torch.empty(query_xy.shape[0], 3, device=query_xy.device)
+    x0, y0, cell, g, off, items = grid.args()
+    check(lib().dsu_knn8_blend(ptr(query_xy), query_xy.shape[0], ptr(known_xy), ptr(known_rgb),
+                               known_xy.shape[0], x0, y0, cell, g, off, items, ptr(out), stream()),
+          "dsu_knn8_blend")
+    return out

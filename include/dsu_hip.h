@@ -708,6 +708,54 @@ int dsu_smooth_iterate(const int32_t* nbr, int64_t nv, const double* lower, cons
 int dsu_smooth_energy(const int32_t* nbr, int64_t nv, const double* x, double* y,
                       double* partials, void* stream);
 
+/* ------------------------------------------------------------------------------------
+ * Mesh post-processing of the export (save_mesh, instant_nsr/utils/mesh_utils.py:25-73): the
+ * geometric queries of color_projection (utils/coloring_utils.py:91-138) and get_offset_mask
+ * (utils/thinning_utils.py:96-193).  SURVEY.md 8f-2.
+ * ---------------------------------------------------------------------------------- */
+
+/* Uniform xy grid over the triangles (tris: (n_faces, 3 vertices, 3) f32): cell (cx, cy) =
+ * floor((x - x0) / cell), clamped to [0, g); a triangle is listed in every cell its xy bounding
+ * box overlaps.  Counting sort in two launches around the caller's exclusive prefix sum:
+ * dsu_zgrid_count adds to counts (g*g int32, zeroed by the caller); dsu_zgrid_fill writes the
+ * face ids into items at offsets[cell] (+ a zeroed cursor array it increments). */
+int dsu_zgrid_count(const float* tris, int64_t n_faces, float x0, float y0, float cell, int32_t g,
+                    int32_t* counts, void* stream);
+int dsu_zgrid_fill(const float* tris, int64_t n_faces, float x0, float y0, float cell, int32_t g,
+                   const int32_t* offsets, int32_t* cursor, int32_t* items, void* stream);
+/* mesh_raycast.raycast(origin, (0, 0, sign), mesh=triangles) for n_rays origins (coloring_utils.py:
+ * 107-130, thinning_utils.py:101-193): per ray the number of hits, the nearest and the farthest
+ * hit (distance t >= 0 along the ray and face id; ties -> smaller face id; no hit: id -1, t 0).
+ * A hit = (x, y) inside or on the boundary of the triangle's xy projection and not behind the
+ * origin.  self_vertex (optional, with faces (n_faces,3) int32): the mesh vertex a ray starts at;
+ * triangles incident to it count as hits at distance exactly 0. */
+int dsu_zray_cast(const float* tris, const int32_t* faces, int64_t n_faces, float x0, float y0,
+                  float cell, int32_t g, const int32_t* offsets, const int32_t* items,
+                  const float* origins, int64_t n_rays, int32_t sign, const int32_t* self_vertex,
+                  int32_t* hit_count, float* t_near, int32_t* face_near, float* t_far,
+                  int32_t* face_far, void* stream);
+/* MaskRenderer.render (coloring_utils.py:22-41; pytorch3d orthographic rasteriser, zbuf > -1):
+ * silhouette of `scale` x the mesh seen from +z on a res x res image, 255 where a pixel centre
+ * (x = (2 col + 1) / res - 1, y = 1 - (2 row + 1) / res) is covered; mask zeroed by the caller. */
+int dsu_raster_mask(const float* tris, int64_t n_faces, float scale, int32_t res, uint8_t* mask,
+                    void* stream);
+/* cv2.erode(src, cv2.getStructuringElement(cv2.MORPH_ELLIPSE, (ksize, ksize))) (coloring_utils.py:
+ * 61-64), single channel uint8, default border. */
+int dsu_erode_ellipse_u8(const uint8_t* src, int32_t H, int32_t W, int32_t ksize, uint8_t* dst,
+                         void* stream);
+/* interpolate_rgb (coloring_utils.py:43-58): for every query point the 8 nearest known points in
+ * the xy plane (scipy cKDTree.query(k=8)), colours blended with weights 1 / (d + 1e-6).  The
+ * known points are binned on an xy grid by dsu_point_bin_count / _fill (same protocol as the
+ * triangle grid). */
+int dsu_point_bin_count(const float* xy, int64_t n, float x0, float y0, float cell, int32_t g,
+                        int32_t* counts, void* stream);
+int dsu_point_bin_fill(const float* xy, int64_t n, float x0, float y0, float cell, int32_t g,
+                       const int32_t* offsets, int32_t* cursor, int32_t* items, void* stream);
+int dsu_knn8_blend(const float* query_xy, int64_t n_query, const float* known_xy,
+                   const float* known_rgb, int64_t n_known, float x0, float y0, float cell,
+                   int32_t g, const int32_t* offsets, const int32_t* items, float* out_rgb,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif
