@@ -157,11 +157,13 @@ __global__ __launch_bounds__(256) void erode_ellipse_kernel(const uint8_t* __res
 
 // interpolate_rgb (coloring_utils.py:43-58): the K nearest known points in the xy plane (scipy
 // cKDTree.query(k = 8)), weights 1 / (d + 1e-6) normalised, colours blended in float64.  Known
-// points sit in the same kind of xy grid (point bins); rings of cells are visited outward until
+// points sit in the same kind of xy grid (point bins, assigned from the float32 cast of the
+// coordinates; distances in float64 like scipy: front / back vertices of a flat mesh are almost
+// coincident in xy and the weights 1 / (d + 1e-6) feel a float32 rounding of d); rings of cells are visited outward until
 // the K-th distance found cannot be beaten by anything outside the visited square.
 constexpr int KNN_K = 8;
-__global__ __launch_bounds__(128) void knn_blend_kernel(const float* __restrict__ query, int64_t nq,
-                                                        const float* __restrict__ known_xy,
+__global__ __launch_bounds__(128) void knn_blend_kernel(const double* __restrict__ query, int64_t nq,
+                                                        const double* __restrict__ known_xy,
                                                         const float* __restrict__ known_rgb,
                                                         int64_t nk, ZGrid gr,
                                                         const int32_t* __restrict__ offsets,
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(128) void knn_blend_kernel(const float* __restrict_
         const int c = yy * gr.g + xx;
         for (int p = offsets[c]; p < offsets[c + 1]; ++p) {
           const int j = items[p];
-          const double dx = (double)known_xy[j * 2] - qx, dy = (double)known_xy[j * 2 + 1] - qy;
+          const double dx = known_xy[j * 2] - qx, dy = known_xy[j * 2 + 1] - qy;
           const double d2 = dx * dx + dy * dy;
           if (d2 < bd[KNN_K - 1] || (d2 == bd[KNN_K - 1] && j < bi[KNN_K - 1])) {
             // insertion into the sorted list (ties by index: deterministic)
@@ -319,7 +321,7 @@ int dsu_point_bin_fill(const float* xy, int64_t n, float x0, float y0, float cel
   return DSU_OK;
 }
 
-int dsu_knn8_blend(const float* query_xy, int64_t n_query, const float* known_xy,
+int dsu_knn8_blend(const double* query_xy, int64_t n_query, const double* known_xy,
                    const float* known_rgb, int64_t n_known, float x0, float y0, float cell,
                    int32_t g, const int32_t* offsets, const int32_t* items, float* out_rgb,
                    void* stream) {

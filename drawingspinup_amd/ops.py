@@ -1062,13 +1062,17 @@ def erode_ellipse_u8(mask, ksize):
 
 
 def knn8_blend(query_xy, known_xy, known_rgb):
-    """interpolate_rgb: colours of the 8 nearest known points (xy distance), weights 1/(d+1e-6)."""
-    query_xy, known_xy, known_rgb = _f32c(query_xy), _f32c(known_xy), _f32c(known_rgb)
-    both = torch.cat([query_xy, known_xy], 0)
-    grid = ZGrid(known_xy, both.amin(0).tolist(), both.amax(0).tolist(), points=True)
-    out = torch.empty(query_xy.shape[0], 3, device=query_xy.device)
+    """interpolate_rgb: colours of the 8 nearest known points (xy distance, float64 like scipy's
+    cKDTree), weights 1/(d+1e-6)."""
+    q64 = query_xy.to(torch.float64).contiguous()
+    k64 = known_xy.to(torch.float64).contiguous()
+    known_rgb = _f32c(known_rgb)
+    k32 = k64.to(torch.float32).contiguous()
+    both = torch.cat([q64.to(torch.float32), k32], 0)
+    grid = ZGrid(k32, both.amin(0).tolist(), both.amax(0).tolist(), points=True)
+    out = torch.empty(q64.shape[0], 3, device=q64.device)
     x0, y0, cell, g, off, items = grid.args()
-    check(lib().dsu_knn8_blend(ptr(query_xy), query_xy.shape[0], ptr(known_xy), ptr(known_rgb),
-                               known_xy.shape[0], x0, y0, cell, g, off, items, ptr(out), stream()),
-          "dsu_knn8_blend")
+    check(lib().dsu_knn8_blend(ptr(q64, torch.float64), q64.shape[0], ptr(k64, torch.float64),
+                               ptr(known_rgb), k64.shape[0], x0, y0, cell, g, off, items, ptr(out),
+                               stream()), "dsu_knn8_blend")
     return out

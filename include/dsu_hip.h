@@ -744,14 +744,15 @@ int dsu_raster_mask(const float* tris, int64_t n_faces, float scale, int32_t res
 int dsu_erode_ellipse_u8(const uint8_t* src, int32_t H, int32_t W, int32_t ksize, uint8_t* dst,
                          void* stream);
 /* interpolate_rgb (coloring_utils.py:43-58): for every query point the 8 nearest known points in
- * the xy plane (scipy cKDTree.query(k=8)), colours blended with weights 1 / (d + 1e-6).  The
+ * the xy plane (scipy cKDTree.query(k=8); coordinates float64), colours blended with weights
+ * 1 / (d + 1e-6).  The
  * known points are binned on an xy grid by dsu_point_bin_count / _fill (same protocol as the
  * triangle grid). */
 int dsu_point_bin_count(const float* xy, int64_t n, float x0, float y0, float cell, int32_t g,
                         int32_t* counts, void* stream);
 int dsu_point_bin_fill(const float* xy, int64_t n, float x0, float y0, float cell, int32_t g,
                        const int32_t* offsets, int32_t* cursor, int32_t* items, void* stream);
-int dsu_knn8_blend(const float* query_xy, int64_t n_query, const float* known_xy,
+int dsu_knn8_blend(const double* query_xy, int64_t n_query, const double* known_xy,
                    const float* known_rgb, int64_t n_known, float x0, float y0, float cell,
                    int32_t g, const int32_t* offsets, const int32_t* items, float* out_rgb,
                    void* stream);
