@@ -16,6 +16,7 @@ What differs from the reference implementation:
     them raises.
 """
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -226,6 +227,11 @@ class FFCResNetGenerator(nn.Module):
         self.model = nn.Sequential(*layers)
 
     def forward(self, x):
+        # on the device, in eval mode: the library's own convolution kernel for every layer
+        # (contour/ffc_hip.py); DSU_CONTOUR=torch keeps the torch operators (A/B, training)
+        if x.is_cuda and not self.training and os.environ.get("DSU_CONTOUR", "hip") != "torch":
+            from . import ffc_hip
+            return ffc_hip.generator_forward(self, x)
         return self.model(x)
 
 

@@ -37,7 +37,15 @@ def _conv_small_cin(conv, x_nhwc):
 
 
 def _conv1x1_nhwc(conv, x_nhwc):
-    return F.linear(x_nhwc, conv.weight.view(conv.out_channels, conv.in_channels), conv.bias)
+    w = conv.weight.view(conv.out_channels, conv.in_channels)
+    if x_nhwc.is_cuda and x_nhwc.dtype == torch.float16:
+        shp = x_nhwc.shape
+        x2 = x_nhwc.reshape(-1, shp[-1])
+        if shp[-1] % 8:                       # quant / post_quant convs: 8 -> 8 and 4 -> 4 channels
+            pad = 8 - shp[-1] % 8             # zero columns: 16-byte rows for the GEMM's loads
+            x2, w = F.pad(x2, (0, pad)), F.pad(w, (0, pad))
+        return ops.linear_f16(x2.contiguous(), w.contiguous(), conv.bias).view(*shp[:-1], -1)
+    return F.linear(x_nhwc, w, conv.bias)
 
 
 # ----------------------------------------------------------------------------------- scheduler
@@ -113,8 +121,10 @@ class VaeResnet(nn.Module):
 
 
 class VaeAttention(nn.Module):
-    """single-head spatial self-attention of the VAE mid block (run once per encode/decode;
-    d=512 single head -> library matmuls)."""
+    """single-head spatial self-attention of the VAE mid block (run once per encode / decode; one
+    head of d = 512): projections, Q K^T and P V on the library's own f16 GEMM (the `to_v`
+    projection is produced transposed, so P V is a plain `x W^T` product as well); softmax in f32
+    as diffusers' AttnProcessor upcasts it."""
 
     def __init__(self, ch, groups=32, eps=1e-6):
         super().__init__()
@@ -125,6 +135,20 @@ class VaeAttention(nn.Module):
     def forward(self, x):
         B, H, W, C = x.shape
         h = group_norm(self.group_norm, x).view(B, H * W, C)
+        if h.is_cuda and h.dtype == torch.float16:
+            q = ops.linear_f16(h, self.to_q.weight, self.to_q.bias)
+            k = ops.linear_f16(h, self.to_k.weight, self.to_k.bias)
+            # V^T (B, C, N): the bias is per channel = per ROW of the transposed output
+            vt = ops.linear_f16(h, self.to_v.weight, transposed_tokens=H * W) \
+                + self.to_v.bias.view(1, C, 1)
+            o = torch.empty_like(q)
+            for b in range(B):
+                s_ = ops.linear_f16(q[b], k[b].contiguous())                       # (N, N) = Q K^T
+                a = torch.softmax(s_.float() * C ** -0.5, -1).to(q.dtype)
+                o[b] = ops.linear_f16(a, vt[b].contiguous())                       # (N, C) = P V
+            o = ops.linear_f16(o, self.to_out[0].weight, self.to_out[0].bias,
+                               residual=x.reshape(B, H * W, C))
+            return o.view(B, H, W, C)
         q, k, v = self.to_q(h), self.to_k(h), self.to_v(h)
         a = torch.softmax(torch.bmm(q, k.transpose(1, 2)).float() * C ** -0.5, -1).to(q.dtype)
         o = self.to_out[0](torch.bmm(a, v))

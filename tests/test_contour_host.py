@@ -143,3 +143,36 @@ def test_remove_contour_end_to_end_on_the_host():
     assert np.array_equal(out[keep][:, :3], (x[:, :, :3] * 255).astype(np.uint8)[keep])
     body = out[stroke & (xx > 14) & (xx < 34)][:, :3].astype(int)
     assert np.abs(body - np.array([180, 90, 40])).max() <= 3          # the line is gone
+
+
+def test_kernel_form_of_the_generator_is_the_same_function(monkeypatch):
+    """contour/ffc_hip.py re-expresses every layer through ONE operator (ops.conv2d: zero-padded
+    convolution + folded BatchNorm / activation / residual epilogue): concatenated FFC branches,
+    reflect padding as a copy, transposed convolutions as convolutions of the zero-dilated input,
+    the FourierUnit's transforms as 1x1 convolutions over the transformed axis.  With the operator
+    served by torch on the CPU the re-expression must reproduce the module tree's output."""
+    import torch.nn.functional as F
+    from drawingspinup_amd.contour import ffc_hip
+
+    def conv2d(x, w, bias=None, stride=1, padding=0, ep_scale=None, ep_shift=None, act=None,
+               residual=None, in_relu=False):
+        y = F.conv2d(x, w, bias, stride, padding)
+        if ep_scale is not None:
+            y = y * ep_scale[None, :, None, None] + ep_shift[None, :, None, None]
+        if act == "relu":
+            y = torch.relu(y)
+        return y if residual is None else y + residual
+    monkeypatch.setattr(ffc_hip.ops, "conv2d", conv2d)
+    torch.manual_seed(0)
+    cfg = dict(LAMA_FOURIER_GENERATOR, ngf=8, n_blocks=2)
+    net = make_generator(**cfg).eval()
+    for m in net.modules():                                   # non-trivial BatchNorm statistics
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.normal_(0, 0.3); m.running_var.uniform_(0.5, 2.0)
+            m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(0, 0.2)
+    for hw in ((32, 32), (48, 40)):
+        x = torch.rand(2, 4, *hw)
+        with torch.no_grad():
+            want = net.model(x)
+            got = ffc_hip.generator_forward(net, x)
+        torch.testing.assert_close(got, want, rtol=0, atol=2e-5)
