@@ -167,6 +167,7 @@ _PROTOS = {
                                P, P],
     "dsu_shade_prep_fwd": [P, P, c_i64, P, P, P],
     "dsu_shade_prep_bwd": [P, P, P, c_i64, P, P, P],
+    "dsu_shade_prep_bwd_tail": [P, P, P, c_i64, c_i64, P, P, P],
     "dsu_occgrid_ema": [P, P, P, c_i64, c_f32, P],
     "dsu_occgrid_binarize": [P, c_i64, c_f32, P, P],
     "dsu_ric_offsets": [c_i32, c_i32, P, P],

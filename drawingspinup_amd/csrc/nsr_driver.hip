@@ -97,6 +97,7 @@ struct SmallArgs {
   float *m, *v;
   // outputs for the next step
   float *w0_eff, *w1_eff, *inv_s;
+  float* zero_terms;   // the three sample-loss accumulators of the NEXT step
   float lr_geo, lr_tex, lr_var, beta1, beta2, eps, wd, bc1, bc2_sqrt;
   int32_t update;   // 0: forward part only (first call)
 };
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(1024) void small_update_kernel(SmallArgs a) {
       a.inv_s[0] = expf(x * 10.0f);
       a.d_inv[0] = 0.0f;
     }
+    if (t < 3) a.zero_terms[t] = 0.0f;
     __syncthreads();                                   // every read of s_gain / g_tex is done
     if (t < 64) s_gain[t] = new_gain;
     if (t < 13) s_gain[64 + t] = new_gain1;
@@ -311,7 +313,7 @@ int carve(const dsu_nsr_driver_cfg& c, char* base, Layout& L) {
   L.enc_cache = k.take<char>(L.enc_cache_bytes);
   L.normal = k.take<float>(N * 3); L.tex_in = k.take<float>(N * 16); L.rgb = k.take<float>(N * 3);
   L.alpha = k.take<float>(N); L.w = k.take<float>(N);
-  L.comp = k.take<float>(R * 8); L.d_comp = k.take<float>(R * 8); L.terms = k.take<float>(8);
+  L.comp = k.take<float>(R * 8); L.d_comp = k.take<float>(R * 8); L.terms = k.take<float>(16);
   L.d_sdf_all = k.take<float>(rows); L.d_grad_all = k.take<float>(rows * 3);
   L.d_feat_all = k.take<float>(rows * 13);
   L.d_normal = k.take<float>(N * 3); L.d_rgb = k.take<float>(N * 3); L.d_tex_in = k.take<float>(N * 16);
@@ -452,6 +454,7 @@ int launch_small_update(dsu_nsr_driver* d, const dsu_nsr_step_args* a, int updat
   sa.g_geo = d->L.g_geo; sa.g_tex = d->L.g_tex; sa.d_inv = d->L.d_inv;
   sa.m = d->L.adam_m; sa.v = d->L.adam_v;
   sa.w0_eff = d->L.w0_eff; sa.w1_eff = d->L.w1_eff; sa.inv_s = d->L.inv_s;
+  sa.zero_terms = d->L.terms + 8 * (int)((a->step + 1) & 1) + 4;
   sa.beta1 = c.beta1; sa.beta2 = c.beta2; sa.eps = c.adam_eps; sa.wd = c.weight_decay;
   sa.update = update;
   sa.lr_geo = sa.lr_tex = sa.lr_var = 0.0f;
@@ -559,11 +562,13 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
   hipStream_t s = (hipStream_t)main_stream;
   const int p = (int)(a->step % 3);
   Prefetch& f = L.pf[p];
+  float* terms = L.terms + 8 * (int)(a->step & 1);   // two sets: the optimizer kernel pre-zeroes the next one
   if (!d->initialised) {
     // zeroed accumulators and optimizer moments
     DSU_HIP(hipMemsetAsync(L.g_geo, 0, (N_GEO + N_TEX + 1) * sizeof(float), s));
     DSU_HIP(hipMemsetAsync(L.adam_m, 0, N_SMALL * sizeof(float), s));
     DSU_HIP(hipMemsetAsync(L.adam_v, 0, N_SMALL * sizeof(float), s));
+    DSU_HIP(hipMemsetAsync(L.terms, 0, 16 * sizeof(float), s));
   }
   if (!d->initialised || a->refresh_effective) {
     DSU_TRY(launch_small_update(d, a, 0, s));       // effective weights and inv_s
@@ -659,9 +664,8 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
     DSU_HIP(hipMemsetAsync(L.comp, 0, (size_t)a->n_rays * 8 * sizeof(float), s));
   }
   DSU_TRY(dsu_ray_losses(L.comp, f.rgb, f.normal, f.mask, f.cosines, f.vw, a->n_rays, &c.ray_loss,
-                         L.terms, L.d_comp, s));
+                         terms, L.d_comp, s));
   // ---- backward
-  DSU_HIP(hipMemsetAsync(L.d_feat_all + n_s * 13, 0, (size_t)(2 * n_r) * 13 * sizeof(float), s));
   if (n_s > 0) {
     DSU_TRY(dsu_neus_composite_bwd(L.a_sdf, L.normal, L.rgb, f.rays_d, f.t_starts, f.t_ends,
                                    f.offsets, f.counts, a->n_rays, L.inv_s, a->cos_anneal_ratio,
@@ -671,11 +675,14 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
     float* gt = L.g_tex;
     DSU_TRY(dsu_texture_bwd(&tex, L.tex_in, L.rgb, L.d_rgb, n_s, L.d_tex_in, gt, gt + 1024,
                             gt + 1088, gt + 5184, gt + 5248, gt + 5440, L.tex_ws, L.tex_ws_bytes, s));
-    DSU_TRY(dsu_shade_prep_bwd(L.a_grad, L.d_normal, L.d_tex_in, n_s, L.d_grad_all, L.d_feat_all, s));
+    DSU_TRY(dsu_shade_prep_bwd_tail(L.a_grad, L.d_normal, L.d_tex_in, n_s, 2 * n_r, L.d_grad_all,
+                                    L.d_feat_all, s));
+  } else {
+    DSU_HIP(hipMemsetAsync(L.d_feat_all, 0, (size_t)(2 * n_r) * 13 * sizeof(float), s));
   }
   DSU_TRY(dsu_sample_losses(L.a_sdf, L.a_grad, n_s, n_r, c.lambda_eikonal, c.lambda_sparsity,
-                            c.sparsity_scale, c.lambda_smooth, 1, L.d_sdf_all, L.d_grad_all,
-                            L.terms + 4, s));
+                            c.sparsity_scale, c.lambda_smooth, 1 | 2, L.d_sdf_all, L.d_grad_all,
+                            terms + 4, s));
   float* gg = L.g_geo;
   DSU_TRY(mark(d, 1, s));
   DSU_TRY(dsu_sdf_fd_bwd_sorted_mid(&c.grid, a->table_img, &mlp, pts, perm, n_all, c.radius, a->eps,

@@ -583,9 +583,16 @@ __global__ void shade_prep_fwd_kernel(const float* __restrict__ grad,
 __global__ void shade_prep_bwd_kernel(const float* __restrict__ grad,
                                       const float* __restrict__ d_normal,
                                       const float* __restrict__ d_tex_in, int64_t n,
-                                      float* __restrict__ d_grad, float* __restrict__ d_feat) {
+                                      int64_t tail, float* __restrict__ d_grad,
+                                      float* __restrict__ d_feat) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  if (i >= n) {
+    // rows of points that are not ray samples (the regulariser points evaluated in the same
+    // geometry launch): no feature gradient reaches them
+    if (i < n + tail)
+      for (int k = 0; k < 13; ++k) d_feat[i * 13 + k] = 0.0f;
+    return;
+  }
   const float g0 = grad[i * 3], g1 = grad[i * 3 + 1], g2 = grad[i * 3 + 2];
   const float len = sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
   const float inv = 1.0f / fmaxf(len, 1e-12f);
@@ -855,10 +862,18 @@ int dsu_shade_prep_fwd(const float* grad, const float* feature, int64_t n, float
 
 int dsu_shade_prep_bwd(const float* grad, const float* d_normal, const float* d_tex_in, int64_t n,
                        float* d_grad, float* d_feature, void* stream) {
-  if (n < 0 || (n && (!grad || !d_tex_in || !d_grad || !d_feature))) return DSU_EINVAL;
-  if (n == 0) return DSU_OK;
-  shade_prep_bwd_kernel<<<dsu_blocks_for(n, 256), 256, 0, (hipStream_t)stream>>>(
-      grad, d_normal, d_tex_in, n, d_grad, d_feature);
+  return dsu_shade_prep_bwd_tail(grad, d_normal, d_tex_in, n, 0, d_grad, d_feature, stream);
+}
+
+int dsu_shade_prep_bwd_tail(const float* grad, const float* d_normal, const float* d_tex_in,
+                            int64_t n, int64_t tail_rows, float* d_grad, float* d_feature,
+                            void* stream) {
+  if (n < 0 || tail_rows < 0 || (n && (!grad || !d_tex_in || !d_grad)) ||
+      ((n || tail_rows) && !d_feature))
+    return DSU_EINVAL;
+  if (n + tail_rows == 0) return DSU_OK;
+  shade_prep_bwd_kernel<<<dsu_blocks_for(n + tail_rows, 256), 256, 0, (hipStream_t)stream>>>(
+      grad, d_normal, d_tex_in, n, tail_rows, d_grad, d_feature);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }

@@ -602,11 +602,14 @@ int dsu_sample_losses(const float* sdf_all, const float* grad_all, int64_t n_sam
   const int64_t n = n_samples + n_random;
   if (n && (!sdf_all || !grad_all || !d_sdf_all || !d_grad_all)) return DSU_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  if (hipMemsetAsync(terms, 0, 3 * sizeof(float), s) != hipSuccess) return DSU_ELAUNCH;
+  // bit 1 of accumulate_prefix: the caller has zeroed `terms` already (the step driver does it in
+  // the previous step's optimizer kernel: one fill launch less per step)
+  if (!(accumulate_prefix & 2) && hipMemsetAsync(terms, 0, 3 * sizeof(float), s) != hipSuccess)
+    return DSU_ELAUNCH;
   if (n == 0) return DSU_OK;
   sample_losses_kernel<<<dsu_capped_blocks(n, 256, 512), 256, 0, s>>>(
       sdf_all, grad_all, n_samples, n_random, lambda_eikonal, lambda_sparsity, sparsity_scale,
-      lambda_smooth, accumulate_prefix, d_sdf_all, d_grad_all, terms);
+      lambda_smooth, accumulate_prefix & 1, d_sdf_all, d_grad_all, terms);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }

@@ -413,7 +413,7 @@ class NativeStepDriver:
         self.adam_step = 0
         self.param_versions = [p._version for p in self.params]
         off = int(_lib.lib().dsu_nsr_driver_terms(h)) - self.workspace.data_ptr()
-        self.terms = self.workspace[off:off + 32].view(torch.float32)
+        self.terms2 = self.workspace[off:off + 64].view(torch.float32).view(2, 8)
         self.timing_on = False
         self.dataset = ds
 
@@ -700,7 +700,7 @@ class OrthoNeuSSystem:
             self.train_num_rays = int(a.out_next_n_rays)
         self._step_table(geo.active_levels)
         self.global_step += 1
-        t = drv.terms
+        t = drv.terms2[(self.global_step - 1) & 1]
         L = self.config.loss
         terms = {"rgb_mse": t[0]}
         if L.lambda_rgb_l1:

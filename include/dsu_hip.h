@@ -292,6 +292,11 @@ int dsu_shade_prep_fwd(const float* grad, const float* feature, int64_t n, float
                        float* tex_in, void* stream);
 int dsu_shade_prep_bwd(const float* grad, const float* d_normal, const float* d_tex_in, int64_t n,
                        float* d_grad, float* d_feature, void* stream);
+/* The same, and rows [n, n + tail_rows) of d_feature set to zero: the regulariser points that
+ * share the geometry launch with the n ray samples (neus.py:155-162) receive no feature gradient. */
+int dsu_shade_prep_bwd_tail(const float* grad, const float* d_normal, const float* d_tex_in,
+                            int64_t n, int64_t tail_rows, float* d_grad, float* d_feature,
+                            void* stream);
 
 /* VolumeRadiance (2_charactor_reconstructor/instant_nsr/models/texture.py:9-30): VanillaMLP
  * 16 -> 64 -> 64 -> 3, ReLU, no weight norm (models/network_utils.py:94-138), then sigmoid.
@@ -355,7 +360,8 @@ int dsu_ray_losses(const float* comp, const float* rgb, const float* normal, con
  * and their gradients: d_grad_all[:n_samples] += eikonal part when accumulate_prefix != 0
  * (the compositing/shading backward has already written it; d_sdf_all[:n_samples] is left
  * untouched) or = when 0 (then d_sdf_all[:n_samples] = 0); the random / perturbed rows of
- * d_sdf_all and d_grad_all are written. */
+ * d_sdf_all and d_grad_all are written.  accumulate_prefix bit 1 (value 2): `terms` was zeroed by
+ * the caller (otherwise this call zeroes it first). */
 int dsu_sample_losses(const float* sdf_all, const float* grad_all, int64_t n_samples,
                       int64_t n_random, float lambda_eikonal, float lambda_sparsity,
                       float sparsity_scale, float lambda_smooth, int32_t accumulate_prefix,
@@ -679,8 +685,9 @@ void dsu_nsr_driver_destroy(dsu_nsr_driver* d);
 /* One step on `main_stream`.  DSU_EUNSUP: the step produced more samples than cap_points (or a
  * ray more than the march scratch row holds); out_n_samples / out_max_count say how many. */
 int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* args, void* main_stream);
-/* Device pointer to the 7 loss terms of the last step: rgb_mse, rgb_l1, normal, mask, eikonal,
- * sparsity, normal_smooth (each already multiplied by its lambda). */
+/* Device pointer to two sets of 8 floats; the set of step s starts at 8 * (s & 1) and holds its 7
+ * loss terms: rgb_mse, rgb_l1, normal, mask, eikonal, sparsity, normal_smooth (each already
+ * multiplied by its lambda).  A set is reused (zeroed) at the end of the following step. */
 const float* dsu_nsr_driver_terms(const dsu_nsr_driver* d);
 /* HIP-event timing of the two geometry launches of a step (family 0: dsu_sdf_fd_fwd_sorted,
  * 1: dsu_sdf_fd_bwd_sorted) on the stream they run on: enable (resets) / disable, then read the
