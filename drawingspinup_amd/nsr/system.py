@@ -690,7 +690,15 @@ class OrthoNeuSSystem:
         topt = self.table_opt
         topt.activate(int(geo.active_levels))
         a.table_img, a.table_grad = topt.img.data_ptr(), topt.grad.data_ptr()
-        rc = drv._lib.lib().dsu_nsr_driver_step(drv.handle, C.byref(a), ops.stream())
+        for attempt in range(6):
+            rc = drv._lib.lib().dsu_nsr_driver_step(drv.handle, C.byref(a), ops.stream())
+            if rc != -3 or a.out_n_samples <= _PACK_CAPACITY or a.n_rays <= 64:
+                break
+            # more samples than the packed buffers hold (twice the schedule's target): nothing of
+            # the step has run yet — march half the rays instead (the dynamic ray schedule would
+            # have shrunk the batch over the next steps anyway)
+            a.n_rays = max(64, a.n_rays // 2)
+            self.train_num_rays = int(a.n_rays)
         if rc != 0:
             raise ops.DsuError(f"dsu_nsr_driver_step failed ({rc}): {a.out_n_samples} samples, "
                                f"longest ray {a.out_max_count} (capacity {_PACK_CAPACITY})")
