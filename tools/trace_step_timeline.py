@@ -42,3 +42,18 @@ b = one[0][0]
 print("one step:")
 for s, e, q, n in one:
     print(f"  +{(s - b) / 1e3:8.1f} us  {(e - s) / 1e3:7.1f} us  q{q}  {n}")
+
+# where the main queue idles: gaps > 4 us between consecutive kernels of the busiest queue, by
+# (kernel before -> kernel after), summed over the window
+mainq = max(byq, key=lambda q: sum(e - s for s, e, _, _ in byq[q]))
+rs = byq[mainq]
+gap = defaultdict(lambda: [0, 0])
+for i in range(len(rs) - 1):
+    g = rs[i + 1][0] - rs[i][1]
+    if g > 4000:
+        k = (rs[i][3][-28:], rs[i + 1][3][-28:])
+        gap[k][0] += 1
+        gap[k][1] += g
+print("idle gaps > 4 us on the main queue (before -> after): count/step, us/step")
+for k, (c, t) in sorted(gap.items(), key=lambda kv: -kv[1][1])[:12]:
+    print(f"  {k[0]:>28s} -> {k[1]:<28s} {c / steps:5.2f} {t / steps / 1e3:7.1f}")
