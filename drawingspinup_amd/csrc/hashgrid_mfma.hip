@@ -1034,7 +1034,8 @@ __device__ __forceinline__ void sc_commit_from(uint32_t* keys, unsigned long lon
 template <int NL>
 __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
     GridMeta m, const float* __restrict__ pts, int64_t n, float radius, float eps, uint32_t active,
-    const float2* __restrict__ dinbuf, float* __restrict__ gtable) {
+    const float2* __restrict__ dinbuf, float* __restrict__ gtable, int merge_levels,
+    int centre_acc) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   uint32_t* c_keys = reinterpret_cast<uint32_t*>(lds);
   unsigned long long* c_acc = reinterpret_cast<unsigned long long*>(lds + SC_SLOTS);
@@ -1106,32 +1107,69 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
       const int64_t ii = valid ? i : last;
       const float p[3] = {pn[0], pn[1], pn[2]};
       const int64_t inext = i + blockDim.x < r1 ? i + blockDim.x : last;   // clamped: harmless re-read
+      // The seven evaluations of a point are its centre and six offsets of one finite-difference
+      // step, which is the cell size of the FINEST active level: on every coarser level most of
+      // them fall into the centre's cell and hit the same eight entries.  Their contributions are
+      // summed in registers (`cv`) and emitted once, after the offsets that left the cell:
+      // 2.5-5.6 emissions per point and level instead of 7 (queue entries, LDS atomics and
+      // same-cell merges shrink by a quarter at 4 levels, by more than a third at 6).
+      float cv[16];
+      CellPos ccp;
+      int ckey = 0;
 #pragma unroll 1
-      for (int e = 0; e < 7; ++e) {
-        float2 d = dn;
-        if (e == 2) {   // wave-uniform: the next chunk's position, four iterations ahead of its use
-          pn[0] = pts[inext * 3]; pn[1] = pts[inext * 3 + 1]; pn[2] = pts[inext * 3 + 2];
-        }
-        {
-          const bool wrap = e == 6;
-          const int64_t in_ = wrap ? inext : ii;
-          dn = dinbuf[((size_t)(wrap ? 0 : e + 1) * active + lev) * n + in_];
-        }
-        d.x = valid ? d.x : 0.0f;
-        d.y = valid ? d.y : 0.0f;
-        float q[3];
-        fd_point(p, e, eps, radius, q);
-        const float cx = contract(q[0], radius), cy = contract(q[1], radius),
-                    cz = contract(q[2], radius);
-        const CellPos cp = cell_of(l_scale, cx, cy, cz);
+      for (int e = 0; e < 8; ++e) {          // e = 7: the centre cell's accumulated sum
+        CellPos cp;
         float v[16];
+        bool flush;
+        if (e < 7) {
+          float2 d = dn;
+          if (e == 2) {   // wave-uniform: the next chunk's position, four iterations ahead of its use
+            pn[0] = pts[inext * 3]; pn[1] = pts[inext * 3 + 1]; pn[2] = pts[inext * 3 + 2];
+          }
+          {
+            const bool wrap = e == 6;
+            const int64_t in_ = wrap ? inext : ii;
+            dn = dinbuf[((size_t)(wrap ? 0 : e + 1) * active + lev) * n + in_];
+          }
+          d.x = valid ? d.x : 0.0f;
+          d.y = valid ? d.y : 0.0f;
+          float q[3];
+          fd_point(p, e, eps, radius, q);
+          const float cx = contract(q[0], radius), cy = contract(q[1], radius),
+                      cz = contract(q[2], radius);
+          cp = cell_of(l_scale, cx, cy, cz);
 #pragma unroll
-        for (int c = 0; c < 8; ++c) {
-          const float w = corner_weight(cp, c);
-          v[2 * c] = w * d.x;
-          v[2 * c + 1] = w * d.y;
+          for (int c = 0; c < 8; ++c) {
+            const float w = corner_weight(cp, c);
+            v[2 * c] = w * d.x;
+            v[2 * c + 1] = w * d.y;
+          }
+          const int key = (int)(cp.c[0] | (cp.c[1] << 10) | (cp.c[2] << 20));
+          if (e == 0) {                      // wave-uniform
+            ccp = cp;
+            ckey = key;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) cv[k] = v[k];
+            continue;
+          }
+          const bool same = (key == ckey) & (centre_acc != 0);
+#pragma unroll
+          for (int k = 0; k < 16; ++k) cv[k] += same ? v[k] : 0.0f;
+          flush = valid & !same;
+          if (__ballot(flush) == 0ull) continue;   // wave-uniform: every offset stayed in the centre cell
+        } else {
+          cp = ccp;
+#pragma unroll
+          for (int k = 0; k < 16; ++k) v[k] = cv[k];
+          flush = valid;
         }
-        const int key = (int)(cp.c[0] | (cp.c[1] << 10) | (cp.c[2] << 20));
+        // lanes with nothing to emit this round: a key no neighbour shares, zero contribution
+        const int key = flush ? (int)(cp.c[0] | (cp.c[1] << 10) | (cp.c[2] << 20))
+                              : (0x40000000 | lane);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v[k] = flush ? v[k] : 0.0f;
+        bool lead = flush;
+        if (lev < merge_levels) {        // wave-uniform
         const int l15 = lane & 15;
         // neighbour keys with all lanes active (see the fused kernel: a DPP move under the EXEC
         // mask of a short-circuit reads disabled source lanes as 0)
@@ -1148,9 +1186,9 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
         }
         DSU_SEG_STEP(0x101) DSU_SEG_STEP(0x102) DSU_SEG_STEP(0x104) DSU_SEG_STEP(0x108)
 #undef DSU_SEG_STEP
-        // padding lanes (beyond the range) repeat the last point with d = 0: they may extend a run
-        // but never lead one
-        const bool lead = ((l15 == 0) | (key_prev != key)) & valid;
+        // padding lanes (beyond the range) and lanes that emit nothing never lead a run
+        lead = ((l15 == 0) | (key_prev != key)) & flush;
+        }
         const unsigned long long bal = __ballot(lead);
         if (lead) {
           const int pos = qn + 8 * __popcll(bal & ((1ull << lane) - 1ull));
@@ -1416,8 +1454,20 @@ int dsu_sdf_fd_bwd_sorted_mid(const dsu_hashgrid_cfg* cfg, const void* table_f16
       // the MLP part holds every SIMD with one 458-register wave; what a caller wants to run
       // beside the rest of the backward (two 96-register waves per SIMD) waits for this event
       if (mid_event && hipEventRecord((hipEvent_t)mid_event, s) != hipSuccess) return DSU_ELAUNCH;
+      // same-cell run merge (DPP segmented sums over 16 lanes) only where neighbouring lanes of the
+      // Morton order can share a cell: DSU_SC_MERGE_LEVELS (default: all levels)
+      static int merge_lv = -1;
+      if (merge_lv < 0) {
+        const char* e = getenv("DSU_SC_MERGE_LEVELS");
+        merge_lv = e ? atoi(e) : 64;
+      }
+      static int centre_acc = -1;      // DSU_SC_CENTRE=0: every evaluation emitted on its own (A/B)
+      if (centre_acc < 0) {
+        const char* e = getenv("DSU_SC_CENTRE");
+        centre_acc = e ? atoi(e) != 0 : 1;
+      }
       k2<<<dim3(sblocks), dim3(SC_THREADS), shm2, s>>>(m, pts, n, radius, eps, active_levels,
-                                                      dinbuf, grad_table);
+                                                      dinbuf, grad_table, merge_lv, centre_acc);
       reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 63) / 64), dim3(1024), 0, s>>>(
           (const float*)workspace, blocks, g_w0, g_b0, g_w1, g_b1);
     });
