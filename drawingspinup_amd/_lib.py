@@ -180,6 +180,9 @@ _PROTOS = {
                                 c_i32, P, P, P, P],
     "dsu_conv2d_nhwc_f16_fwd_ws": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                                    c_i32, P, P, P, c_i32, P, c_i64, P],
+    "dsu_conv2d_nhwc_f16_fwd_fx": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                   c_i32, P, P, P, c_i32, P, c_i64, P, c_i64, P],
+    "dsu_gemm_f16_fwd_fx": [P, P, P, c_i64, c_i32, c_i32, P, P, c_i32, c_i32, P, c_i64, P, c_i64, P],
     "dsu_conv2d_nhwc_f16_split_k": [c_i32] * 9,
     "dsu_conv2d_nhwc_f16_workspace_bytes": [c_i32] * 9,
     "dsu_gemm_f16_split_k": [c_i64, c_i32, c_i32],

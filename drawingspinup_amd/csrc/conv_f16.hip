@@ -53,6 +53,8 @@ struct CArgs {
   int split_k;          // > 1: blockIdx.z owns a contiguous range of K chunks, f32 partials -> ws
   float* ws;            // (split_k, npix, O) f32 when split_k > 1
   int out_t;            // 1: out[(n * O + o) * (OH*OW) + pixel-in-image]  (V^T for the attention kernel)
+  int* counters;        // split_k > 1: one zeroed int per output tile -> the LAST workgroup of a
+                        // tile sums the partials and runs the epilogue itself (no reduce launch)
 };
 
 template <int MODE>
@@ -213,6 +215,46 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
             for (int e = 0; e < 4 && o + e < a.O; ++e) ws[(size_t)p * a.O + o + e] = acc[i][j][4 * r4 + e];
           }
         }
+    }
+    if (a.counters == nullptr) return;              // conv_f16_reduce_kernel finishes the job
+    // Fix-up by the last arrival: every workgroup of a tile publishes its partial sums (device-scope
+    // release: the eight XCDs have private L2s), takes a ticket, and the one that draws the last
+    // ticket adds the split_k partials in z order (the order does not depend on who is last) and
+    // runs the epilogue.  The UNet forward issued ~180 reduce launches (7 us + a launch gap each,
+    // 1.2 ms of 13) for its split-K layers.
+    __shared__ int s_ticket;
+    __threadfence();
+    __syncthreads();
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+    if (tid == 0) s_ticket = atomicAdd(&a.counters[tile], 1);
+    __syncthreads();
+    if (s_ticket != a.split_k - 1) return;
+    __threadfence();
+    if (tid == 0) a.counters[tile] = 0;             // ready for the next launch on this stream
+    const int hw = a.OH * a.OW;
+    for (int idx = tid; idx < TN * (TM / 4); idx += 256) {
+      const int64_t p = p0 + idx / (TM / 4);
+      const int o = o0 + (idx % (TM / 4)) * 4;
+      if (p >= npix || o >= a.O) continue;
+      const int n = (int)(p / hw);
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      const bool full = o + 3 < a.O && (a.O & 3) == 0;
+      for (int z = 0; z < a.split_k; ++z) {
+        const float* w = a.ws + ((size_t)z * npix + p) * a.O + o;
+        if (full) {
+          const float4 q = *reinterpret_cast<const float4*>(w);
+          v[0] += q.x; v[1] += q.y; v[2] += q.z; v[3] += q.w;
+        } else {
+          for (int e = 0; e < 4 && o + e < a.O; ++e) v[e] += w[e];
+        }
+      }
+      for (int e = 0; e < 4 && o + e < a.O; ++e) {
+        float tv = v[e];
+        if (a.bias) tv += (float)a.bias[o + e];
+        if (a.addvec) tv += (float)a.addvec[(size_t)n * a.O + o + e];
+        if (a.residual) tv += (float)a.residual[(size_t)p * a.O + o + e];
+        a.out[(size_t)p * a.O + o + e] = (f16)tv;
+      }
     }
     return;
   }
@@ -377,6 +419,17 @@ int dsu_conv2d_nhwc_f16_fwd_ws(const void* input, const void* weight_okc, const 
                                const void* addvec, const void* residual, void* out,
                                int32_t split_k, void* workspace, int64_t workspace_bytes,
                                void* stream) {
+  return dsu_conv2d_nhwc_f16_fwd_fx(input, weight_okc, bias, B, H, W, C, O, k, stride, pad, upsample2x,
+                                    addvec, residual, out, split_k, workspace, workspace_bytes,
+                                    nullptr, 0, stream);
+}
+
+int dsu_conv2d_nhwc_f16_fwd_fx(const void* input, const void* weight_okc, const void* bias,
+                               int32_t B, int32_t H, int32_t W, int32_t C, int32_t O, int32_t k,
+                               int32_t stride, int32_t pad, int32_t upsample2x,
+                               const void* addvec, const void* residual, void* out,
+                               int32_t split_k, void* workspace, int64_t workspace_bytes,
+                               int32_t* tile_counters, int64_t n_counters, void* stream) {
   if (!input || !weight_okc || !out) return DSU_EINVAL;
   if (split_k < 1 || split_k > 64) return DSU_EINVAL;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || O <= 0 || k <= 0 || stride <= 0 || pad < 0)
@@ -389,7 +442,7 @@ int dsu_conv2d_nhwc_f16_fwd_ws(const void* input, const void* weight_okc, const 
   a.addvec = (const f16*)addvec; a.residual = (const f16*)residual; a.out = (f16*)out;
   a.B = B; a.H = H; a.W = W; a.C = C; a.O = O; a.KS = k; a.stride = stride; a.pad = pad;
   a.up2 = upsample2x ? 1 : 0;
-  a.out_t = 0;
+  a.out_t = 0; a.counters = nullptr;
   const int IH = a.up2 ? 2 * H : H, IW = a.up2 ? 2 * W : W;
   a.OH = (IH + 2 * pad - k) / stride + 1;
   a.OW = (IW + 2 * pad - k) / stride + 1;
@@ -409,8 +462,10 @@ int dsu_conv2d_nhwc_f16_fwd_ws(const void* input, const void* weight_okc, const 
       (!workspace || workspace_bytes < (int64_t)a.split_k * npix * O * (int64_t)sizeof(float)))
     return DSU_EINVAL;
   dim3 grid((unsigned)((npix + TN - 1) / TN), (unsigned)((O + TM - 1) / TM), (unsigned)a.split_k);
+  a.counters = (a.split_k > 1 && tile_counters && (int64_t)grid.x * grid.y <= n_counters)
+                   ? tile_counters : nullptr;
   conv_f16_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
-  if (a.split_k > 1) {
+  if (a.split_k > 1 && !a.counters) {
     const int64_t total = npix * ((O + 3) / 4);
     conv_f16_reduce_kernel<<<dsu_capped_blocks(total, 256, 2048), 256, 0, (hipStream_t)stream>>>(
         a, npix);
@@ -433,7 +488,7 @@ static int gemm_args(CArgs& a, const void* x, const void* w, const void* bias, i
   a.residual = (const f16*)residual; a.out = (f16*)out;
   a.B = 1; a.H = (int)M; a.W = 1; a.C = K; a.O = N; a.OH = (int)M; a.OW = 1;
   a.KS = 1; a.stride = 1; a.pad = 0; a.up2 = 0; a.Ktot = K; a.split_k = 1; a.ws = nullptr;
-  a.out_t = 0;
+  a.out_t = 0; a.counters = nullptr;
   return DSU_OK;
 }
 
@@ -451,6 +506,14 @@ int64_t dsu_gemm_f16_workspace_bytes(int64_t M, int32_t N, int32_t split_k) {
 int dsu_gemm_f16_fwd(const void* x, const void* w, const void* bias, int64_t M, int32_t K, int32_t N,
                      const void* residual, void* out, int32_t tokens_per_image, int32_t split_k,
                      void* workspace, int64_t workspace_bytes, void* stream) {
+  return dsu_gemm_f16_fwd_fx(x, w, bias, M, K, N, residual, out, tokens_per_image, split_k, workspace,
+                             workspace_bytes, nullptr, 0, stream);
+}
+
+int dsu_gemm_f16_fwd_fx(const void* x, const void* w, const void* bias, int64_t M, int32_t K,
+                        int32_t N, const void* residual, void* out, int32_t tokens_per_image,
+                        int32_t split_k, void* workspace, int64_t workspace_bytes,
+                        int32_t* tile_counters, int64_t n_counters, void* stream) {
   CArgs a;
   int rc = gemm_args(a, x, w, bias, M, K, N, residual, out);
   if (rc) return rc;
@@ -468,8 +531,10 @@ int dsu_gemm_f16_fwd(const void* x, const void* w, const void* bias, int64_t M, 
   if (split_k > 1 && (!workspace || workspace_bytes < (int64_t)split_k * M * N * (int64_t)sizeof(float)))
     return DSU_EINVAL;
   dim3 grid((unsigned)((M + TN - 1) / TN), (unsigned)((N + TM - 1) / TM), (unsigned)split_k);
+  a.counters = (split_k > 1 && tile_counters && (int64_t)grid.x * grid.y <= n_counters)
+                   ? tile_counters : nullptr;
   conv_f16_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
-  if (split_k > 1) {
+  if (split_k > 1 && !a.counters) {
     const int64_t total = M * ((N + 3) / 4);
     conv_f16_reduce_kernel<<<dsu_capped_blocks(total, 256, 2048), 256, 0, (hipStream_t)stream>>>(a, M);
   }

@@ -837,6 +837,26 @@ def conv_weight_okc(weight):
     return weight.detach().permute(0, 2, 3, 1).reshape(O, k * k, Cin).to(torch.float16).contiguous()
 
 
+_TILE_COUNTERS = {}
+_N_TILE_COUNTERS = 1 << 16
+
+
+def _tile_counters(device):
+    """Zeroed, persistent per (device, stream) int32 buffer for the in-kernel split-K fix-up (the
+    kernel resets what it touches; launches that share a buffer must share a stream).  OFF unless
+    DSU_SPLITK_FIXUP=1: the device-scope release / acquire around the ticket writes back and
+    invalidates the XCD's L2 per workgroup — the UNet forward took 26.6 ms with it against 12.6 ms
+    with the separate reduce launches (profiles/round3_unet_splitk_fixup.txt)."""
+    import os
+    if os.environ.get("DSU_SPLITK_FIXUP", "0") != "1":
+        return None
+    key = (str(device), stream().value)
+    t = _TILE_COUNTERS.get(key)
+    if t is None:
+        t = _TILE_COUNTERS[key] = torch.zeros(_N_TILE_COUNTERS, dtype=torch.int32, device=device)
+    return t
+
+
 def conv2d_nhwc_f16(x_nhwc, w_okc, bias=None, k=3, stride=1, pad=1, upsample2x=False, addvec=None,
                     residual=None, split_k=None):
     """x_nhwc (B,H,W,C) f16 contiguous -> (B,OH,OW,O) f16.  split_k None = the library's choice
@@ -856,10 +876,12 @@ def conv2d_nhwc_f16(x_nhwc, w_okc, bias=None, k=3, stride=1, pad=1, upsample2x=F
         wbytes = int(lib().dsu_conv2d_nhwc_f16_workspace_bytes(B, H, W, O, k, stride, pad, up,
                                                                split_k))
         ws = torch.empty(wbytes // 4, dtype=torch.float32, device=x_nhwc.device)
-    check(lib().dsu_conv2d_nhwc_f16_fwd_ws(ptr(x_nhwc, f16), ptr(w_okc, f16), ptr(bias, f16), B, H,
+    cnt = _tile_counters(x_nhwc.device) if split_k > 1 else None
+    check(lib().dsu_conv2d_nhwc_f16_fwd_fx(ptr(x_nhwc, f16), ptr(w_okc, f16), ptr(bias, f16), B, H,
                                            W, Cin, O, k, stride, pad, up, ptr(addvec, f16),
                                            ptr(residual, f16), ptr(out), int(split_k), ptr(ws),
-                                           wbytes, stream()), "dsu_conv2d_nhwc_f16_fwd")
+                                           wbytes, ptr(cnt), _N_TILE_COUNTERS if cnt is not None else 0,
+                                           stream()), "dsu_conv2d_nhwc_f16_fwd")
     return out
 
 
@@ -885,9 +907,12 @@ def linear_f16(x, weight, bias=None, residual=None, transposed_tokens=0, split_k
         ws = torch.empty(wbytes // 4, dtype=torch.float32, device=x.device)
     if residual is not None:
         assert residual.is_contiguous() and residual.numel() == M * N
-    check(lib().dsu_gemm_f16_fwd(ptr(x, f16), ptr(weight, f16), ptr(bias, f16), M, K, N,
-                                 ptr(residual, f16), ptr(out), int(transposed_tokens), int(split_k),
-                                 ptr(ws), wbytes, stream()), "dsu_gemm_f16_fwd")
+    cnt = _tile_counters(x.device) if split_k > 1 else None
+    check(lib().dsu_gemm_f16_fwd_fx(ptr(x, f16), ptr(weight, f16), ptr(bias, f16), M, K, N,
+                                    ptr(residual, f16), ptr(out), int(transposed_tokens), int(split_k),
+                                    ptr(ws), wbytes, ptr(cnt),
+                                    _N_TILE_COUNTERS if cnt is not None else 0, stream()),
+          "dsu_gemm_f16_fwd")
     return out
 
 

@@ -531,6 +531,21 @@ int dsu_conv2d_nhwc_f16_fwd_ws(const void* input, const void* weight_okc, const 
                                const void* addvec, const void* residual, void* out,
                                int32_t split_k, void* workspace, int64_t workspace_bytes,
                                void* stream);
+/* Split-K with the reduction inside the kernel: `tile_counters` is a caller-owned, ZEROED int32
+ * buffer of at least (output tiles) entries that stays allocated between calls; the last workgroup
+ * of a tile to finish sums the split_k partial tiles (in z order) and runs the epilogue, then
+ * resets the tile's counter — no separate reduce launch.  One buffer serves every launch issued
+ * on ONE stream (launches on different streams need their own).  NULL = the reduce kernel. */
+int dsu_conv2d_nhwc_f16_fwd_fx(const void* input, const void* weight_okc, const void* bias,
+                               int32_t B, int32_t H, int32_t W, int32_t C, int32_t O, int32_t k,
+                               int32_t stride, int32_t pad, int32_t upsample2x,
+                               const void* addvec, const void* residual, void* out,
+                               int32_t split_k, void* workspace, int64_t workspace_bytes,
+                               int32_t* tile_counters, int64_t n_counters, void* stream);
+int dsu_gemm_f16_fwd_fx(const void* x, const void* w, const void* bias, int64_t M, int32_t K,
+                        int32_t N, const void* residual, void* out, int32_t tokens_per_image,
+                        int32_t split_k, void* workspace, int64_t workspace_bytes,
+                        int32_t* tile_counters, int64_t n_counters, void* stream);
 
 /* nn.Linear forward of the UNet's transformer blocks and embedding MLPs on the same MFMA kernel
  * (a 1x1 convolution over M rows): Attention.to_q / to_k / to_out, FeedForward.net.2,

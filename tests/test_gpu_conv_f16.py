@@ -58,10 +58,14 @@ def test_conv_f16_identity_kat(dev):
 
 
 @gpu
+@pytest.mark.parametrize("fixup", [True, False])
 @pytest.mark.parametrize("split", [1, 2, 7, 16])
-def test_conv_f16_split_k_matches_plain(dev, split):
-    """Split-K (f32 partials + reduce/epilogue kernel) against the single-pass kernel and torch,
-    on a 4x4-level UNet shape with the full fused epilogue and on an O that is not a multiple of 4."""
+def test_conv_f16_split_k_matches_plain(dev, split, fixup, monkeypatch):
+    """Split-K (f32 partials, summed by the last workgroup of a tile — `fixup` — or by the separate
+    reduce/epilogue kernel) against the single-pass kernel and torch, on a 4x4-level UNet shape with
+    the full fused epilogue and on an O that is not a multiple of 4.  The fix-up form is run
+    three times on the same counters: they must come back to zero."""
+    monkeypatch.setenv("DSU_SPLITK_FIXUP", "1" if fixup else "0")
     B, C, O, H, W = 3, 1280, 640, 4, 4
     x, w, b = _r((B, C, H, W), 14), _r((O, C, 3, 3), 15, (C * 9) ** -0.5), _r((O,), 16, 0.1)
     tv, res = _r((B, O), 17, 0.5), _r((B, O, H, W), 18)
@@ -74,6 +78,12 @@ def test_conv_f16_split_k_matches_plain(dev, split):
     ref6 = F.conv2d(x.float(), w6.float(), None, 1, 1)
     got6 = ops.conv2d_nhwc_f16(xg, ops.conv_weight_okc(w6).to(dev), None, 3, 1, 1, split_k=split)
     torch.testing.assert_close(got6.cpu().float().permute(0, 3, 1, 2), ref6, rtol=3e-3, atol=3e-3)
+    if fixup and split > 1:
+        for _ in range(2):
+            again = ops.conv2d_nhwc_f16(xg, wg, b.to(dev), 3, 1, 1, False, tv.to(dev),
+                                        res.permute(0, 2, 3, 1).contiguous().to(dev), split_k=split)
+            assert torch.equal(again, got)                    # same z-order sum whoever arrives last
+        assert int(ops._tile_counters(dev).abs().sum()) == 0
 
 
 def test_conv_f16_split_k_heuristic():
