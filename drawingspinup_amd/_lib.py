@@ -159,6 +159,9 @@ _PROTOS = {
     "dsu_texture_fwd": [C.POINTER(TexMlp), P, c_i64, P, P],
     "dsu_texture_bwd_workspace_bytes": [c_i64],
     "dsu_texture_bwd": [C.POINTER(TexMlp), P, P, P, c_i64, P, P, P, P, P, P, P, P, c_i64, P],
+    "dsu_texture_fwd_shaded": [C.POINTER(TexMlp), P, P, c_i64, P, P, P],
+    "dsu_texture_bwd_shaded": [C.POINTER(TexMlp), P, P, P, P, P, c_i64, c_i64, P, P, P, P, P, P, P, P,
+                               P, c_i64, P],
     "dsu_weights_from_alpha_fwd": [P, P, P, c_i64, P, P],
     "dsu_weights_from_alpha_bwd": [P, P, P, P, P, c_i64, P, P],
     "dsu_accumulate_fwd": [P, P, c_i32, P, P, c_i64, P, P],

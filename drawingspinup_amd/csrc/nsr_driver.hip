@@ -271,8 +271,8 @@ struct Layout {
   float *scratch_ts, *scratch_te;
   float *a_sdf, *a_grad, *a_feat;
   void* enc_cache;
-  float *normal, *tex_in, *rgb, *alpha, *w, *comp, *d_comp, *terms;
-  float *d_sdf_all, *d_grad_all, *d_feat_all, *d_normal, *d_rgb, *d_tex_in;
+  float *normal, *rgb, *alpha, *w, *comp, *d_comp, *terms;
+  float *d_sdf_all, *d_grad_all, *d_feat_all, *d_normal, *d_rgb;
   void *tex_ws, *sdf_ws;
   float *g_geo, *g_tex, *d_inv;      // contiguous: zeroed as one block
   float *w0_eff, *w1_eff, *inv_s, *adam_m, *adam_v;
@@ -311,12 +311,12 @@ int carve(const dsu_nsr_driver_cfg& c, char* base, Layout& L) {
   L.scratch_te = k.take<float>(R * (int64_t)rowcap);
   L.a_sdf = k.take<float>(rows); L.a_grad = k.take<float>(rows * 3); L.a_feat = k.take<float>(rows * 13);
   L.enc_cache = k.take<char>(L.enc_cache_bytes);
-  L.normal = k.take<float>(N * 3); L.tex_in = k.take<float>(N * 16); L.rgb = k.take<float>(N * 3);
+  L.normal = k.take<float>(N * 3); L.rgb = k.take<float>(N * 3);
   L.alpha = k.take<float>(N); L.w = k.take<float>(N);
   L.comp = k.take<float>(R * 8); L.d_comp = k.take<float>(R * 8); L.terms = k.take<float>(16);
   L.d_sdf_all = k.take<float>(rows); L.d_grad_all = k.take<float>(rows * 3);
   L.d_feat_all = k.take<float>(rows * 13);
-  L.d_normal = k.take<float>(N * 3); L.d_rgb = k.take<float>(N * 3); L.d_tex_in = k.take<float>(N * 16);
+  L.d_normal = k.take<float>(N * 3); L.d_rgb = k.take<float>(N * 3);
   L.tex_ws = k.take<char>(L.tex_ws_bytes > 4 ? L.tex_ws_bytes : 4);
   L.sdf_ws = k.take<char>(L.sdf_ws_bytes > 4 ? L.sdf_ws_bytes : 4);
   L.g_geo = k.take<float>(N_GEO + N_TEX + 1);
@@ -654,9 +654,8 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
     DSU_HIP(hipEventRecord(d->ready[q], d->side));
   }
   if (n_s > 0) {
-    DSU_TRY(dsu_shade_prep_fwd(L.a_grad, L.a_feat, n_s, L.normal, L.tex_in, s));
     dsu_tex_mlp tex{c.tex[0], c.tex[1], c.tex[2], c.tex[3], c.tex[4], c.tex[5]};
-    DSU_TRY(dsu_texture_fwd(&tex, L.tex_in, n_s, L.rgb, s));
+    DSU_TRY(dsu_texture_fwd_shaded(&tex, L.a_feat, L.a_grad, n_s, L.normal, L.rgb, s));
     DSU_TRY(dsu_neus_composite_fwd(L.a_sdf, L.normal, L.rgb, f.rays_d, f.t_starts, f.t_ends,
                                    f.offsets, f.counts, a->n_rays, L.inv_s, a->cos_anneal_ratio,
                                    L.alpha, L.w, L.comp, s));
@@ -673,10 +672,9 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
                                    L.d_inv, s));
     dsu_tex_mlp tex{c.tex[0], c.tex[1], c.tex[2], c.tex[3], c.tex[4], c.tex[5]};
     float* gt = L.g_tex;
-    DSU_TRY(dsu_texture_bwd(&tex, L.tex_in, L.rgb, L.d_rgb, n_s, L.d_tex_in, gt, gt + 1024,
-                            gt + 1088, gt + 5184, gt + 5248, gt + 5440, L.tex_ws, L.tex_ws_bytes, s));
-    DSU_TRY(dsu_shade_prep_bwd_tail(L.a_grad, L.d_normal, L.d_tex_in, n_s, 2 * n_r, L.d_grad_all,
-                                    L.d_feat_all, s));
+    DSU_TRY(dsu_texture_bwd_shaded(&tex, L.a_feat, L.a_grad, L.rgb, L.d_rgb, L.d_normal, n_s, 2 * n_r,
+                                   L.d_grad_all, L.d_feat_all, gt, gt + 1024, gt + 1088, gt + 5184,
+                                   gt + 5248, gt + 5440, L.tex_ws, L.tex_ws_bytes, s));
   } else {
     DSU_HIP(hipMemsetAsync(L.d_feat_all, 0, (size_t)(2 * n_r) * 13 * sizeof(float), s));
   }

@@ -163,8 +163,28 @@ __device__ __forceinline__ void layer2_partial(const float* lds, const f32x16 (&
 
 __device__ __forceinline__ float sigmoidf(float x) { return 1.0f / (1.0f + expf(-x)); }
 
+// SHADE: the input row is not read from a (n,16) buffer but built here from the geometry network's
+// outputs — cat(feature(13), normalize(sdf_grad)(3)) (neus.py:143, texture.py:22): what
+// shade_prep_fwd_kernel materialised in a separate launch.  `normal_out` (n,3) is written for the
+// compositing kernels.
+struct ShadeIn {
+  const float* feature;   // (n,13)
+  const float* grad;      // (n,3)
+};
+
+__device__ __forceinline__ void load_shaded(const ShadeIn& si, int64_t ii, float (&in)[TIN],
+                                            float& inv_len) {
+#pragma unroll
+  for (int k = 0; k < 13; ++k) in[k] = si.feature[ii * 13 + k];
+  const float g0 = si.grad[ii * 3], g1 = si.grad[ii * 3 + 1], g2 = si.grad[ii * 3 + 2];
+  inv_len = 1.0f / fmaxf(sqrtf(g0 * g0 + g1 * g1 + g2 * g2), 1e-12f);
+  in[13] = g0 * inv_len; in[14] = g1 * inv_len; in[15] = g2 * inv_len;
+}
+
+template <bool SHADE>
 __global__ __launch_bounds__(256) void texture_fwd_kernel(dsu_tex_mlp m,
-                                                          const float* __restrict__ x, int64_t n,
+                                                          const float* __restrict__ x, ShadeIn sh,
+                                                          float* __restrict__ normal_out, int64_t n,
                                                           float* __restrict__ rgb) {
   __shared__ __attribute__((aligned(16))) float lds[L_WEND];
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
@@ -184,10 +204,18 @@ __global__ __launch_bounds__(256) void texture_fwd_kernel(dsu_tex_mlp m,
     const int64_t wave_first = base + wave * 64;
     if (wave_first >= r1) continue;                    // wave-uniform, no barrier in the loop
     float in[TIN];
+    if (SHADE) {
+      float inv_len;
+      load_shaded(sh, ii, in, inv_len);
+      if (valid) {
+        normal_out[i * 3] = in[13]; normal_out[i * 3 + 1] = in[14]; normal_out[i * 3 + 2] = in[15];
+      }
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(x + ii * TIN + 4 * q);
-      in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(x + ii * TIN + 4 * q);
+        in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+      }
     }
     float out[TOUT] = {0.0f, 0.0f, 0.0f};
 #pragma unroll 1
@@ -210,10 +238,21 @@ __global__ __launch_bounds__(256) void texture_fwd_kernel(dsu_tex_mlp m,
   }
 }
 
+// SHADE (backward): the gradient of the input row is not stored as (n,16) but pulled back through
+// cat / normalize right here (what shade_prep_bwd_kernel did in a separate launch):
+//   d_feature[s] = d_x[0:13];  dn = d_x[13:16] + d_normal[s];  d_grad[s] = (dn - n (n.dn)) / |grad|
+struct ShadeOut {
+  const float* d_normal;  // (n,3) from the compositing backward
+  float* d_grad;          // (n,3)
+  float* d_feature;       // (n + tail,13): rows n .. n + tail - 1 are set to zero (points that are
+  int64_t tail;           // not ray samples: the regulariser points of the same geometry launch)
+};
+
+template <bool SHADE>
 __global__ __launch_bounds__(256) void texture_bwd_kernel(
-    dsu_tex_mlp m, const float* __restrict__ x, const float* __restrict__ rgb,
-    const float* __restrict__ d_rgb, int64_t n, float* __restrict__ d_x,
-    float* __restrict__ partials) {
+    dsu_tex_mlp m, const float* __restrict__ x, ShadeIn sh, ShadeOut so,
+    const float* __restrict__ rgb, const float* __restrict__ d_rgb, int64_t n,
+    float* __restrict__ d_x, float* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   float* st = lds + L_WEND + wave * STAGE_F;
@@ -224,6 +263,11 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
   load_weights(lds, m);
   __syncthreads();
 
+  if (SHADE) {
+    for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < so.tail * 13;
+         t += (int64_t)gridDim.x * blockDim.x)
+      so.d_feature[n * 13 + t] = 0.0f;
+  }
   f32x16 gw1[2][2], gw0[2], gw2[2];     // D[i = row unit][j]: W1[i][j], W0[i][k | bias], W2^T[i][o]
   float gb1[2][16], gb2[TOUT] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
@@ -245,10 +289,15 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
     const int64_t wave_first = base + wave * 64;
     if (wave_first >= r1) continue;                    // wave-uniform, no workgroup barrier in the loop
     float in[TIN];
+    if (SHADE) {
+      float inv_len;
+      load_shaded(sh, ii, in, inv_len);
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float4 v = *reinterpret_cast<const float4*>(x + ii * TIN + 4 * q);
-      in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+      for (int q = 0; q < 4; ++q) {
+        const float4 v = *reinterpret_cast<const float4*>(x + ii * TIN + 4 * q);
+        in[4 * q] = v.x; in[4 * q + 1] = v.y; in[4 * q + 2] = v.z; in[4 * q + 3] = v.w;
+      }
     }
     // gradient on the pre-sigmoid outputs of the lane's own sample (0 for padding lanes)
     float dz[TOUT];
@@ -482,10 +531,36 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
       }
       const int64_t si = wave_first + a * 32 + l31;              // the sample of column l31
       if (si < r1) {
+        if (SHADE) {
+          // lane h holds components 8q + 4h + {0..3}: h = 0 -> 0-3, 8-11; h = 1 -> 4-7, 12-15
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-          *reinterpret_cast<float4*>(d_x + si * TIN + 8 * q + 4 * h) =
-              make_float4(din[4 * q], din[4 * q + 1], din[4 * q + 2], din[4 * q + 3]);
+          for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int comp = 8 * q + 4 * h + e;
+              if (comp < 13) so.d_feature[si * 13 + comp] = din[4 * q + e];
+            }
+          if (h == 1) {
+            const float g0 = sh.grad[si * 3], g1 = sh.grad[si * 3 + 1], g2 = sh.grad[si * 3 + 2];
+            const float len = sqrtf(g0 * g0 + g1 * g1 + g2 * g2);
+            const float inv = 1.0f / fmaxf(len, 1e-12f);
+            const float n0 = g0 * inv, n1 = g1 * inv, n2 = g2 * inv;
+            float d0 = din[5], d1 = din[6], d2 = din[7];          // components 13, 14, 15
+            if (so.d_normal) {
+              d0 += so.d_normal[si * 3]; d1 += so.d_normal[si * 3 + 1]; d2 += so.d_normal[si * 3 + 2];
+            }
+            const float dot = n0 * d0 + n1 * d1 + n2 * d2;
+            const bool ok = len > 1e-12f;
+            so.d_grad[si * 3] = ok ? (d0 - n0 * dot) * inv : d0 * inv;
+            so.d_grad[si * 3 + 1] = ok ? (d1 - n1 * dot) * inv : d1 * inv;
+            so.d_grad[si * 3 + 2] = ok ? (d2 - n2 * dot) * inv : d2 * inv;
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 2; ++q)
+            *reinterpret_cast<float4*>(d_x + si * TIN + 8 * q + 4 * h) =
+                make_float4(din[4 * q], din[4 * q + 1], din[4 * q + 2], din[4 * q + 3]);
+        }
       }
     }
   }
@@ -567,8 +642,18 @@ int dsu_texture_fwd(const dsu_tex_mlp* mlp, const float* tex_in, int64_t n, floa
                     void* stream) {
   if (!mlp_ok(mlp) || n < 0 || (n && (!tex_in || !rgb))) return DSU_EINVAL;
   if (n == 0) return DSU_OK;
-  texture_fwd_kernel<<<dsu_capped_blocks(n, 256, 2048), 256, 0, (hipStream_t)stream>>>(
-      *mlp, tex_in, n, rgb);
+  texture_fwd_kernel<false><<<dsu_capped_blocks(n, 256, 2048), 256, 0, (hipStream_t)stream>>>(
+      *mlp, tex_in, ShadeIn{nullptr, nullptr}, nullptr, n, rgb);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_texture_fwd_shaded(const dsu_tex_mlp* mlp, const float* feature, const float* grad,
+                           int64_t n, float* normal, float* rgb, void* stream) {
+  if (!mlp_ok(mlp) || n < 0 || (n && (!feature || !grad || !normal || !rgb))) return DSU_EINVAL;
+  if (n == 0) return DSU_OK;
+  texture_fwd_kernel<true><<<dsu_capped_blocks(n, 256, 2048), 256, 0, (hipStream_t)stream>>>(
+      *mlp, nullptr, ShadeIn{feature, grad}, normal, n, rgb);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }
@@ -592,9 +677,36 @@ int dsu_texture_bwd(const dsu_tex_mlp* mlp, const float* tex_in, const float* rg
   const int blocks = dsu_capped_blocks(n, 256, TEX_MAX_BLOCKS);
   const size_t shm = (size_t)BWD_LDS_F * sizeof(float);
   static_assert(PART_N <= 4 * STAGE_F, "reduction buffer must fit the staging area");
-  DSU_ENSURE_DYN_LDS(texture_bwd_kernel, shm);
-  texture_bwd_kernel<<<blocks, 256, shm, s>>>(*mlp, tex_in, rgb, d_rgb, n, d_tex_in,
-                                             (float*)workspace);
+  DSU_ENSURE_DYN_LDS(texture_bwd_kernel<false>, shm);
+  texture_bwd_kernel<false><<<blocks, 256, shm, s>>>(*mlp, tex_in, ShadeIn{nullptr, nullptr},
+                                                    ShadeOut{nullptr, nullptr, nullptr, 0}, rgb, d_rgb,
+                                                    n, d_tex_in, (float*)workspace);
+  texture_reduce_kernel<<<(PART_N + 63) / 64, 1024, 0, s>>>((const float*)workspace, blocks, g_w0,
+                                                           g_b0, g_w1, g_b1, g_w2, g_b2);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_texture_bwd_shaded(const dsu_tex_mlp* mlp, const float* feature, const float* grad,
+                           const float* rgb, const float* d_rgb, const float* d_normal, int64_t n,
+                           int64_t tail_rows, float* d_grad, float* d_feature, float* g_w0,
+                           float* g_b0, float* g_w1,
+                           float* g_b1, float* g_w2, float* g_b2, void* workspace,
+                           int64_t workspace_bytes, void* stream) {
+  if (!mlp_ok(mlp) || n < 0) return DSU_EINVAL;
+  if (!g_w0 || !g_b0 || !g_w1 || !g_b1 || !g_w2 || !g_b2) return DSU_EINVAL;
+  if (tail_rows < 0 || (n && (!feature || !grad || !rgb || !d_rgb || !d_grad || !d_feature)))
+    return DSU_EINVAL;
+  if (n == 0) return DSU_EUNSUP;                    // the caller zeroes the tail itself
+  const int64_t need = dsu_texture_bwd_workspace_bytes(n);
+  if (!workspace || workspace_bytes < need) return DSU_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = dsu_capped_blocks(n, 256, TEX_MAX_BLOCKS);
+  const size_t shm = (size_t)BWD_LDS_F * sizeof(float);
+  DSU_ENSURE_DYN_LDS(texture_bwd_kernel<true>, shm);
+  texture_bwd_kernel<true><<<blocks, 256, shm, s>>>(*mlp, nullptr, ShadeIn{feature, grad},
+                                                   ShadeOut{d_normal, d_grad, d_feature, tail_rows}, rgb, d_rgb,
+                                                   n, nullptr, (float*)workspace);
   texture_reduce_kernel<<<(PART_N + 63) / 64, 1024, 0, s>>>((const float*)workspace, blocks, g_w0,
                                                            g_b0, g_w1, g_b1, g_w2, g_b2);
   DSU_CHECK_LAUNCH();

@@ -443,6 +443,40 @@ def texture_bwd(params, tex_in, rgb, d_rgb):
     return d_in, g
 
 
+def texture_fwd_shaded(params, feature, grad):
+    """shade_prep_fwd + texture_fwd in one launch: returns (normal (n,3), rgb (n,3))."""
+    feature, grad = _f32c(feature), _f32c(grad)
+    n = feature.shape[0]
+    normal = torch.empty((n, 3), dtype=torch.float32, device=feature.device)
+    rgb = torch.empty((n, 3), dtype=torch.float32, device=feature.device)
+    m = _tex_struct(params)
+    check(lib().dsu_texture_fwd_shaded(C.byref(m), ptr(feature), ptr(grad), n, ptr(normal), ptr(rgb),
+                                       stream()), "dsu_texture_fwd_shaded")
+    return normal, rgb
+
+
+def texture_bwd_shaded(params, feature, grad, rgb, d_rgb, d_normal, tail_rows=0):
+    """texture_bwd + shade_prep_bwd in one launch (+ the reduction): returns
+    (d_grad (n,3), d_feature (n + tail_rows, 13) with zero tail rows, [g_w0 .. g_b2])."""
+    feature, grad, rgb, d_rgb = _f32c(feature), _f32c(grad), _f32c(rgb), _f32c(d_rgb)
+    n = rgb.shape[0]
+    dev = rgb.device
+    d_grad = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    d_feat = torch.empty((n + tail_rows, 13), dtype=torch.float32, device=dev)
+    sizes = [t.numel() for t in params]
+    flat = torch.zeros(sum(sizes), dtype=torch.float32, device=dev)
+    g = [v.view_as(t) for v, t in zip(torch.split(flat, sizes), params)]
+    wbytes = int(lib().dsu_texture_bwd_workspace_bytes(n))
+    ws = torch.empty(max(wbytes, 4) // 4, dtype=torch.float32, device=dev)
+    m = _tex_struct(params)
+    dn = None if d_normal is None else _f32c(d_normal)
+    check(lib().dsu_texture_bwd_shaded(C.byref(m), ptr(feature), ptr(grad), ptr(rgb), ptr(d_rgb),
+                                       ptr(dn), n, int(tail_rows), ptr(d_grad), ptr(d_feat),
+                                       *[ptr(t) for t in g], ptr(ws), wbytes, stream()),
+          "dsu_texture_bwd_shaded")
+    return d_grad, d_feat, g
+
+
 def ortho_ray_batch(index, x, y, c2w, origins, directions, images, normals, masks, view_weights):
     """Fused preprocess_data: returns the batch dict (rays (n,6), rgb, normal, mask, cosines,
     view_weights) for int64 (index, x, y) draws.  Dataset tensors (V,H,W,*) f32 contiguous."""

@@ -316,6 +316,20 @@ int dsu_texture_bwd(const dsu_tex_mlp* mlp, const float* tex_in, const float* rg
                     float* g_w1, float* g_b1, float* g_w2, float* g_b2, void* workspace,
                     int64_t workspace_bytes, void* stream);
 
+/* The same two calls with the shading glue of neus.py:143 / texture.py:22 inside: the input row is
+ * cat(feature (n,13), normalize(sdf_grad (n,3))) built in the kernel (`normal` (n,3) is written for
+ * the compositing kernels), and the backward pulls the row's gradient back through cat / normalize
+ * itself: d_feature (n + tail_rows, 13) (the tail rows zeroed), d_grad (n,3) =
+ * (dn - n (n.dn)) / |sdf_grad| with dn = d_row[13:16] + d_normal (d_normal may be NULL).  Replaces
+ * dsu_shade_prep_fwd + dsu_texture_fwd and dsu_texture_bwd + dsu_shade_prep_bwd. */
+int dsu_texture_fwd_shaded(const dsu_tex_mlp* mlp, const float* feature, const float* grad,
+                           int64_t n, float* normal, float* rgb, void* stream);
+int dsu_texture_bwd_shaded(const dsu_tex_mlp* mlp, const float* feature, const float* grad,
+                           const float* rgb, const float* d_rgb, const float* d_normal, int64_t n,
+                           int64_t tail_rows, float* d_grad, float* d_feature, float* g_w0,
+                           float* g_b0, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
+                           void* workspace, int64_t workspace_bytes, void* stream);
+
 /* OrthoNeuSSystem.preprocess_data (systems/neus_ortho.py:26-82) for n sampled (view, y, x)
  * triples (int64, drawn by the caller): c2w gather, get_ortho_rays (models/ray_utils.py:36-58),
  * colour / normal / mask / view-weight gathers, cosines = cosine_similarity(rays_d, normal,

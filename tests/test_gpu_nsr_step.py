@@ -393,3 +393,28 @@ def test_packed_step_buffers_equal_the_plain_calls(dev):
             perm = bufs.perm[:nn].long()
             assert torch.equal(torch.sort(perm).values, torch.arange(nn, device=dev))
             assert torch.equal(bufs.sorted[:nn], bufs.points[:nn][perm])
+
+
+@pytest.mark.parametrize("n", [1, 63, 1000, 100003])
+def test_shaded_texture_kernels_equal_the_separate_launches(dev, n):
+    """dsu_texture_fwd_shaded / _bwd_shaded = shade_prep + texture MLP (+ their backward) in one
+    launch each: the same arithmetic on the same values — per-sample results are bit-identical."""
+    g = torch.Generator().manual_seed(n)
+    mk = lambda *s: (torch.randn(*s, generator=g)).to(dev)
+    params = [mk(64, 16) * 0.3, mk(64) * 0.1, mk(64, 64) * 0.15, mk(64) * 0.1, mk(3, 64) * 0.2,
+              mk(3) * 0.1]
+    feat, grad = mk(n + 7, 13), mk(n + 7, 3)
+    grad[0] = 0.0                                            # zero gradient: the clamped-norm branch
+    d_rgb, d_normal = mk(n, 3), mk(n, 3)
+    normal, tex_in = ops.shade_prep_fwd(grad[:n].contiguous(), feat[:n].contiguous())
+    rgb = ops.texture_fwd(params, tex_in)
+    d_tex_in, gp = ops.texture_bwd(params, tex_in, rgb, d_rgb)
+    d_grad, d_feat = ops.shade_prep_bwd(grad[:n].contiguous(), d_normal, d_tex_in)
+    normal2, rgb2 = ops.texture_fwd_shaded(params, feat[:n].contiguous(), grad[:n].contiguous())
+    assert torch.equal(normal2, normal) and torch.equal(rgb2, rgb)
+    d_grad2, d_feat2, gp2 = ops.texture_bwd_shaded(params, feat[:n].contiguous(), grad[:n].contiguous(),
+                                                   rgb2, d_rgb, d_normal, tail_rows=7)
+    assert torch.equal(d_grad2, d_grad)
+    assert torch.equal(d_feat2[:n], d_feat) and float(d_feat2[n:].abs().max()) == 0.0
+    for a, b in zip(gp, gp2):          # sums over the samples: the two instantiations agree to rounding
+        torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(a.abs().max()))
