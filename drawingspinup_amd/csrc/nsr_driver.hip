@@ -344,10 +344,11 @@ struct dsu_nsr_driver {
   // step t+1's — three sets in flight, indexed by step % 3.
   hipStream_t side = nullptr;
   hipEvent_t ready[3] = {nullptr, nullptr, nullptr};   // side: set packed, stats copied to the host
-  hipEvent_t freed[3] = {nullptr, nullptr, nullptr};   // main: the step that used the set has been queued
   hipEvent_t gate = nullptr;                           // main: MLP part of the latest backward done
   hipEvent_t fwd_done = nullptr;                       // main: this step's geometry forward done
-  bool side_high_priority = true, pack_behind_fwd = true;   // A/B switches (DSU_NSR_SIDE_PRIO / _PACK_GATE)
+  bool side_high_priority = true;   // DSU_NSR_SIDE_PRIO
+  int pack_gate = 1;                // DSU_NSR_PACK_GATE: 0 with the march, 1 behind this step's geometry
+                                    // forward (own event), 2 behind the MLP part of this step's backward
   int32_t* host_stats = nullptr;                       // pinned, 3 x int32[2]
   bool pf_valid[3] = {false, false, false};
   int64_t pf_step[3] = {-1, -1, -1};
@@ -515,13 +516,12 @@ int dsu_nsr_driver_create(const dsu_nsr_driver_cfg* cfg, dsu_nsr_driver** out) {
   d->rowcap = march_row_capacity(cfg->radius, cfg->render_step_size);
   int lo = 0, hi = 0;
   if (const char* e = getenv("DSU_NSR_SIDE_PRIO")) d->side_high_priority = atoi(e) != 0;
-  if (const char* e = getenv("DSU_NSR_PACK_GATE")) d->pack_behind_fwd = atoi(e) != 0;
+  if (const char* e = getenv("DSU_NSR_PACK_GATE")) d->pack_gate = atoi(e);
   bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
             hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking,
                                         d->side_high_priority ? hi : lo) == hipSuccess;
   for (int p = 0; p < 3; ++p)
-    ok = ok && hipEventCreateWithFlags(&d->ready[p], hipEventDisableTiming) == hipSuccess &&
-         hipEventCreateWithFlags(&d->freed[p], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&d->ready[p], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->gate, hipEventDisableTiming) == hipSuccess &&
        hipEventCreateWithFlags(&d->fwd_done, hipEventDisableTiming) == hipSuccess &&
        hipHostMalloc((void**)&d->host_stats, 6 * sizeof(int32_t), hipHostMallocDefault) == hipSuccess;
@@ -539,10 +539,8 @@ void dsu_nsr_driver_destroy(dsu_nsr_driver* d) {
     (void)hipStreamSynchronize(d->side);
     (void)hipStreamDestroy(d->side);
   }
-  for (int p = 0; p < 3; ++p) {
+  for (int p = 0; p < 3; ++p)
     if (d->ready[p]) (void)hipEventDestroy(d->ready[p]);
-    if (d->freed[p]) (void)hipEventDestroy(d->freed[p]);
-  }
   if (d->gate) (void)hipEventDestroy(d->gate);
   if (d->fwd_done) (void)hipEventDestroy(d->fwd_done);
   if (d->host_stats) (void)hipHostFree(d->host_stats);
@@ -613,15 +611,16 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
     // trace).  It is therefore queued one step earlier, behind the MLP part of the backward the
     // device is executing NOW (`gate`, recorded by the previous call): it then runs beside the
     // table-gradient scatter, the optimizer kernels and the next geometry forward, which all
-    // leave registers free.  Set q was last read by step t-2.
+    // leave registers free.  Set q was last read by step t-2, whose kernels precede `gate` in
+    // the main stream's order: no event of its own (an event record costs the main queue a
+    // 6-11 us bubble: barrier packet + the next dispatch waiting for it).
     const int q = (int)((a->step + 1) % 3);
     DSU_HIP(hipStreamWaitEvent(d->side, d->gate, 0));
-    DSU_HIP(hipStreamWaitEvent(d->side, d->freed[q], 0));
     dsu_nsr_step_args na = *a;
     na.inj_index = na.inj_x = na.inj_y = nullptr;
     na.inj_jitter = na.inj_pts_random = na.inj_perturb = nullptr;
     DSU_TRY(enqueue_march(d, q, a->step + 1, next_rays, na, false, d->side));
-    if (!d->pack_behind_fwd) {
+    if (d->pack_gate == 0) {
       DSU_TRY(enqueue_pack(d, q, next_rays, na, false, d->side));
       DSU_HIP(hipEventRecord(d->ready[q], d->side));
     }
@@ -640,7 +639,7 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
                                 a->active_levels, L.a_sdf, L.a_grad, L.a_feat, nullptr, L.enc_cache, s));
   DSU_TRY(mark(d, 0, s));
   if (d->timing) d->work[0] += alg_bytes;
-  if (a->prefetch_next && d->pack_behind_fwd) {
+  if (a->prefetch_next && d->pack_gate == 1) {
     // The packing / sorting launches of the next set (a dozen short, chip-wide kernels) slowed the
     // gather-bound geometry forward by a quarter when they ran beside it (kernel trace: 221 vs
     // 175 us); behind it they share the chip with the small shading / loss kernels instead.
@@ -690,9 +689,22 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
                                     d->gate, s));
   DSU_TRY(mark(d, 1, s));
   if (d->timing) d->work[1] += alg_bytes;
-  // ---- optimizer step of the small tensors (the hash table's is the caller's dsu_table_adamw)
+  if (a->prefetch_next && d->pack_gate == 2) {
+    const int q = (int)((a->step + 1) % 3);
+    dsu_nsr_step_args na = *a;
+    na.inj_index = na.inj_x = na.inj_y = nullptr;
+    na.inj_jitter = na.inj_pts_random = na.inj_perturb = nullptr;
+    DSU_HIP(hipStreamWaitEvent(d->side, d->gate, 0));          // recorded inside the call above
+    DSU_TRY(enqueue_pack(d, q, next_rays, na, false, d->side));
+    DSU_HIP(hipEventRecord(d->ready[q], d->side));
+  }
+  // ---- optimizer: the hash table (active levels; level / decay bookkeeping is the caller's) ...
+  if (a->table_p)
+    DSU_TRY(dsu_table_adamw(a->table_p, a->table_grad, a->table_m, a->table_v,
+                            const_cast<void*>(a->table_img), a->table_n, a->table_lr, c.beta1, c.beta2,
+                            a->table_eps, a->table_wd, a->table_bc1, a->table_bc2_sqrt, s));
+  // ... and the small tensors
   DSU_TRY(launch_small_update(d, a, 1, s));
-  DSU_HIP(hipEventRecord(d->freed[p], s));          // set p may be refilled once this has run
   return DSU_OK;
 }
 

@@ -281,7 +281,9 @@ class TableAdamW:
             self.img = self.enc.lock_shadow()
         self._catch_up(max(active_levels, self.active))
 
-    def step(self, active_levels, lr=None):
+    def prepare_step(self, active_levels, lr=None):
+        """Host bookkeeping of one update: returns the launch arguments of `dsu_table_adamw`
+        (n floats of the active levels, lr, bias corrections).  `commit_step(lr)` afterwards."""
         lr = self.lr if lr is None else lr
         if self.img is None or self.enc._shadow is not self.img or not self.enc._shadow_locked:
             self.img = self.enc.lock_shadow()      # first step, or someone invalidated the image
@@ -290,14 +292,20 @@ class TableAdamW:
             # live, handle everything densely from here on
             active_levels = self.active
         self._catch_up(active_levels)
-        self.step_count += 1
         b1, b2 = self.betas
-        bc1 = 1.0 - b1 ** self.step_count
-        bc2_sqrt = math.sqrt(1.0 - b2 ** self.step_count)
-        n = self.offsets[self.active]
+        k = self.step_count + 1
+        return self.offsets[self.active], lr, 1.0 - b1 ** k, math.sqrt(1.0 - b2 ** k)
+
+    def commit_step(self, lr):
+        self.step_count += 1
+        self.pending *= 1.0 - lr * self.wd
+
+    def step(self, active_levels, lr=None):
+        n, lr, bc1, bc2_sqrt = self.prepare_step(active_levels, lr)
+        b1, b2 = self.betas
         ops.table_adamw(self.enc.params.data, self.grad, self.m, self.v, self.img, n, lr, b1, b2,
                         self.eps, self.wd, bc1, bc2_sqrt)
-        self.pending *= 1.0 - lr * self.wd
+        self.commit_step(lr)
 
     def finalize(self):
         """Bring the still-masked levels up to date (end of fit, before state_dict / export)."""
@@ -689,7 +697,11 @@ class OrthoNeuSSystem:
             a.occ_binary, a.occ_res = None, 0
         topt = self.table_opt
         topt.activate(int(geo.active_levels))
+        n_tab, lr_tab, bc1, bc2s = topt.prepare_step(int(geo.active_levels), lrs["geometry"])
         a.table_img, a.table_grad = topt.img.data_ptr(), topt.grad.data_ptr()
+        a.table_p, a.table_m, a.table_v = enc.params.data_ptr(), topt.m.data_ptr(), topt.v.data_ptr()
+        a.table_n, a.table_lr, a.table_bc1, a.table_bc2_sqrt = int(n_tab), lr_tab, bc1, bc2s
+        a.table_eps, a.table_wd = float(topt.eps), float(topt.wd)
         for attempt in range(6):
             rc = drv._lib.lib().dsu_nsr_driver_step(drv.handle, C.byref(a), ops.stream())
             if rc != -3 or a.out_n_samples <= _PACK_CAPACITY or a.n_rays <= 64:
@@ -706,7 +718,7 @@ class OrthoNeuSSystem:
         n_rays = int(self.train_num_rays)
         if m.config.dynamic_ray_sampling:
             self.train_num_rays = int(a.out_next_n_rays)
-        self._step_table(geo.active_levels)
+        topt.commit_step(lr_tab)               # the update itself was launched by the driver
         self.global_step += 1
         t = drv.terms2[(self.global_step - 1) & 1]
         L = self.config.loss

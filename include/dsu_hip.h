@@ -640,7 +640,7 @@ int dsu_adamw_multi(const dsu_adamw_tensor* tensors, int32_t count, float beta1,
  * variance groups (configs/neuralangelo-ortho-wmask.yaml:96-127) sequenced by the library
  * itself: the host-side cost of a step is ~20 kernel launches issued from C instead of ~1.4 ms
  * of interpreter work (as long as the step's device time).  The hash table's own update stays the
- * caller's dsu_table_adamw (level bookkeeping), the occupancy-grid refresh of every 16th step
+ * caller's bookkeeping (levels, lazy decay) with the launch itself inside the step, the occupancy-grid refresh of every 16th step
  * the caller's too (dsu_sdf_fwd + dsu_occgrid_*).
  *
  * All device memory is the caller's: parameters, dataset tensors and ONE workspace of
@@ -696,8 +696,14 @@ typedef struct dsu_nsr_step_args {
   /* injected draws for THIS step (tests; any NULL = the driver's own draw) */
   const int64_t *inj_index, *inj_x, *inj_y;
   const float *inj_jitter, *inj_pts_random, *inj_perturb;
+  /* the hash table's AdamW step (dsu_table_adamw), launched by the driver behind the backward:
+   * master parameters and moments, number of floats of the active levels, this step's lr and
+   * bias corrections (the caller keeps the level / decay bookkeeping); table_p NULL = skip */
+  float *table_p, *table_m, *table_v;
+  int64_t table_n;
+  float table_lr, table_bc1, table_bc2_sqrt, table_eps, table_wd;
   /* outputs (host) */
-  int32_t out_n_samples, out_max_count, out_next_n_rays, reserved;
+  int32_t out_n_samples, out_max_count, out_next_n_rays;
 } dsu_nsr_step_args;
 
 /* The random draws of step `step` (neus_ortho.py:31-41: view / pixel triples of the ray batch;
