@@ -91,6 +91,25 @@ __device__ __forceinline__ int dpp_i(int v) {
   return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
 }
 
+// Takes a value over from the vector-memory pipeline: the compiler has to wait for the load that
+// produces it HERE, and every later use sees an ordinary register (no instruction is emitted).
+// (-DDSU_K1_ROLLED, variant build for A/B runs: no hand-overs and the point halves as a loop — the
+// waits then sit where the compiler puts them, as before round 3)
+#ifdef DSU_K1_ROLLED
+__device__ __forceinline__ void vm_take(float&) {}
+__device__ __forceinline__ void vm_take(__half2&) {}
+#define DSU_K1_HALF_UNROLL(c) 1
+#else
+#define DSU_K1_HALF_UNROLL(c) ((c) ? 2 : 1)
+__device__ __forceinline__ void vm_take(float& x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void vm_take(__half2& x) {
+  uint32_t u;
+  __builtin_memcpy(&u, &x, 4);
+  asm volatile("" : "+v"(u));
+  __builtin_memcpy(&x, &u, 4);
+}
+#endif
+
 template <int NL>
 struct Frags {
   float w0[2][MC<NL>::KP];   // A operand of layer 0: W0'[32T + (lane&31)][2t + (lane>>5)]
@@ -509,19 +528,41 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     float ds = 0.f, dl = 0.f, dg[3] = {0.f, 0.f, 0.f};
     // sorted evaluation order: the upstream gradients stay in the caller's row order
     const int64_t gi = perm ? (int64_t)perm[ii] : ii;
+    float dfe[NOUT];                   // upstream gradient on the centre evaluation's feature vector
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) dfe[o] = 0.0f;
     if (valid) {
       if (d_sdf) ds = d_sdf[gi];
       if (d_laplace) dl = d_laplace[gi];
       if (d_grad) { dg[0] = d_grad[gi * 3]; dg[1] = d_grad[gi * 3 + 1]; dg[2] = d_grad[gi * 3 + 2]; }
-    }
-    __half2 rw[NL];                    // feature-cache row of the NEXT evaluation (ENC path)
+      if (d_feature) {
 #pragma unroll
-    for (int l = 0; l < NL; ++l) rw[l] = __float2half2_rn(0.0f);
+        for (int o = 0; o < NOUT; ++o) dfe[o] = d_feature[gi * NOUT + o];
+      }
+    }
+    // Feature-cache rows (ENC path): `rw` is the row of the CURRENT evaluation, `rwn` the one in
+    // flight for the next.  Where the kernel waits for a load matters at one wave per SIMD, and the
+    // wait counter is shared by loads and stores (a wait for a load while stores are in flight is
+    // vmcnt(0)): a use of a loaded register right behind the dIn stores of an evaluation, or a
+    // use inside a loop entered right behind the loads (the compiler then drains the counter in
+    // the loop preheader), cost ~3.6 k clocks per evaluation (10 % of the kernel, phase clocks).
+    // Every loaded value is therefore taken over (`vm_take`) at a point where everything in flight
+    // was issued thousands of clocks earlier: the prologue values here, the next row in front of
+    // the second point half's stores.
+    __half2 rw[NL], rwn[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) rw[l] = rwn[l] = __float2half2_rn(0.0f);
     if (ENC) {
+      // (unconditional loads from a clamped column: a branch per level kept the compiler from
+      // issuing the row's loads together; masked levels are zeroed where the row is used)
       const __half2* row = enc + (size_t)ii * active;
 #pragma unroll
-      for (int l = 0; l < NL; ++l)
-        if ((uint32_t)l < active) rw[l] = row[l];
+      for (int l = 0; l < NL; ++l) rw[l] = row[(uint32_t)l < active ? l : 0];
+#pragma unroll
+      for (int l = 0; l < NL; ++l) vm_take(rw[l]);
+      vm_take(ds); vm_take(dl); vm_take(dg[0]); vm_take(dg[1]); vm_take(dg[2]);
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) vm_take(dfe[o]);
     }
     const int n_eval = wave_first < r1 ? 7 : 0;             // a wave beyond the range only joins the barriers
 #pragma unroll 1
@@ -541,14 +582,13 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
           const float2 f = __half22float2(rw[l]);
-          in[2 * l] = f.x;
-          in[2 * l + 1] = f.y;
+          in[2 * l] = (uint32_t)l < active ? f.x : 0.0f;
+          in[2 * l + 1] = (uint32_t)l < active ? f.y : 0.0f;
         }
         if (e < 6) {
           const __half2* row = enc + ((size_t)(e + 1) * n + ii) * active;
 #pragma unroll
-          for (int l = 0; l < NL; ++l)
-            if ((uint32_t)l < active) rw[l] = row[l];
+          for (int l = 0; l < NL; ++l) rwn[l] = row[(uint32_t)l < active ? l : 0];
         }
         in[2 * NL + 0] = cx * 2.0f + -1.0f;
         in[2 * NL + 1] = cy * 2.0f + -1.0f;
@@ -564,10 +604,8 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
       for (int o = 0; o < NOUT; ++o) dout[o] = 0.0f;
       if (valid) {
         if (e == 0) {
-          if (d_feature) {
 #pragma unroll
-            for (int o = 0; o < NOUT; ++o) dout[o] = d_feature[gi * NOUT + o];
-          }
+          for (int o = 0; o < NOUT; ++o) dout[o] = dfe[o];
           dout[0] += ds - 6.0f * dl / eps2;
         } else {
           const int ax = (e - 1) >> 1;
@@ -583,11 +621,16 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
       const float pcx = partner32(cx, h), pcy = partner32(cy, h), pcz = partner32(cz, h);
 
       DSU_PROF(1)   // upstream gradient loads
-#pragma unroll 1
+      // (SPLIT && ENC: both halves as straight-line code, so that the hand-over of the next row
+      // below is on every path and not inside a loop)
+#pragma unroll DSU_K1_HALF_UNROLL(SPLIT && ENC && NL <= 10)
       for (int half = 0; half < 2; ++half) {
-        if (wave_first + half * 32 >= r1) continue;          // no point in this half (wave-uniform)
-        // gradient on the outputs of the points of this half: own if this lane owns the half
+        const bool live = wave_first + half * 32 < r1;       // a point in this half (wave-uniform)
+        f32x16 din;
+        f32x16 Hh[2];
         float d[NOUT];
+        if (live) {
+        // gradient on the outputs of the points of this half: own if this lane owns the half
 #pragma unroll
         for (int o = 0; o < NOUT; ++o) {
           float other = 0.0f;
@@ -595,10 +638,8 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
           d[o] = (h == half) ? dout[o] : other;
         }
         DSU_PROF(2)   // partner shuffles
-        f32x16 Hh[2];
         layer0_mfma_half<NL>(fr, in, active, half, Hh, ablate);
         DSU_PROF(3)   // layer 0 + softplus
-        f32x16 din;
 #pragma unroll
         for (int r = 0; r < 16; ++r) din[r] = 0.0f;
 #ifdef DSU_DIN_2ACC
@@ -788,6 +829,17 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
             for (int r = 0; r < 16; ++r) gw1c0[T][r] = fmaf(Hh[T][r], d[0], gw1c0[T][r]);
         }
         DSU_PROF(7)   // gW1 GEMM / column
+        }  // live
+        if (ENC && half == 1 && e < 6) {
+          // the next evaluation's row, requested ~30 k clocks ago; the stores in flight are the
+          // first half's (~8 k clocks old)
+#pragma unroll
+          for (int l = 0; l < NL; ++l) {
+            vm_take(rwn[l]);
+            rw[l] = rwn[l];
+          }
+        }
+        if (!live) continue;
         // scatter dIn rows held by this lane: input row i = (r&3) + 8(r>>2) + 4h, levels (i>>1)
         if (SPLIT) {
           // dIn of this half's points -> dinbuf: lane (l31, h) holds the feature pairs of levels
