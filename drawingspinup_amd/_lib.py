@@ -132,6 +132,9 @@ _PROTOS = {
     "dsu_point_bin_count": [P, c_i64, c_f32, c_f32, c_f32, c_i32, P, P],
     "dsu_point_bin_fill": [P, c_i64, c_f32, c_f32, c_f32, c_i32, P, P, P, P],
     "dsu_knn8_blend": [P, c_i64, P, P, c_i64, c_f32, c_f32, c_f32, c_i32, P, P, P, P],
+    "dsu_mesh_decimate_quadric": [P, c_i64, P, c_i64, c_i64, C.c_double, c_i32, P, P, P, P],
+    "dsu_distance_transform_l2_5x5": [P, c_i32, c_i32, P],
+    "dsu_skeletonize_lee_2d": [P, c_i32, c_i32, P],
     "dsu_nsr_draws": [C.c_uint64, c_i64, c_i32, c_i32, c_i32, c_i32, P, P, P, P, c_i32, P, P, P],
     "dsu_nsr_driver_workspace_bytes": [C.POINTER(NsrDriverCfg)],
     "dsu_nsr_driver_create": [C.POINTER(NsrDriverCfg), C.POINTER(c_vp)],

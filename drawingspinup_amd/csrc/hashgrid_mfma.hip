@@ -528,16 +528,19 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     float ds = 0.f, dl = 0.f, dg[3] = {0.f, 0.f, 0.f};
     // sorted evaluation order: the upstream gradients stay in the caller's row order
     const int64_t gi = perm ? (int64_t)perm[ii] : ii;
-    float dfe[NOUT];                   // upstream gradient on the centre evaluation's feature vector
+    // (NL = 12 has no registers left for the hoisted loads and the second row below: it keeps the
+    // form with the loads inside the evaluation loop)
+    constexpr bool HANDOVER = NL <= 10;
+    float dfe[HANDOVER ? NOUT : 1];    // upstream gradient on the centre evaluation's feature vector
 #pragma unroll
-    for (int o = 0; o < NOUT; ++o) dfe[o] = 0.0f;
+    for (int o = 0; o < (HANDOVER ? NOUT : 1); ++o) dfe[o] = 0.0f;
     if (valid) {
       if (d_sdf) ds = d_sdf[gi];
       if (d_laplace) dl = d_laplace[gi];
       if (d_grad) { dg[0] = d_grad[gi * 3]; dg[1] = d_grad[gi * 3 + 1]; dg[2] = d_grad[gi * 3 + 2]; }
-      if (d_feature) {
+      if (HANDOVER && d_feature) {
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) dfe[o] = d_feature[gi * NOUT + o];
+        for (int o = 0; o < NOUT; ++o) dfe[HANDOVER ? o : 0] = d_feature[gi * NOUT + o];
       }
     }
     // Feature-cache rows (ENC path): `rw` is the row of the CURRENT evaluation, `rwn` the one in
@@ -549,20 +552,24 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     // Every loaded value is therefore taken over (`vm_take`) at a point where everything in flight
     // was issued thousands of clocks earlier: the prologue values here, the next row in front of
     // the second point half's stores.
-    __half2 rw[NL], rwn[NL];
+    __half2 rw[NL], rwn[HANDOVER ? NL : 1];
 #pragma unroll
-    for (int l = 0; l < NL; ++l) rw[l] = rwn[l] = __float2half2_rn(0.0f);
+    for (int l = 0; l < NL; ++l) rw[l] = __float2half2_rn(0.0f);
+#pragma unroll
+    for (int l = 0; l < (HANDOVER ? NL : 1); ++l) rwn[l] = __float2half2_rn(0.0f);
     if (ENC) {
       // (unconditional loads from a clamped column: a branch per level kept the compiler from
       // issuing the row's loads together; masked levels are zeroed where the row is used)
       const __half2* row = enc + (size_t)ii * active;
 #pragma unroll
       for (int l = 0; l < NL; ++l) rw[l] = row[(uint32_t)l < active ? l : 0];
+      if (HANDOVER) {
 #pragma unroll
-      for (int l = 0; l < NL; ++l) vm_take(rw[l]);
-      vm_take(ds); vm_take(dl); vm_take(dg[0]); vm_take(dg[1]); vm_take(dg[2]);
+        for (int l = 0; l < NL; ++l) vm_take(rw[l]);
+        vm_take(ds); vm_take(dl); vm_take(dg[0]); vm_take(dg[1]); vm_take(dg[2]);
 #pragma unroll
-      for (int o = 0; o < NOUT; ++o) vm_take(dfe[o]);
+        for (int o = 0; o < NOUT; ++o) vm_take(dfe[HANDOVER ? o : 0]);
+      }
     }
     const int n_eval = wave_first < r1 ? 7 : 0;             // a wave beyond the range only joins the barriers
 #pragma unroll 1
@@ -588,7 +595,10 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
         if (e < 6) {
           const __half2* row = enc + ((size_t)(e + 1) * n + ii) * active;
 #pragma unroll
-          for (int l = 0; l < NL; ++l) rwn[l] = row[(uint32_t)l < active ? l : 0];
+          for (int l = 0; l < NL; ++l) {
+            if (HANDOVER) rwn[HANDOVER ? l : 0] = row[(uint32_t)l < active ? l : 0];
+            else rw[l] = row[(uint32_t)l < active ? l : 0];
+          }
         }
         in[2 * NL + 0] = cx * 2.0f + -1.0f;
         in[2 * NL + 1] = cy * 2.0f + -1.0f;
@@ -604,8 +614,13 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
       for (int o = 0; o < NOUT; ++o) dout[o] = 0.0f;
       if (valid) {
         if (e == 0) {
+          if (HANDOVER) {
 #pragma unroll
-          for (int o = 0; o < NOUT; ++o) dout[o] = dfe[o];
+            for (int o = 0; o < NOUT; ++o) dout[o] = dfe[HANDOVER ? o : 0];
+          } else if (d_feature) {
+#pragma unroll
+            for (int o = 0; o < NOUT; ++o) dout[o] = d_feature[gi * NOUT + o];
+          }
           dout[0] += ds - 6.0f * dl / eps2;
         } else {
           const int ax = (e - 1) >> 1;
@@ -830,13 +845,13 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
         }
         DSU_PROF(7)   // gW1 GEMM / column
         }  // live
-        if (ENC && half == 1 && e < 6) {
+        if (ENC && HANDOVER && half == 1 && e < 6) {
           // the next evaluation's row, requested ~30 k clocks ago; the stores in flight are the
           // first half's (~8 k clocks old)
 #pragma unroll
           for (int l = 0; l < NL; ++l) {
-            vm_take(rwn[l]);
-            rw[l] = rwn[l];
+            vm_take(rwn[HANDOVER ? l : 0]);
+            rw[l] = rwn[HANDOVER ? l : 0];
           }
         }
         if (!live) continue;

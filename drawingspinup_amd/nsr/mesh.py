@@ -36,9 +36,9 @@ in the snapshot: PARITY UNPINNED for those two packages).  What is restated, and
 
 Everything runs as tensor programs on the device (prefix sums over the sweep order instead of the
 serial vertex list); the integer outputs are checked bit for bit against a serial restatement
-(oracle/mcubes_ref.py).  Not here: trimesh quadric decimation (`remesh`, geometry.py:63-64) and
-the thinning / Laplacian smoothing / colour back-projection / shear / uv steps of save_mesh
-(trimesh, igl, mesh_raycast: CPU geometry).
+(oracle/mcubes_ref.py).  `remesh` (geometry.py:63-64: quadric decimation of the fine mesh to
+50 000 faces) is host code of the library (csrc/mesh_decimate.hip), as it is host code in the
+reference; save_mesh's steps are further down and in nsr/mesh_post.py, nsr/thinning.py.
 """
 import functools
 import math
@@ -460,14 +460,36 @@ def resize_cubic_u8(img, out_hw):
 # ------------------------------------------------------------------------------------------------
 # MarchingCubeHelper / isosurface / export
 # ------------------------------------------------------------------------------------------------
-class MarchingCubeHelper:
-    """geometry.py:33-69 (remeshing = trimesh quadric decimation is not part of this path)."""
+def remesh(verts, faces, face_count, boundary_weight=1.0, keep_manifold=True):
+    """mesh_utils.py:10-22 (`trimesh.simplify_quadratic_decimation(face_count)` -> Open3D's quadric
+    decimation): (N,3) float verts, (M,3) int faces -> (verts float64, faces int64), collapsed until
+    the face count is <= face_count (or no admissible collapse is left).  Host arrays in and out —
+    `dsu_mesh_decimate_quadric` (restated from the published method; trimesh / Open3D are absent:
+    unpinned — see the kernel file's header for what is kept and what is added)."""
+    import ctypes as C
+    from .. import _lib, ops
+    v = np.ascontiguousarray(np.asarray(verts.detach().cpu() if torch.is_tensor(verts) else verts,
+                                        dtype=np.float64))
+    f = np.ascontiguousarray(np.asarray(faces.detach().cpu() if torch.is_tensor(faces) else faces)
+                             .astype(np.int32))
+    ov, of = np.empty_like(v), np.empty_like(f)
+    nv, nf = C.c_int64(0), C.c_int64(0)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    ops.check(_lib.lib().dsu_mesh_decimate_quadric(
+        p(v), v.shape[0], p(f), f.shape[0], int(face_count), float(boundary_weight),
+        0 if keep_manifold else 1, p(ov), C.byref(nv), p(of), C.byref(nf)), "dsu_mesh_decimate_quadric")
+    return ov[:nv.value].copy(), of[:nf.value].astype(np.int64)
 
-    def __init__(self, resolution):
+
+class MarchingCubeHelper:
+    """geometry.py:33-69; `face_count` switches the fine stage's `remesh` on (geometry.py:63-64)."""
+
+    def __init__(self, resolution, face_count=None):
         self.resolution = int(resolution)
+        self.face_count = face_count
 
     @torch.no_grad()
-    def __call__(self, level, threshold=0.0, front_mask=None):
+    def __call__(self, level, threshold=0.0, front_mask=None, fine_stage=False):
         res = self.resolution
         level = level.float().view(res, res, res)
         binary = level <= 0
@@ -476,7 +498,12 @@ class MarchingCubeHelper:
             binary = binary & (fm[:, None, :].expand(res, res, res) > 127)       # np.tile(front_mask[:, None, :])
         value = smooth_constrained(binary)
         verts, faces = marching_cubes(value, threshold)
-        return {"verts": verts / (res - 1.0), "faces": faces, "binary": binary}
+        verts = verts / (res - 1.0)
+        if fine_stage and self.face_count and faces.shape[0] > int(self.face_count):
+            v, f = remesh(verts, faces, int(self.face_count))
+            verts = torch.from_numpy(v).to(verts.device)
+            faces = torch.from_numpy(f).to(faces.device)
+        return {"verts": verts, "faces": faces, "binary": binary}
 
 
 def scale_anything(x, src, dst):                    # instant_nsr/models/utils.py:101-106
@@ -492,19 +519,19 @@ def crop_front_mask(front_mask, vmin, vmax):
 
 
 @torch.no_grad()
-def isosurface(model, front_mask=None, resolution=None):
+def isosurface(model, front_mask=None, resolution=None, face_count=None):
     """BaseImplicitGeometry.isosurface (geometry.py:108-117) on the device: coarse pass over the
     whole box, bounding box of the coarse MESH's vertices padded by 10 % and clamped, fine pass in
-    it with the front mask.  Returns the fine mesh {verts (N,3) f64 world, faces (M,3) i64} plus
-    the two level volumes."""
+    it with the front mask (and, with `face_count`, the fine stage's remesh).  Returns the fine
+    mesh {verts (N,3) f64 world, faces (M,3) i64} plus the two level volumes."""
     r = float(model.config.radius)
     res = resolution or model.config.geometry.isosurface.resolution
     thr = float(model.config.geometry.isosurface.threshold)
-    helper = MarchingCubeHelper(res)
+    helper = MarchingCubeHelper(res, face_count)
 
-    def one(vmin, vmax, fm):
+    def one(vmin, vmax, fm, fine_stage=False):
         level = model.isosurface_levels(vmin, vmax, res)
-        mesh = helper(level, thr, fm)
+        mesh = helper(level, thr, fm, fine_stage)
         v = mesh["verts"]
         mesh["verts"] = torch.stack([scale_anything(v[:, a], (0, 1), (vmin[a], vmax[a])) for a in range(3)], -1)
         mesh["level"] = level
@@ -517,7 +544,7 @@ def isosurface(model, front_mask=None, resolution=None):
     vmin_ = (vmin - (vmax - vmin) * 0.1).clamp(-r, r).tolist()
     vmax_ = (vmax + (vmax - vmin) * 0.1).clamp(-r, r).tolist()
     fm = None if front_mask is None else crop_front_mask(front_mask, vmin_, vmax_)
-    fine = one(vmin_, vmax_, fm)
+    fine = one(vmin_, vmax_, fm, True)
     fine["vmin"], fine["vmax"] = vmin_, vmax_
     return fine, coarse
 
@@ -595,7 +622,7 @@ def nearest_vertex_colors(old_verts, new_verts, colors):
 
 
 def save_obj(path, verts, faces, colors=None, ortho_scale=1.35, smoothing=False, shearing=False,
-             color_back_projection=None):
+             color_back_projection=None, thinning=None):
     """save_mesh (mesh_utils.py:25-73): halve, swap to the front-facing convention (x right, y up,
     z front), [Laplacian smoothing], [colour back-projection | nearest-vertex colour transfer],
     [shear], ortho_scale, OBJ with per-vertex colours (trimesh's export of `vertex_colors`:
@@ -603,13 +630,20 @@ def save_obj(path, verts, faces, colors=None, ortho_scale=1.35, smoothing=False,
     them on).  color_back_projection: dict(color_front, mask_front, color_back) of (res,res[,3])
     uint8 device tensors — the LANCZOS-resized <uid>/mv PNGs — runs nsr/mesh_post.color_projection
     (coloring_utils.py:91-138) on the device instead of the nearest-vertex transfer
-    (mesh_utils.py:48-53).  Thinning's harmonic deformation (igl) and decimation (trimesh) are
-    not part of this path; the thinning OFFSETS are (nsr/mesh_post.get_offset_mask)."""
+    (mesh_utils.py:48-53).  thinning: dict(mask=(res,res) uint8 character mask, type='double' |
+    'front' | 'back') runs nsr/thinning.thinning_processing (mesh_utils.py:38-39) first; the
+    nearest-vertex colour transfer then reads the thinned vertices, as the reference's does."""
     v = verts.detach().cpu().numpy().astype(np.float64) * 0.5
     old = np.zeros_like(v)
     old[:, 0], old[:, 1], old[:, 2] = v[:, 0], v[:, 2], -v[:, 1]
     fz = faces.detach().cpu().numpy().astype(np.int64)
     c = None if colors is None else colors.detach().float().cpu().numpy()
+    if thinning is not None and len(fz):
+        from .thinning import thinning_processing
+        mask = thinning["mask"]
+        mask = mask.detach().cpu().numpy() if torch.is_tensor(mask) else np.asarray(mask)
+        old = thinning_processing(old, fz, mask, thinning.get("type", "double"),
+                                  device=thinning.get("device", verts.device if verts.is_cuda else None))
     out = old
     if smoothing and len(fz):
         out = laplacian_smooth_implicit(old, fz, lamb=2.0, iterations=5)

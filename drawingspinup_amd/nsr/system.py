@@ -1043,7 +1043,7 @@ class OrthoNeuSSystem:
 
     # ----------------------------------------------------------------- export
     @torch.no_grad()
-    def export_mesh(self, front_mask=None, resolution=None, with_colors=True):
+    def export_mesh(self, front_mask=None, resolution=None, with_colors=True, face_count=None):
         """OrthoNeuSSystem.export -> model.export (neus_ortho.py:183-200, neus.py:220-238,
         geometry.py:108-117) on the device: coarse 512^3 pass, iso-surface of the smoothed coarse
         binary volume, fine box = the coarse MESH's bounding box padded by 10 %, fine pass with
@@ -1054,7 +1054,7 @@ class OrthoNeuSSystem:
         if self.table_opt is not None:
             self.table_opt.finalize()          # loops that call training_step() directly never ran it
         self.model.eval()
-        fine, coarse = M.isosurface(self.model, front_mask, resolution)
+        fine, coarse = M.isosurface(self.model, front_mask, resolution, face_count)
         fine["coarse_level"] = coarse["level"]
         fine["vert_colors"] = M.vertex_colors(self.model, fine["verts"].to(self.device)) \
             if with_colors and fine["verts"].shape[0] else None

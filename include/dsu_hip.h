@@ -799,6 +799,27 @@ int dsu_knn8_blend(const double* query_xy, int64_t n_query, const double* known_
                    int32_t g, const int32_t* offsets, const int32_t* items, float* out_rgb,
                    void* stream);
 
+/* remesh() (instant_nsr/utils/mesh_utils.py:10-22, called by models/geometry.py:63-64 with
+ * face_count 50000): quadric edge-collapse decimation of a triangle mesh down to `target_faces`
+ * triangles.  HOST function on HOST arrays (as in the reference, where trimesh hands the mesh to
+ * Open3D's simplify_quadric_decimation): verts (n_verts,3) float64, faces (n_faces,3) int32.
+ * out_verts / out_faces must hold n_verts / n_faces rows; the counts come back through
+ * out_n_verts / out_n_faces.  boundary_weight: weight of the boundary-edge planes (Open3D: 1.0).
+ * flags bit 0: skip the link-condition test (collapses may then create non-manifold edges, as
+ * Open3D's can).  Collapses stop at the first face count <= target_faces (a collapse removes two
+ * triangles, one on a boundary edge); more remain when no admissible collapse is left. */
+int dsu_mesh_decimate_quadric(const double* verts, int64_t n_verts, const int32_t* faces,
+                              int64_t n_faces, int64_t target_faces, double boundary_weight,
+                              int32_t flags, double* out_verts, int64_t* out_n_verts,
+                              int32_t* out_faces, int64_t* out_n_faces);
+
+/* Image-side host steps of thinning_processing (instant_nsr/utils/thinning_utils.py:205-218) on
+ * HOST arrays (H,W) uint8, non-zero = character:
+ *   cv2.distanceTransform(mask, cv2.DIST_L2, 5)            -> out (H,W) float32
+ *   skimage.morphology.skeletonize(mask, method='lee')     -> out (H,W) uint8, 0 / 255 */
+int dsu_distance_transform_l2_5x5(const uint8_t* mask, int32_t H, int32_t W, float* out);
+int dsu_skeletonize_lee_2d(const uint8_t* img, int32_t H, int32_t W, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

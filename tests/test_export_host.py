@@ -1,0 +1,296 @@
+"""Host-side rows of the NSR export tail: quadric decimation (`remesh`), the image
+steps of the thinning (distance transform, skeleton, thin-pixel selection) and the bi-harmonic
+deformation solve.  trimesh / Open3D / OpenCV / scikit-image / libigl are absent here (parity
+unpinned): the tests hold the functions to their published contracts and to known answers."""
+import ctypes as C
+
+import numpy as np
+import pytest
+from scipy import ndimage as ndi
+
+from drawingspinup_amd import _lib
+from drawingspinup_amd.nsr import mesh as M
+from drawingspinup_amd.nsr import thinning as T
+
+
+# ------------------------------------------------------------------------------------------------
+# remesh
+# ------------------------------------------------------------------------------------------------
+def _uv_sphere(nu, nv, r=0.5):
+    vs = [(0, 0, r)]
+    for i in range(1, nv):
+        th = np.pi * i / nv
+        for j in range(nu):
+            ph = 2 * np.pi * j / nu
+            vs.append((r * np.sin(th) * np.cos(ph), r * np.sin(th) * np.sin(ph), r * np.cos(th)))
+    vs.append((0, 0, -r))
+    f = [(0, 1 + j, 1 + (j + 1) % nu) for j in range(nu)]
+    for i in range(nv - 2):
+        a, b = 1 + i * nu, 1 + (i + 1) * nu
+        for j in range(nu):
+            j2 = (j + 1) % nu
+            f += [(a + j, b + j, b + j2), (a + j, b + j2, a + j2)]
+    last, a = len(vs) - 1, 1 + (nv - 2) * nu
+    f += [(last, a + (j + 1) % nu, a + j) for j in range(nu)]
+    return np.array(vs, np.float64), np.array(f, np.int64)
+
+
+def _grid(n, z=None):
+    g = np.linspace(-0.5, 0.5, n)
+    x, y = np.meshgrid(g, g, indexing="ij")
+    zz = np.zeros_like(x) if z is None else z(x, y)
+    v = np.stack([x.ravel(), y.ravel(), zz.ravel()], 1)
+    idx = np.arange(n * n).reshape(n, n)
+    a, b, c, d = idx[:-1, :-1].ravel(), idx[1:, :-1].ravel(), idx[1:, 1:].ravel(), idx[:-1, 1:].ravel()
+    return v, np.concatenate([np.stack([a, b, c], 1), np.stack([a, c, d], 1)])
+
+
+def _edge_counts(f):
+    e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), 1)
+    u, c = np.unique(e, axis=0, return_counts=True)
+    return u, c
+
+
+def _signed_volume(v, f):
+    return float(np.einsum("ij,ij->i", v[f[:, 0]], np.cross(v[f[:, 1]], v[f[:, 2]])).sum() / 6.0)
+
+
+def test_remesh_sphere_contract():
+    v, f = _uv_sphere(160, 120)
+    v2, f2 = M.remesh(v, f, 3000)
+    assert f2.shape == (3000, 3) and f2.dtype == np.int64 and v2.dtype == np.float64
+    assert f2.min() == 0 and f2.max() == v2.shape[0] - 1 and len(np.unique(f2)) == v2.shape[0]
+    u, c = _edge_counts(f2)
+    assert np.all(c == 2)                                         # still a closed 2-manifold ...
+    assert v2.shape[0] - u.shape[0] + f2.shape[0] == 2            # ... of genus 0
+    # consistent orientation kept (every directed edge once), no flipped faces: outward normals
+    d = np.concatenate([f2[:, [0, 1]], f2[:, [1, 2]], f2[:, [2, 0]]])
+    assert len(np.unique(d, axis=0)) == len(d)
+    n = np.cross(v2[f2[:, 1]] - v2[f2[:, 0]], v2[f2[:, 2]] - v2[f2[:, 0]])
+    assert np.all(np.einsum("ij,ij->i", n, v2[f2].mean(1)) > 0)
+    # on the input surface: vertices within 0.2 % of the radius, volume within 0.5 %
+    r = np.linalg.norm(v2, axis=1)
+    assert abs(r - 0.5).max() < 1e-3
+    assert abs(_signed_volume(v2, f2) / _signed_volume(v, f) - 1) < 5e-3
+    # deterministic
+    v3, f3 = M.remesh(v, f, 3000)
+    assert np.array_equal(v2, v3) and np.array_equal(f2, f3)
+
+
+def test_remesh_spends_faces_where_the_surface_bends():
+    """A plane with a narrow Gaussian bump: after decimation the flat part is covered by few large
+    triangles, the bump keeps its shape (quadric error, not uniform resampling)."""
+    bump = lambda x, y: 0.2 * np.exp(-(x * x + y * y) / (2 * 0.05 ** 2))
+    v, f = _grid(121, bump)
+    v2, f2 = M.remesh(v, f, 1500)
+    assert f2.shape[0] in (1499, 1500)        # a boundary collapse removes one face, an interior one two
+    assert np.abs(v2[:, 2] - bump(v2[:, 0], v2[:, 1])).max() < 4e-3       # vertices stay on the surface
+    rad = np.linalg.norm(v2[f2].mean(1)[:, :2], axis=1)
+    assert (rad < 0.15).sum() > (rad >= 0.15).sum()          # 9 % of the area holds most faces
+    # the square outline survives (boundary planes): extent and area of the xy projection
+    assert np.allclose(v2[:, :2].min(0), -0.5, atol=1e-6) and np.allclose(v2[:, :2].max(0), 0.5, atol=1e-6)
+    a = v2[f2]
+    p, q = a[:, 1, :2] - a[:, 0, :2], a[:, 2, :2] - a[:, 0, :2]
+    area_xy = 0.5 * np.abs(p[:, 0] * q[:, 1] - p[:, 1] * q[:, 0]).sum()
+    assert abs(area_xy - 1.0) < 1e-3
+    u, c = _edge_counts(f2)
+    assert set(np.unique(c)) <= {1, 2}
+
+
+def test_remesh_edge_cases():
+    v, f = _uv_sphere(24, 16)
+    same_v, same_f = M.remesh(v, f, len(f) + 10)               # target above the input: untouched
+    assert np.array_equal(same_f, f) and np.allclose(same_v, v)
+    # a tetrahedron cannot lose a face without losing the manifold: the link condition refuses
+    tv = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], np.float64)
+    tf = np.array([[0, 2, 1], [0, 1, 3], [0, 3, 2], [1, 2, 3]])
+    _, f4 = M.remesh(tv, tf, 2)
+    assert f4.shape[0] == 4
+    _, f2 = M.remesh(tv, tf, 2, keep_manifold=False)           # Open3D's behaviour: collapses anyway
+    assert f2.shape[0] <= 2
+    # degenerate input triangles are dropped, not propagated
+    fd = np.concatenate([f, [[0, 0, 1], [5, 5, 5]]])
+    _, f3 = M.remesh(v, fd, len(f))
+    assert f3.shape[0] == len(f)
+    # empty mesh
+    ev, ef = M.remesh(np.zeros((0, 3)), np.zeros((0, 3), np.int64), 10)
+    assert ev.shape == (0, 3) and ef.shape == (0, 3)
+
+
+def test_remesh_argument_validation():
+    lib = _lib.lib()
+    v, f = _uv_sphere(8, 6)
+    f32 = f.astype(np.int32)
+    ov, of = np.empty_like(v), np.empty_like(f32)
+    nv, nf = C.c_int64(), C.c_int64()
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    call = lambda *a: lib.dsu_mesh_decimate_quadric(*a)
+    assert call(p(v), len(v), p(f32), len(f32), 10, 1.0, 0, p(ov), C.byref(nv), p(of), C.byref(nf)) == 0
+    assert call(None, len(v), p(f32), len(f32), 10, 1.0, 0, p(ov), C.byref(nv), p(of), C.byref(nf)) == -1
+    assert call(p(v), len(v), p(f32), len(f32), -1, 1.0, 0, p(ov), C.byref(nv), p(of), C.byref(nf)) == -1
+    assert call(p(v), len(v), p(f32), len(f32), 10, -1.0, 0, p(ov), C.byref(nv), p(of), C.byref(nf)) == -1
+    bad = f32.copy(); bad[3, 1] = len(v)                         # index out of range
+    assert call(p(v), len(v), p(bad), len(bad), 10, 1.0, 0, p(ov), C.byref(nv), p(of), C.byref(nf)) == -1
+
+
+# ------------------------------------------------------------------------------------------------
+# thinning: image steps
+# ------------------------------------------------------------------------------------------------
+def _character_mask(res=256):
+    yy, xx = np.mgrid[0:res, 0:res]
+    body = (xx - 90) ** 2 + (yy - 128) ** 2 <= 60 ** 2
+    arm = (np.abs(yy - 128) <= 4) & (xx >= 90) & (xx <= 230)
+    leg = (np.abs(xx - 100) <= 3) & (yy >= 128) & (yy <= 245)
+    return ((body | arm | leg) * 255).astype(np.uint8)
+
+
+def test_distance_transform_known_values_and_error_bound():
+    m = np.ones((9, 9), np.uint8)
+    m[4, 4] = 0
+    d = T.distance_transform(m)
+    # OpenCV's documented 5x5 DIST_L2 weights: 1, 1.4, 2.1969 and their sums
+    assert d.dtype == np.float32 and d[4, 4] == 0
+    np.testing.assert_allclose(d[4, 5:], [1, 2, 3, 4], atol=1e-4)
+    np.testing.assert_allclose([d[5, 5], d[5, 6], d[6, 6], d[6, 7], d[7, 7]],
+                               [1.4, 2.1969, 2.8, 3.5969, 4.2], atol=1e-4)
+    assert np.array_equal(d, d.T) and np.array_equal(d, d[::-1]) and np.array_equal(d, d[:, ::-1])
+    mask = _character_mask()
+    d = T.distance_transform(mask)
+    ex = ndi.distance_transform_edt(mask > 0)
+    assert np.all(d[mask == 0] == 0) and np.all(d[mask > 0] >= 1)
+    assert np.abs(d - ex).max() <= 0.021 * ex.max() + 1e-3      # the chamfer's known error (~2 %)
+    # an all-object image has nothing to measure against: OpenCV leaves its "infinity" there
+    assert T.distance_transform(np.ones((4, 5), np.uint8)).min() > 1000
+    assert T.distance_transform(np.zeros((0, 0), np.uint8)).shape == (0, 0)
+
+
+def test_skeleton_contract():
+    mask = _character_mask()
+    sk = T.skeletonize(mask)
+    assert sk.dtype == np.uint8 and set(np.unique(sk)) == {0, 255}
+    obj = sk > 0
+    assert not np.any(obj & (mask == 0))                           # inside the shape
+    eight = np.ones((3, 3))
+    assert ndi.label(obj, structure=eight)[1] == ndi.label(mask > 0, structure=eight)[1] == 1
+    # same number of holes (background components) as the shape
+    assert ndi.label(~obj)[1] == ndi.label(mask == 0)[1]
+    # one pixel thin: no 2x2 block, and no pixel can be removed without changing the topology
+    assert not np.any(obj[:-1, :-1] & obj[1:, :-1] & obj[:-1, 1:] & obj[1:, 1:])
+    assert np.array_equal(T.skeletonize(sk), sk)                   # idempotent
+    # medial: the arm's and the leg's skeletons run along their centre lines to the far ends
+    assert np.all(obj[128, 150:225]) and obj[128 - 1:128 + 2, 150:225].sum() == 75
+    assert np.all(obj[200:240, 100]) and obj[200:240, 99:102].sum() == 40
+    ends = T.get_end_points(sk)
+    assert len(ends) == 2 and {e[0] > 200 or e[1] > 200 for e in ends} == {True}
+    # a ring keeps its hole; isolated pixels and 2-pixel segments survive
+    yy, xx = np.mgrid[0:64, 0:64]
+    ring = ((xx - 32) ** 2 + (yy - 32) ** 2 <= 24 ** 2) & ((xx - 32) ** 2 + (yy - 32) ** 2 >= 14 ** 2)
+    rs = T.skeletonize(ring.astype(np.uint8)) > 0
+    assert ndi.label(~rs)[1] == 2 and ndi.label(rs, structure=eight)[1] == 1 and T.get_end_points(rs) == []
+    dots = np.zeros((8, 8), np.uint8); dots[1, 1] = 1; dots[5, 4] = dots[5, 5] = 1
+    assert np.array_equal(T.skeletonize(dots) > 0, dots > 0)
+
+
+def test_thin_pixel_selection():
+    """remove_intersection / get_thin_coords / get_coord_dist on the synthetic character: the thin
+    mask is the arm's and leg's centre lines (distance <= theta_2), cut back by a disc of radius r
+    where they run into the body, dilated by the 3x3 cross and mapped to mesh xy."""
+    res = 256
+    mask = _character_mask(res)
+    dist, sk = T.distance_transform(mask), T.skeletonize(mask)
+    mov = sk * (dist <= 6)
+    # the thin parts' centre lines, nothing of the body
+    assert mov[128, 160:220].all() and mov[200:235, 100].all() and not mov[100:127, 40:140].any()
+    ep_thin, ep_sk = T.get_end_points(mov), set(T.get_end_points(sk))
+    inner = [p for p in ep_thin if p not in ep_sk]
+    assert len(inner) >= 2                                          # where arm and leg leave the body
+    cut = T.remove_intersection(mov.copy(), sk, 11)
+    for (cx, cy) in inner:
+        assert not cut[max(cy - 7, 0):cy + 8, max(cx - 7, 0):cx + 8].any()
+    assert cut[128, 200] and cut[220, 100] and cut.sum() < mov.sum()
+    grey = T.remove_intersection(mov.copy(), sk, 11, 100)           # the reference's debug rendering
+    assert set(np.unique(grey)) == {0, 100, 255}
+    tc = T.get_thin_coords(cut, res)
+    n_dil = int((ndi.binary_dilation(cut > 0, structure=ndi.generate_binary_structure(2, 1))).sum())
+    assert tc.shape == (n_dil, 2)
+    # pixel (row 128, col 200) -> x = 200/255 - 0.5, y = -(128/255 - 0.5)
+    want = np.array([200 / 255 - 0.5, -(128 / 255 - 0.5)])
+    assert np.abs(tc - want).sum(1).min() < 1e-6
+    cd = T.get_coord_dist(tc, dist, res)
+    assert cd.shape == (n_dil,) and cd.min() >= 2.0 and cd.max() <= 6.0 + 1e-6
+    # bilinear read at pixel centres returns the map itself; halfway the mean
+    px = np.array([[200 / 255 - 0.5, -(128 / 255 - 0.5)]])
+    assert abs(T.get_coord_dist(px, dist, res)[0] - dist[128, 200]) < 1e-4
+    half = np.array([[200.5, 128.0]])
+    assert abs(T.bilinear_interpolation(dist, half)[0] - 0.5 * (dist[128, 200] + dist[128, 201])) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------
+# harmonic
+# ------------------------------------------------------------------------------------------------
+def test_cotangent_laplacian_and_voronoi_mass():
+    v, f = _grid(9)
+    rng = np.random.default_rng(0)
+    inner = (np.abs(v[:, 0]) < 0.49) & (np.abs(v[:, 1]) < 0.49)
+    v[inner, :2] += rng.uniform(-0.02, 0.02, (int(inner.sum()), 2))   # irregular, still planar
+    L = T.cotmatrix(v, f)
+    assert abs(L - L.T).max() < 1e-12 and np.abs(L.sum(1)).max() < 1e-12
+    lin = 0.3 * v[:, 0] - 1.7 * v[:, 1] + 0.2
+    assert np.abs((L @ lin)[inner]).max() < 1e-12                 # linear precision in the interior
+    assert (L.diagonal() < 0).all()
+    m = T.massmatrix_voronoi(v, f)
+    assert abs(m.sum() - 1.0) < 1e-12 and (m > 0).all()           # partitions the surface area
+    # one right triangle: the cell of the right-angle corner is half the area, the others a quarter
+    tv = np.array([[0, 0, 0], [2, 0, 0], [0, 1, 0]], np.float64)
+    np.testing.assert_allclose(T.massmatrix_voronoi(tv, np.array([[0, 1, 2]])), [0.5, 0.25, 0.25], atol=1e-12)
+    # obtuse at corner 0
+    ov = np.array([[0, 0, 0], [2, 0, 0], [-1, 0.5, 0]], np.float64)
+    a = 0.5 * 2 * 0.5
+    np.testing.assert_allclose(T.massmatrix_voronoi(ov, np.array([[0, 1, 2]])), [a / 2, a / 4, a / 4], atol=1e-12)
+    # equilateral: thirds, cotangent weight 1 / (2 sqrt 3) per angle
+    ev = np.array([[0, 0, 0], [1, 0, 0], [0.5, np.sqrt(3) / 2, 0]])
+    np.testing.assert_allclose(T.massmatrix_voronoi(ev, np.array([[0, 1, 2]])), np.full(3, np.sqrt(3) / 12), atol=1e-12)
+    assert abs(T.cotmatrix(ev, np.array([[0, 1, 2]]))[0, 1] - 0.5 / np.sqrt(3)) < 1e-12
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_harmonic_solves_its_variational_problem(k):
+    v, f = _uv_sphere(24, 16)
+    rng = np.random.default_rng(1)
+    b = np.sort(rng.choice(len(v), 40, replace=False))
+    bc = rng.normal(size=(40, 3))
+    W = T.harmonic(v, f, b, bc, k)
+    assert W.shape == (len(v), 3) and np.array_equal(W[b], bc)
+    # stationarity: the energy's gradient vanishes at every free vertex
+    L = T.cotmatrix(v, f)
+    if k == 1:
+        Q = -L
+    else:
+        import scipy.sparse as sp
+        Q = L @ sp.diags(1.0 / T.massmatrix_voronoi(v, f)) @ L
+    free = np.setdiff1d(np.arange(len(v)), b)
+    g = (Q @ W)[free]
+    assert np.abs(g).max() < 1e-8 * np.abs(Q @ W).max()
+    # and it is the minimum: any perturbation of the free values raises the energy
+    e0 = np.trace(W.T @ (Q @ W))
+    for _ in range(3):
+        P = W.copy()
+        P[free] += rng.normal(scale=1e-3, size=(len(free), 3))
+        assert np.trace(P.T @ (Q @ P)) > e0
+    # constants are reproduced exactly (Q annihilates them)
+    Wc = T.harmonic(v, f, b, np.full((40, 1), 2.5), k)
+    assert np.abs(Wc - 2.5).max() < 1e-8
+
+
+def test_biharmonic_field_is_smoother_than_harmonic_at_the_handles():
+    """k = 2 (what the reference asks igl for) has no cusp at a constrained vertex: on a fine flat
+    grid with a single lifted vertex and a fixed rim the neighbours follow the handle."""
+    v, f = _grid(41)
+    rim = np.flatnonzero((np.abs(v[:, 0]) > 0.499) | (np.abs(v[:, 1]) > 0.499))
+    c = np.argmin(np.abs(v[:, 0]) + np.abs(v[:, 1]))
+    b = np.concatenate([rim, [c]])
+    bc = np.concatenate([np.zeros(len(rim)), [1.0]])[:, None]
+    w1, w2 = T.harmonic(v, f, b, bc, 1)[:, 0], T.harmonic(v, f, b, bc, 2)[:, 0]
+    nb = np.argmin(np.abs(v[:, 0] - v[c, 0] - 0.025) + np.abs(v[:, 1] - v[c, 1]))
+    assert w2[nb] > 0.9 > 0.7 > w1[nb] > 0.2
+    assert w1.min() > -1e-12 and w1.max() <= 1 + 1e-12             # maximum principle for k = 1

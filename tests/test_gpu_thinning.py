@@ -1,0 +1,122 @@
+"""thinning_processing end to end (nsr/thinning.py: host image steps + device z-ray offsets +
+bi-harmonic solve) and the fine stage's remesh inside the export, on a synthetic character whose
+answer is known: a slab of constant z-thickness 0.05 with a thick round body and two thin limbs.
+(OpenCV / scikit-image / libigl / trimesh are absent: unpinned — contract tests.)"""
+import numpy as np
+import pytest
+import torch
+
+from drawingspinup_amd.nsr import mesh as M
+from drawingspinup_amd.nsr import thinning as T
+
+pytestmark = pytest.mark.gpu
+RES, N, HALF = 256, 160, 0.025
+
+
+def _mask():
+    yy, xx = np.mgrid[0:RES, 0:RES]
+    body = (xx - 90) ** 2 + (yy - 128) ** 2 <= 60 ** 2
+    arm = (np.abs(yy - 128) <= 4) & (xx >= 90) & (xx <= 230)
+    leg = (np.abs(xx - 100) <= 3) & (yy >= 128) & (yy <= 245)
+    return ((body | arm | leg) * 255).astype(np.uint8)
+
+
+def _slab_mesh(dev):
+    """marching cubes of {mask(x, y) and |z| < HALF} on an N^3 lattice over [-0.5, 0.5]^3, in
+    save_mesh's front-facing convention (x right, y up, z front)."""
+    mask = torch.from_numpy(_mask()).to(dev) > 0
+    g = torch.linspace(-0.5, 0.5, N, device=dev)
+    col = ((g + 0.5) * (RES - 1)).round().long()                  # x -> column
+    row = ((0.5 - g) * (RES - 1)).round().long()                  # y -> row (y up)
+    inside_xy = mask[row[None, :], col[:, None]]                   # [x index, y index]
+    inside = inside_xy[:, :, None] & (g.abs() < HALF)[None, None, :]
+    value = M.smooth_constrained(inside)
+    verts, faces = M.marching_cubes(value, 0.0)
+    return (verts / (N - 1.0) - 0.5).cpu().numpy().astype(np.float64), faces.cpu().numpy()
+
+
+@pytest.fixture(scope="module")
+def slab(dev):
+    v, f = _slab_mesh(dev)
+    assert 20000 < len(f) < 400000
+    return v, f
+
+
+@pytest.mark.parametrize("ty", ["double", "front", "back"])
+def test_thin_limbs_are_squeezed_and_the_body_stays(dev, slab, ty):
+    v, f = slab
+    out, parts = T.thinning_processing(v, f, _mask(), ty, device=dev, return_parts=True)
+    assert out.shape == v.shape and np.isfinite(out).all()
+    d = out - v
+    # fixed vertices (distance map >= theta_1 at their pixel) do not move at all
+    fix = parts["fix_mask"]
+    assert fix.sum() > 1000 and np.abs(d[fix]).max() == 0.0
+    # only z moves where offsets are prescribed; x / y are carried by the field but stay small
+    assert parts["offset_mask"].sum() > 200
+    ov = parts["offset_values"][parts["offset_mask"]]
+    assert np.abs(ov[:, :2]).max() == 0.0 and np.abs(ov[:, 2]).max() < 0.03
+    # the limbs: vertices over the arm's / leg's far halves
+    arm = (v[:, 0] > 0.2) & (v[:, 0] < 0.38) & (np.abs(v[:, 1]) < 0.03)
+    leg = (np.abs(v[:, 0] - (100 / 255 - 0.5)) < 0.02) & (v[:, 1] < -0.3) & (v[:, 1] > -0.44)
+    for limb, half_width in ((arm, 4.5), (leg, 3.5)):
+        front, back = limb & (v[:, 2] > 0.015), limb & (v[:, 2] < -0.015)
+        assert front.sum() > 50 and back.sum() > 50
+        thick0 = v[front, 2].mean() - v[back, 2].mean()
+        thick1 = out[front, 2].mean() - out[back, 2].mean()
+        target = 2 * half_width / RES                       # twice the distance-map value
+        assert 0.040 < thick0 < 0.056                       # (the limb's side walls pull the means in)
+        # squeezed towards the target thickness (the field is smooth: not all the way everywhere)
+        assert thick1 < thick0 - 0.5 * (thick0 - target), (thick0, thick1, target)
+        assert thick1 > target - 0.008
+        if ty == "front":
+            assert abs(d[back, 2]).mean() < 0.25 * abs(d[front, 2]).mean() and d[front, 2].mean() < 0
+        if ty == "back":
+            assert abs(d[front, 2]).mean() < 0.25 * abs(d[back, 2]).mean() and d[back, 2].mean() > 0
+        if ty == "double":
+            assert d[front, 2].mean() < 0 < d[back, 2].mean()
+            assert abs(d[front, 2].mean() + d[back, 2].mean()) < 0.3 * abs(d[front, 2].mean())
+    # the body's middle keeps its thickness
+    body = (np.hypot(v[:, 0] - (90 / 255 - 0.5), v[:, 1]) < 0.12)
+    assert np.abs(d[body]).max() < 1e-3
+    assert np.abs(d).max() < 0.035
+
+
+def test_save_obj_with_thinning_and_remesh(dev, slab, tmp_path):
+    """the switches as save_mesh / MarchingCubeHelper apply them: remesh on the [0, 1] mesh of the
+    fine stage, thinning before smoothing inside save_obj."""
+    v, f = slab
+    v2, f2 = M.remesh(v, f, 20000)
+    assert len(f2) <= 20000 and len(f2) >= 19998
+    # the decimated slab is still the slab: z extent and silhouette area
+    assert abs(v2[:, 2].max() - v[:, 2].max()) < 2e-3 and abs(v2[:, 2].min() - v[:, 2].min()) < 2e-3
+    # save_obj consumes world-convention vertices (x right, y back, z up; halved inside): invert
+    world = np.stack([v2[:, 0], -v2[:, 2], v2[:, 1]], 1) * 2.0
+    p = M.save_obj(str(tmp_path / "t.obj"), torch.from_numpy(world).to(dev), torch.from_numpy(f2).to(dev),
+                   None, ortho_scale=1.0, thinning={"mask": _mask(), "type": "double"})
+    rows = [l.split() for l in open(p) if l.startswith("v ")]
+    got = np.array([[float(x) for x in r[1:4]] for r in rows])
+    assert got.shape == v2.shape
+    want = T.thinning_processing(v2, f2, _mask(), "double", device=dev)
+    np.testing.assert_allclose(got, want, atol=2e-8)
+    arm = (v2[:, 0] > 0.2) & (v2[:, 0] < 0.38) & (np.abs(v2[:, 1]) < 0.03)
+    assert np.abs(got[arm, 2]).mean() < np.abs(v2[arm, 2]).mean() - 0.002
+
+
+def test_export_with_face_count(dev):
+    """export_mesh(face_count=...) = MarchingCubeHelper's fine stage with remeshing on
+    (geometry.py:63-64): the fine mesh is decimated before the colour pass reads its vertices."""
+    from drawingspinup_amd.nsr.system import OrthoNeuSSystem
+    sysm = OrthoNeuSSystem(device=dev, seed=0)                    # sphere-initialised SDF, radius 0.5
+    sysm.model.update_step(0, 0)                                  # level / finite-difference schedule of step 0
+    full = sysm.export_mesh(None, 96, with_colors=False)
+    assert full["faces"].shape[0] > 6000
+    mesh = sysm.export_mesh(None, 96, with_colors=True, face_count=3000)
+    assert mesh["faces"].shape[0] in (2999, 3000)
+    assert mesh["vert_colors"].shape == (mesh["verts"].shape[0], 3)
+    r = mesh["verts"].float().norm(dim=1)
+    r0 = full["verts"].float().norm(dim=1)
+    assert abs(float(r.mean()) - float(r0.mean())) < 5e-3 and float(r.std()) < float(r0.std()) + 5e-3
+    f = mesh["faces"].cpu().numpy()
+    e = np.sort(np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]]), 1)
+    _, c = np.unique(e, axis=0, return_counts=True)
+    assert np.all(c == 2)

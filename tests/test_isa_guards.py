@@ -53,7 +53,9 @@ def test_dominant_nsr_kernels_have_no_scratch():
     # the production variant <NL=10, MLP part only (split), feature cache>: the gather path and its
     # level metadata are compiled out (SGPR spills 130 -> 36 when that was introduced for the fused
     # form, which is kept as an option and allowed a few more for the per-workgroup range scalars)
+    # (round 3: the two point halves as straight-line code with hand-placed load waits doubled the
+    # scalars kept in vector lanes, 43 -> 87; measured faster all the same, profiles/round3_ab_k1_load_waits.txt)
     md, _ = ks["sdf_fd_bwd_mfma_kernel<10,1,1>"]
-    assert md["sspill"] <= 48, md
+    assert md["sspill"] <= 96, md
     md, _ = ks["sdf_fd_bwd_mfma_kernel<10,0,1>"]
-    assert md["sspill"] <= 72, md
+    assert md["sspill"] <= 96, md
