@@ -112,8 +112,18 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
   const bool kfast = (a.C % BK) == 0;             // every UNet/VAE layer but conv_in (C = 8)
   int st_tap = 0, st_c = 0, st_chunk = -2;
 
-  f16x8 ra[4], rb[4];
-  auto load_regs = [&](int chunk) {
+#ifdef DSU_CONV_PREFETCH1
+  f16x8 ra0[4], rb0[4];
+  uint32_t ok0 = 0;
+#else
+  f16x8 ra0[4], rb0[4], ra1[4], rb1[4];
+  uint32_t ok0 = 0, ok1 = 0;
+#endif
+  // Every load is issued unconditionally (rows / taps outside the problem read element 0 and are
+  // zeroed when the chunk is written to LDS): with a branch per load the compiler cannot count how
+  // many loads follow a given one and waits for ALL of them (vmcnt(0)) in front of the first LDS
+  // write — including the chunk that was requested a moment ago.
+  auto load_regs = [&](int chunk, f16x8 (&ra)[4], f16x8 (&rb)[4], uint32_t& okmask) {
     if (kfast && chunk == st_chunk + 1) {
       st_c += BK;
       if (st_c >= a.C) { st_c -= a.C; ++st_tap; }
@@ -129,27 +139,28 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
     else if (a.KS == 1) { ty = 0; tx = 0; }
     else { ty = st_tap / a.KS; tx = st_tap - ty * a.KS; }
     const uint32_t kadv = (uint32_t)(chunk * BK);
+    uint32_t okm = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const bool oka = kin && a_ok[i];
+      ra[i] = *reinterpret_cast<const f16x8*>(a.w + (oka ? w_off[i] + kadv : 0u));
+      int iy = iy0[i] + ty, ix = ix0[i] + tx;
+      const bool okb = kin && b_ok[i] && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
+      if (a.up2) { iy >>= 1; ix >>= 1; }
+      const uint32_t off = pix_base[i] + (uint32_t)((iy * a.W + ix) * a.C + st_c);
+      rb[i] = *reinterpret_cast<const f16x8*>(a.in + (okb ? off : 0u));
+      okm |= (oka ? 1u : 0u) << i | (okb ? 1u : 0u) << (4 + i);
+    }
+    okmask = okm;
+  };
+  auto store_lds = [&](int buf, const f16x8 (&ra)[4], const f16x8 (&rb)[4], uint32_t okmask) {
     f16x8 z;
 #pragma unroll
     for (int e = 0; e < 8; ++e) z[e] = (f16)0.0f;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = z;
-      rb[i] = z;
-      if (kin && a_ok[i]) ra[i] = *reinterpret_cast<const f16x8*>(a.w + (w_off[i] + kadv));
-      int iy = iy0[i] + ty, ix = ix0[i] + tx;
-      if (kin && b_ok[i] && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW) {
-        if (a.up2) { iy >>= 1; ix >>= 1; }
-        rb[i] = *reinterpret_cast<const f16x8*>(
-            a.in + (pix_base[i] + (uint32_t)((iy * a.W + ix) * a.C + st_c)));
-      }
-    }
-  };
-  auto store_lds = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<f16x8*>(&sA[buf][a_row[i] * ROW + kofs]) = ra[i];
-      *reinterpret_cast<f16x8*>(&sB[buf][b_row[i] * ROW + kofs]) = rb[i];
+      *reinterpret_cast<f16x8*>(&sA[buf][a_row[i] * ROW + kofs]) = (okmask >> i) & 1u ? ra[i] : z;
+      *reinterpret_cast<f16x8*>(&sB[buf][b_row[i] * ROW + kofs]) = (okmask >> (4 + i)) & 1u ? rb[i] : z;
     }
   };
 
@@ -167,12 +178,7 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
   const int per = (total_chunks + a.split_k - 1) / a.split_k;
   const int ch0 = blockIdx.z * per;
   const int nchunks = min(total_chunks, ch0 + per);
-  load_regs(ch0);
-  store_lds(ch0 & 1);
-  __syncthreads();
-  for (int ch = ch0; ch < nchunks; ++ch) {
-    const int buf = ch & 1;
-    if (ch + 1 < nchunks) load_regs(ch + 1);       // global loads in flight during the MFMAs
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       f16x8 af[2], bf[2];
@@ -190,9 +196,48 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
         for (int j = 0; j < 2; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
-    if (ch + 1 < nchunks) store_lds(buf ^ 1);
+  };
+#ifdef DSU_CONV_PREFETCH1
+  // (A/B variant: the round-2 pipeline — one chunk ahead)
+  load_regs(ch0, ra0, rb0, ok0);
+  store_lds(ch0 & 1, ra0, rb0, ok0);
+  __syncthreads();
+  for (int ch = ch0; ch < nchunks; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nchunks) load_regs(ch + 1, ra0, rb0, ok0);
+    compute(buf);
+    if (ch + 1 < nchunks) store_lds(buf ^ 1, ra0, rb0, ok0);
     __syncthreads();
   }
+#else
+  // Two chunks ahead: the global loads of chunk k + 2 are issued before chunk k's MFMAs and written
+  // to LDS behind chunk k + 1's.  One chunk is 16 MFMAs per wave (~0.5 k clocks); one chunk ahead,
+  // every iteration ended on the tail of an L2 / HBM round trip (~1-2 k clocks).  Chunk k (counted
+  // from this workgroup's first) lives in LDS buffer k & 1 and register set k & 1, hence the loop
+  // over pairs with the sets named at compile time (an exit between the two halves made the
+  // compiler keep two copies of the accumulators; a set chosen by a branch, copies of the sets).
+  const int nk = nchunks - ch0;
+  if (nk > 0) {
+    load_regs(ch0, ra0, rb0, ok0);
+    store_lds(0, ra0, rb0, ok0);
+    if (nk > 1) load_regs(ch0 + 1, ra1, rb1, ok1);
+  }
+  __syncthreads();
+  int k = 0;
+  for (; k + 1 < nk; k += 2) {                       // whole pairs: chunk k in buffer / set 0
+    // (requested even past this workgroup's last chunk — never written to LDS then: a branch around
+    // the loads would again hide from the compiler how many are in flight)
+    load_regs(ch0 + k + 2, ra0, rb0, ok0);
+    compute(0);
+    store_lds(1, ra1, rb1, ok1);
+    __syncthreads();
+    load_regs(ch0 + k + 3, ra1, rb1, ok1);
+    compute(1);
+    if (k + 2 < nk) store_lds(0, ra0, rb0, ok0);
+    __syncthreads();
+  }
+  if (k < nk) compute(0);                            // odd count: the last chunk is already in buffer 0
+#endif
 
   // epilogue: lane -> pixel (wn*64 + j*32 + l31); register quad r4 -> channels
   //   o = o0 + wm*64 + i*32 + 8*r4 + 4*hh + {0..3}
