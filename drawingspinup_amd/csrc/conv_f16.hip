@@ -29,6 +29,8 @@
 //           rows directly.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 typedef _Float16 f16;
@@ -36,8 +38,8 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int TM = 128;   // output channels per workgroup
-constexpr int TN = 128;   // pixels per workgroup
+constexpr int TM_BIG = 128;   // output channels per workgroup (2 x 2 form)
+constexpr int TN_BIG = 128;   // pixels per workgroup
 constexpr int BK = 64;    // K chunk (halfs)
 constexpr int ROW = BK + 8;  // LDS row stride in halfs: 144 B = 16 * 9 -> conflict-free b128
 
@@ -57,14 +59,21 @@ struct CArgs {
                         // tile sums the partials and runs the epilogue itself (no reduce launch)
 };
 
-template <int MODE>
+// WI x WJ: 32x32 MFMA tiles per wave along output channels x pixels.  2 x 2 (the 128 x 128
+// workgroup tile) for layers that fill the chip; 1 x 1 (64 x 64 tile, 37 KB of LDS: four workgroups
+// = four waves per SIMD on a CU) for the many layers of the UNet whose 128 x 128 tiling leaves
+// most CUs with one wave per SIMD or none (M = 768 ... 3072 rows).
+template <int MODE, int WI, int WJ>
 __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
   constexpr bool GEGLU = MODE == 1;
+  static_assert(!GEGLU || (WI == 2 && WJ == 2), "the GEGLU row pairing is written for 2 x 2");
+  constexpr int TM = 64 * WI, TN = 64 * WJ;       // workgroup tile
+  constexpr int RA = 2 * WI, RB = 2 * WJ;         // 16-byte staging rows per thread per chunk
   __shared__ __attribute__((aligned(16))) f16 sA[2][TM * ROW];
   __shared__ __attribute__((aligned(16))) f16 sB[2][TN * ROW];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, hh = lane >> 5;
-  const int wm = wave >> 1, wn = wave & 1;      // 2x2 waves, 64x64 each
+  const int wm = wave >> 1, wn = wave & 1;      // 2x2 waves, (32 WI) x (32 WJ) each
   // GEGLU: a tile covers 64 output channels (value rows + gate rows of the 2*O-row weight)
   const int o0 = blockIdx.y * (GEGLU ? TM / 2 : TM);
   const int64_t npix = (int64_t)a.B * a.OH * a.OW;
@@ -79,17 +88,16 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
   // recomputed two integer divisions, bounds and 64-bit addresses per row per chunk:
   // ~400 VALU instructions per 16 MFMAs (PMC: SQ_INSTS_VALU / SQ_INSTS_MFMA = 25, 55 % of wave
   // cycles in VALU issue) — the kernel was VALU-bound, not MFMA-, LDS- or latency-bound.
-  int a_row[4], b_row[4];
+  int a_row[RA], b_row[RB];
   const int grp = tid & 7;
   const int kofs = grp * 8;
-  uint32_t w_off[4], pix_base[4];
-  int iy0[4], ix0[4];
-  bool a_ok[4], b_ok[4];
+  uint32_t w_off[RA], pix_base[RB];
+  int iy0[RB], ix0[RB];
+  bool a_ok[RA], b_ok[RB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < RA; ++i) {
     const int idx = tid + 256 * i;
     a_row[i] = idx >> 3;
-    b_row[i] = idx >> 3;
     int o = o0 + a_row[i];
     int wrow = o;
     if (GEGLU) {
@@ -100,6 +108,11 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
     }
     a_ok[i] = o < a.O;
     w_off[i] = (uint32_t)(a_ok[i] ? wrow : 0) * (uint32_t)a.Ktot + (uint32_t)kofs;
+  }
+#pragma unroll
+  for (int i = 0; i < RB; ++i) {
+    const int idx = tid + 256 * i;
+    b_row[i] = idx >> 3;
     const int64_t p = p0 + b_row[i];
     b_ok[i] = p < npix;
     const int64_t pp = b_ok[i] ? p : 0;
@@ -113,17 +126,17 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
   int st_tap = 0, st_c = 0, st_chunk = -2;
 
 #ifdef DSU_CONV_PREFETCH1
-  f16x8 ra0[4], rb0[4];
+  f16x8 ra0[RA], rb0[RB];
   uint32_t ok0 = 0;
 #else
-  f16x8 ra0[4], rb0[4], ra1[4], rb1[4];
+  f16x8 ra0[RA], rb0[RB], ra1[RA], rb1[RB];
   uint32_t ok0 = 0, ok1 = 0;
 #endif
   // Every load is issued unconditionally (rows / taps outside the problem read element 0 and are
   // zeroed when the chunk is written to LDS): with a branch per load the compiler cannot count how
   // many loads follow a given one and waits for ALL of them (vmcnt(0)) in front of the first LDS
   // write — including the chunk that was requested a moment ago.
-  auto load_regs = [&](int chunk, f16x8 (&ra)[4], f16x8 (&rb)[4], uint32_t& okmask) {
+  auto load_regs = [&](int chunk, f16x8 (&ra)[RA], f16x8 (&rb)[RB], uint32_t& okmask) {
     if (kfast && chunk == st_chunk + 1) {
       st_c += BK;
       if (st_c >= a.C) { st_c -= a.C; ++st_tap; }
@@ -141,34 +154,39 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
     const uint32_t kadv = (uint32_t)(chunk * BK);
     uint32_t okm = 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RA; ++i) {
       const bool oka = kin && a_ok[i];
       ra[i] = *reinterpret_cast<const f16x8*>(a.w + (oka ? w_off[i] + kadv : 0u));
+      okm |= (oka ? 1u : 0u) << i;
+    }
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
       int iy = iy0[i] + ty, ix = ix0[i] + tx;
       const bool okb = kin && b_ok[i] && (unsigned)iy < (unsigned)IH && (unsigned)ix < (unsigned)IW;
       if (a.up2) { iy >>= 1; ix >>= 1; }
       const uint32_t off = pix_base[i] + (uint32_t)((iy * a.W + ix) * a.C + st_c);
       rb[i] = *reinterpret_cast<const f16x8*>(a.in + (okb ? off : 0u));
-      okm |= (oka ? 1u : 0u) << i | (okb ? 1u : 0u) << (4 + i);
+      okm |= (okb ? 1u : 0u) << (4 + i);
     }
     okmask = okm;
   };
-  auto store_lds = [&](int buf, const f16x8 (&ra)[4], const f16x8 (&rb)[4], uint32_t okmask) {
+  auto store_lds = [&](int buf, const f16x8 (&ra)[RA], const f16x8 (&rb)[RB], uint32_t okmask) {
     f16x8 z;
 #pragma unroll
     for (int e = 0; e < 8; ++e) z[e] = (f16)0.0f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RA; ++i)
       *reinterpret_cast<f16x8*>(&sA[buf][a_row[i] * ROW + kofs]) = (okmask >> i) & 1u ? ra[i] : z;
+#pragma unroll
+    for (int i = 0; i < RB; ++i)
       *reinterpret_cast<f16x8*>(&sB[buf][b_row[i] * ROW + kofs]) = (okmask >> (4 + i)) & 1u ? rb[i] : z;
-    }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[WI][WJ];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < WI; ++i)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+    for (int j = 0; j < WJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
 
@@ -181,19 +199,19 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
   auto compute = [&](int buf) {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
-      f16x8 af[2], bf[2];
+      f16x8 af[WI], bf[WJ];
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WI; ++i)
         af[i] = *reinterpret_cast<const f16x8*>(
-            &sA[buf][(wm * 64 + i * 32 + l31) * ROW + ks * 16 + hh * 8]);
+            &sA[buf][(wm * 32 * WI + i * 32 + l31) * ROW + ks * 16 + hh * 8]);
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
+      for (int j = 0; j < WJ; ++j)
         bf[j] = *reinterpret_cast<const f16x8*>(
-            &sB[buf][(wn * 64 + j * 32 + l31) * ROW + ks * 16 + hh * 8]);
+            &sB[buf][(wn * 32 * WJ + j * 32 + l31) * ROW + ks * 16 + hh * 8]);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WI; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WJ; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
     }
   };
@@ -239,19 +257,19 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
   if (k < nk) compute(0);                            // odd count: the last chunk is already in buffer 0
 #endif
 
-  // epilogue: lane -> pixel (wn*64 + j*32 + l31); register quad r4 -> channels
-  //   o = o0 + wm*64 + i*32 + 8*r4 + 4*hh + {0..3}
+  // epilogue: lane -> pixel (wn*32*WJ + j*32 + l31); register quad r4 -> channels
+  //   o = o0 + wm*32*WI + i*32 + 8*r4 + 4*hh + {0..3}
   if (a.split_k > 1) {
     float* ws = a.ws + (size_t)blockIdx.z * npix * a.O;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t p = p0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < WJ; ++j) {
+      const int64_t p = p0 + wn * 32 * WJ + j * 32 + l31;
       if (p >= npix) continue;
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WI; ++i)
 #pragma unroll
         for (int r4 = 0; r4 < 4; ++r4) {
-          const int o = o0 + wm * 64 + i * 32 + 8 * r4 + 4 * hh;
+          const int o = o0 + wm * 32 * WI + i * 32 + 8 * r4 + 4 * hh;
           if (o + 3 < a.O) {
             *reinterpret_cast<float4*>(ws + (size_t)p * a.O + o) =
                 make_float4(acc[i][j][4 * r4], acc[i][j][4 * r4 + 1], acc[i][j][4 * r4 + 2],
@@ -303,10 +321,10 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
     }
     return;
   }
-  if (GEGLU) {
+  if constexpr (GEGLU) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-      const int64_t p = p0 + wn * 64 + j * 32 + l31;
+      const int64_t p = p0 + wn * 32 * WJ + j * 32 + l31;
       if (p >= npix) continue;
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
@@ -329,16 +347,16 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
   if (a.out_t) {
     const int hw = a.OH * a.OW;
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int64_t p = p0 + wn * 64 + j * 32 + l31;
+    for (int j = 0; j < WJ; ++j) {
+      const int64_t p = p0 + wn * 32 * WJ + j * 32 + l31;
       if (p >= npix) continue;
       const int n = (int)(p / hw);
       const int t = (int)(p - (int64_t)n * hw);
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int i = 0; i < WI; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          const int o = o0 + wm * 64 + i * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
+          const int o = o0 + wm * 32 * WI + i * 32 + 8 * (r >> 2) + 4 * hh + (r & 3);
           if (o >= a.O) continue;
           float v = acc[i][j][r];
           if (a.bias) v += (float)a.bias[o];
@@ -348,15 +366,15 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
     return;
   }
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int64_t p = p0 + wn * 64 + j * 32 + l31;
+  for (int j = 0; j < WJ; ++j) {
+    const int64_t p = p0 + wn * 32 * WJ + j * 32 + l31;
     if (p >= npix) continue;
     const int n = (int)(p / (a.OH * a.OW));
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < WI; ++i) {
 #pragma unroll
       for (int r4 = 0; r4 < 4; ++r4) {
-        const int o = o0 + wm * 64 + i * 32 + 8 * r4 + 4 * hh;
+        const int o = o0 + wm * 32 * WI + i * 32 + 8 * r4 + 4 * hh;
         if (o >= a.O) continue;
         float v[4];
 #pragma unroll
@@ -427,6 +445,24 @@ __global__ __launch_bounds__(256) void conv_f16_reduce_kernel(CArgs a, int64_t n
 
 int conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k) / stride + 1; }
 
+// 64 x 64 workgroup tiles when the 128 x 128 tiling would leave the chip under-filled
+// (DSU_CONV_SMALL_MAX_TILES: A/B switch, 0 = always 128 x 128)
+bool small_tiles(int64_t npix, int64_t O) {
+  static const int64_t max_big = [] {
+    const char* e = getenv("DSU_CONV_SMALL_MAX_TILES");
+    return e ? (int64_t)atoll(e) : (int64_t)512;
+  }();
+  const int64_t big = ((npix + TN_BIG - 1) / TN_BIG) * ((O + TM_BIG - 1) / TM_BIG);
+  return big < max_big;
+}
+
+template <int WI, int WJ>
+void launch_conv(const CArgs& a, int64_t npix, hipStream_t s) {
+  constexpr int TM = 64 * WI, TN = 64 * WJ;
+  dim3 grid((unsigned)((npix + TN - 1) / TN), (unsigned)((a.O + TM - 1) / TM), (unsigned)a.split_k);
+  conv_f16_kernel<0, WI, WJ><<<grid, 256, 0, s>>>(a);
+}
+
 }  // namespace
 
 extern "C" {
@@ -439,10 +475,12 @@ int32_t dsu_conv2d_nhwc_f16_split_k(int32_t B, int32_t H, int32_t W, int32_t C, 
   const int OH = conv_out_dim(IH, k, stride, pad), OW = conv_out_dim(IW, k, stride, pad);
   if (OH <= 0 || OW <= 0) return 1;
   const int64_t npix = (int64_t)B * OH * OW;
-  const int64_t tiles = ((npix + TN - 1) / TN) * ((O + TM - 1) / TM);
+  const int tile = small_tiles(npix, O) ? 64 : 128;
+  const int64_t tiles = ((npix + tile - 1) / tile) * ((O + tile - 1) / tile);
   const int chunks = (k * k * C + BK - 1) / BK;
-  if (tiles >= 256 || chunks < 8) return 1;          // the output tiles already fill the chip
-  int64_t s = (512 + tiles - 1) / tiles;             // aim at >= 2 workgroups per CU
+  const int64_t fill = tile == 64 ? 512 : 256;       // 64-tiles: four workgroups fit a CU
+  if (tiles >= fill || chunks < 8) return 1;         // the output tiles already fill the chip
+  int64_t s = (2 * fill + tiles - 1) / tiles;        // aim at twice that
   if (s > chunks / 4) s = chunks / 4;                // keep >= 4 chunks (256 k) per workgroup
   if (s > 16) s = 16;
   return s < 2 ? 1 : (int32_t)s;
@@ -506,10 +544,12 @@ int dsu_conv2d_nhwc_f16_fwd_fx(const void* input, const void* weight_okc, const 
   if (a.split_k > 1 &&
       (!workspace || workspace_bytes < (int64_t)a.split_k * npix * O * (int64_t)sizeof(float)))
     return DSU_EINVAL;
-  dim3 grid((unsigned)((npix + TN - 1) / TN), (unsigned)((O + TM - 1) / TM), (unsigned)a.split_k);
-  a.counters = (a.split_k > 1 && tile_counters && (int64_t)grid.x * grid.y <= n_counters)
-                   ? tile_counters : nullptr;
-  conv_f16_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  const bool small = small_tiles(npix, O);
+  const int tile = small ? 64 : 128;
+  const int64_t n_tiles = ((npix + tile - 1) / tile) * ((O + tile - 1) / tile);
+  a.counters = (a.split_k > 1 && tile_counters && n_tiles <= n_counters) ? tile_counters : nullptr;
+  if (small) launch_conv<1, 1>(a, npix, (hipStream_t)stream);
+  else launch_conv<2, 2>(a, npix, (hipStream_t)stream);
   if (a.split_k > 1 && !a.counters) {
     const int64_t total = npix * ((O + 3) / 4);
     conv_f16_reduce_kernel<<<dsu_capped_blocks(total, 256, 2048), 256, 0, (hipStream_t)stream>>>(
@@ -575,10 +615,12 @@ int dsu_gemm_f16_fwd_fx(const void* x, const void* w, const void* bias, int64_t 
   a.ws = (float*)workspace;
   if (split_k > 1 && (!workspace || workspace_bytes < (int64_t)split_k * M * N * (int64_t)sizeof(float)))
     return DSU_EINVAL;
-  dim3 grid((unsigned)((M + TN - 1) / TN), (unsigned)((N + TM - 1) / TM), (unsigned)split_k);
-  a.counters = (split_k > 1 && tile_counters && (int64_t)grid.x * grid.y <= n_counters)
-                   ? tile_counters : nullptr;
-  conv_f16_kernel<0><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  const bool small = small_tiles(M, N);
+  const int tile = small ? 64 : 128;
+  const int64_t n_tiles = ((M + tile - 1) / tile) * ((N + tile - 1) / tile);
+  a.counters = (split_k > 1 && tile_counters && n_tiles <= n_counters) ? tile_counters : nullptr;
+  if (small) launch_conv<1, 1>(a, M, (hipStream_t)stream);
+  else launch_conv<2, 2>(a, M, (hipStream_t)stream);
   if (split_k > 1 && !a.counters) {
     const int64_t total = M * ((N + 3) / 4);
     conv_f16_reduce_kernel<<<dsu_capped_blocks(total, 256, 2048), 256, 0, (hipStream_t)stream>>>(a, M);
@@ -595,8 +637,8 @@ int dsu_gemm_geglu_fwd(const void* x, const void* w, const void* bias, int64_t M
   int rc = gemm_args(a, x, w, bias, M, K, N, nullptr, out);
   if (rc) return rc;
   if (N % 4 != 0 || (int64_t)2 * N * K >= (int64_t)1 << 31) return DSU_EUNSUP;
-  dim3 grid((unsigned)((M + TN - 1) / TN), (unsigned)((N + TM / 2 - 1) / (TM / 2)), 1);
-  conv_f16_kernel<1><<<grid, 256, 0, (hipStream_t)stream>>>(a);
+  dim3 grid((unsigned)((M + TN_BIG - 1) / TN_BIG), (unsigned)((N + TM_BIG / 2 - 1) / (TM_BIG / 2)), 1);
+  conv_f16_kernel<1, 2, 2><<<grid, 256, 0, (hipStream_t)stream>>>(a);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }
