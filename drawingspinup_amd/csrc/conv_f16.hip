@@ -480,7 +480,14 @@ int32_t dsu_conv2d_nhwc_f16_split_k(int32_t B, int32_t H, int32_t W, int32_t C, 
   const int chunks = (k * k * C + BK - 1) / BK;
   const int64_t fill = tile == 64 ? 512 : 256;       // 64-tiles: four workgroups fit a CU
   if (tiles >= fill || chunks < 8) return 1;         // the output tiles already fill the chip
-  int64_t s = (2 * fill + tiles - 1) / tiles;        // aim at twice that
+  static const int64_t target_pct = [] {             // DSU_CONV_SPLIT_TARGET: A/B switch (percent of fill)
+    const char* e = getenv("DSU_CONV_SPLIT_TARGET");
+    return e ? (int64_t)atoll(e) : (int64_t)50;
+  }();
+  if (target_pct <= 0) return 1;
+  // (measured on the UNet forward: 12.2 ms without split-K, 11.1 / 10.8 / 10.6 ms aiming at 2 x / 1 x /
+  // 0.5 x fill — the f32 partials of a split cost a write and a read of the whole output each)
+  int64_t s = (fill * target_pct / 100 + tiles - 1) / tiles;
   if (s > chunks / 4) s = chunks / 4;                // keep >= 4 chunks (256 k) per workgroup
   if (s > 16) s = 16;
   return s < 2 ? 1 : (int32_t)s;
