@@ -132,36 +132,64 @@ __global__ __launch_bounds__(256) void mv_attention_kernel(AttnArgs a) {
     v_goff[j] = (int64_t)d * a.vt_ds + k4 * 4;
   }
 
+  // The K / V^T rows of tile t + 1 are requested (into registers) before tile t's MFMAs and written
+  // to LDS behind them: one LDS buffer, the loads a whole tile of work ahead.  Every load is issued
+  // unconditionally (rows outside the segment or the head dimension read the tile's first element
+  // and are zeroed on the way to LDS) so that the compiler can count the loads in flight.
   const int tiles_per_seg = (a.seg_len + KVBLK - 1) / KVBLK;
-  for (int s = 0; s < a.S; ++s) {
-    const int kb = a.seg_batch[b * a.S + s];
+  const int n_tiles = a.S * tiles_per_seg;
+  f16x8 kreg[NK];
+  f16x4 vreg[NV];
+  uint32_t okk = 0, okv = 0;                         // validity bits of the staged groups
+  auto request = [&](int tile) {
+    const int s = tile / tiles_per_seg, t = tile - s * tiles_per_seg;
+    const int kb = a.seg_batch[b * a.S + (s < a.S ? s : a.S - 1)];
     const f16* kbase = a.k + kb * a.k_bs + h * a.k_hs;
     const f16* vbase = a.vt + kb * a.vt_bs + h * a.vt_hs;
-    for (int t = 0; t < tiles_per_seg; ++t) {
-      const int key0 = t * KVBLK;
+    const int key0 = t * KVBLK;
+    uint32_t ok = 0, ov = 0;
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      const bool on = tile < n_tiles && k_on[j] && key0 + k_key[j] < a.seg_len;
+      kreg[j] = *reinterpret_cast<const f16x8*>(kbase + (on ? (int64_t)key0 * a.k_ts + k_goff[j] : 0));
+      ok |= (on ? 1u : 0u) << j;
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      const bool on = tile < n_tiles && v_on[j] && key0 + v_k4[j] < a.seg_len;   // seg_len % 4 == 0
+      vreg[j] = *reinterpret_cast<const f16x4*>(vbase + (on ? key0 + v_goff[j] : 0));
+      ov |= (on ? 1u : 0u) << j;
+    }
+    okk = ok;
+    okv = ov;
+  };
+  auto publish = [&]() {
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+      if (k_lds[j] < 0) continue;
+      f16x8 z;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) z[e] = (f16)0.0f;
+      *reinterpret_cast<f16x8*>(&sK[k_lds[j]]) = (okk >> j) & 1u ? kreg[j] : z;
+    }
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+      if (v_lds[j] < 0) continue;
+      f16x4 z;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[e] = (f16)0.0f;
+      *reinterpret_cast<f16x4*>(&sV[v_lds[j]]) = (okv >> j) & 1u ? vreg[j] : z;
+    }
+  };
+  static_assert(NK <= 32 && NV <= 32, "one validity bit per staged group");
+  request(0);
+  {
+    for (int tile = 0; tile < n_tiles; ++tile) {
+      const int key0 = (tile % tiles_per_seg) * KVBLK;
       __syncthreads();   // previous tile fully consumed
-      // ---- stage K tile [64 keys][DP] (zero padded) and V^T tile [D rows][64 keys]
-#pragma unroll
-      for (int j = 0; j < NK; ++j) {
-        if (k_lds[j] < 0) continue;
-        f16x8 v;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (f16)0.0f;
-        if (k_on[j] && key0 + k_key[j] < a.seg_len)
-          v = *reinterpret_cast<const f16x8*>(kbase + (int64_t)key0 * a.k_ts + k_goff[j]);
-        *reinterpret_cast<f16x8*>(&sK[k_lds[j]]) = v;
-      }
-#pragma unroll
-      for (int j = 0; j < NV; ++j) {
-        if (v_lds[j] < 0) continue;
-        f16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (f16)0.0f;
-        if (v_on[j] && key0 + v_k4[j] < a.seg_len)   // seg_len % 4 == 0: 4-key groups are whole
-          v = *reinterpret_cast<const f16x4*>(vbase + key0 + v_goff[j]);
-        *reinterpret_cast<f16x4*>(&sV[v_lds[j]]) = v;
-      }
+      publish();
       __syncthreads();
+      request(tile + 1);
 
       // ---- S^T = K.Q^T for the two 32-key tiles: st[kt][r] = score(key = 32kt + row(r), qi)
       f32x16 st[2];
