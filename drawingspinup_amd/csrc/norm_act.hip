@@ -6,6 +6,8 @@
 // with 16-byte accesses and keeps statistics in f32.
 #include "common.h"
 
+#include <stdlib.h>
+
 namespace {
 
 typedef _Float16 f16;
@@ -184,6 +186,100 @@ __global__ __launch_bounds__(256) void gn_fused_small_kernel(const f16* __restri
   }
 }
 
+// ---- the same with 16-byte accesses: one 1024-thread workgroup per (image, SUPER-group), a
+// super-group being the smallest run of whole groups that is also a whole number of 8-channel
+// chunks (10 channels per group -> 4 groups = 40 channels = 5 chunks).  The kernel above reads a
+// group's 10..80 channels of a pixel as half2 pairs, 20..160 bytes out of every 640..5120-byte
+// pixel row: 13 cache lines per wave instruction, each line fetched again by the 3-6 other
+// workgroups whose groups share it (28.7 us for the 7.9 MB of a (12, 32x32, 320) tensor = 0.55 TB/s).
+// Here a thread keeps its <= GS_KEEP chunks in registers between the statistics and the apply pass.
+constexpr int GS_KEEP = 16;
+constexpr int GS_THREADS = 1024;
+__global__ __launch_bounds__(GS_THREADS) void gn_super_kernel(const f16* __restrict__ x,
+                                                              const f16* __restrict__ gamma,
+                                                              const f16* __restrict__ beta, int HW,
+                                                              int C, int cpg, int SG, float eps,
+                                                              int do_silu, f16* __restrict__ out) {
+  __shared__ float red[GS_THREADS / 64][8];
+  __shared__ float stat[8];                       // mean[4] | rstd[4]
+  const int nsg = C / SG, CH = SG >> 3;
+  const int n = blockIdx.x / nsg, c_base = (blockIdx.x % nsg) * SG;
+  const int total = HW * CH;
+  const f16* xb = x + (size_t)n * HW * C + c_base;
+  f16* ob = out + (size_t)n * HW * C + c_base;
+  f16x8 kv[GS_KEEP];
+  int off[GS_KEEP];                                // element offset of the chunk, -1 = none
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, q[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int k = 0; k < GS_KEEP; ++k) {
+    const int e = threadIdx.x + GS_THREADS * k;
+    off[k] = -1;
+    if (e < total) {
+      const int p = e / CH, c = e - p * CH;
+      off[k] = p * C + 8 * c;
+      const f16x8 v = *reinterpret_cast<const f16x8*>(xb + off[k]);
+      kv[k] = v;
+      // cpg >= 8: a chunk touches at most two groups, g0 for its first `split` channels
+      const int g0 = (8 * c) / cpg, split = (g0 + 1) * cpg - 8 * c;
+      float s0 = 0.f, q0 = 0.f, s1 = 0.f, q1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float f = (float)v[j];
+        if (j < split) { s0 += f; q0 += f * f; } else { s1 += f; q1 += f * f; }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        s[g] += g == g0 ? s0 : (g == g0 + 1 ? s1 : 0.0f);
+        q[g] += g == g0 ? q0 : (g == g0 + 1 ? q1 : 0.0f);
+      }
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; ++g)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s[g] += __shfl_xor(s[g], o);
+      q[g] += __shfl_xor(q[g], o);
+    }
+  if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      red[threadIdx.x >> 6][g] = s[g];
+      red[threadIdx.x >> 6][4 + g] = q[g];
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    float ss = 0.f, qq = 0.f;
+    for (int w = 0; w < GS_THREADS / 64; ++w) { ss += red[w][threadIdx.x]; qq += red[w][4 + threadIdx.x]; }
+    const float inv_cnt = 1.0f / ((float)HW * (float)cpg);
+    const float mean = ss * inv_cnt;
+    const float var = fmaxf(qq * inv_cnt - mean * mean, 0.0f);
+    stat[threadIdx.x] = mean;
+    stat[4 + threadIdx.x] = rsqrtf(var + eps);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int k = 0; k < GS_KEEP; ++k) {
+    if (off[k] < 0) continue;
+    const int c8 = off[k] % C;                     // 8 * chunk index inside the super-group
+    const int g0 = c8 / cpg, split = (g0 + 1) * cpg - c8;
+    const float m0 = stat[g0], r0 = stat[4 + g0];
+    const float m1 = stat[g0 + 1 < 4 ? g0 + 1 : 3], r1 = stat[4 + (g0 + 1 < 4 ? g0 + 1 : 3)];
+    const f16x8 gm = *reinterpret_cast<const f16x8*>(gamma + c_base + c8);
+    const f16x8 bt = *reinterpret_cast<const f16x8*>(beta + c_base + c8);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float mean = j < split ? m0 : m1, rstd = j < split ? r0 : r1;
+      float y = ((float)kv[k][j] - mean) * rstd * (float)gm[j] + (float)bt[j];
+      if (do_silu) y = silu(y);
+      o[j] = (f16)y;
+    }
+    *reinterpret_cast<f16x8*>(ob + off[k]) = o;
+  }
+}
+
 // ---- LayerNorm over the last dimension: one wave per row, C % 8 == 0, C <= 64*8*4
 __global__ __launch_bounds__(256) void layernorm_kernel(const f16* __restrict__ x,
                                                         const f16* __restrict__ gamma,
@@ -271,6 +367,24 @@ int dsu_groupnorm_nhwc_f16(const void* x, const void* gamma, const void* beta, i
   if (B <= 0 || HW <= 0 || C <= 0 || G <= 0 || C % G != 0) return DSU_EINVAL;
   if (C % 8 != 0 || C / 8 > 1024 || (C / 8) % ((C / 8 + 255) / 256) != 0) return DSU_EUNSUP;
   hipStream_t s = (hipStream_t)stream;
+  {
+    // super-group form: groups of >= 8 channels whose super-group has <= 4 groups and fits the
+    // registers of one 1024-thread workgroup (DSU_GN_SUPER=0: A/B switch)
+    static const bool use_super = [] { const char* e = getenv("DSU_GN_SUPER"); return !e || atoi(e) != 0; }();
+    const int cpg = C / G;
+    int SG = cpg;
+    while (SG % 8 != 0) SG += cpg;
+    // (measured per UNet shape, tools/gn_time.py: 19-47 us instead of 26-58 at 32x32, 15.6 instead of
+    // 20.1 at 16x16x1280, a tie at 16x16x640, 2-3 us SLOWER on the 8x8 / 4x4 levels — few, fat workgroups)
+    if (use_super && HW >= 256 && cpg >= 8 && SG / cpg <= 4 && C % SG == 0 &&
+        (int64_t)HW * (SG / 8) <= (int64_t)GS_KEEP * GS_THREADS && (int64_t)HW * C < ((int64_t)1 << 31)) {
+      gn_super_kernel<<<B * (C / SG), GS_THREADS, 0, s>>>((const f16*)x, (const f16*)gamma,
+                                                          (const f16*)beta, HW, C, cpg, SG, eps, silu,
+                                                          (f16*)out);
+      DSU_CHECK_LAUNCH();
+      return DSU_OK;
+    }
+  }
   if ((int64_t)HW * (C / G) <= 32768 && (int64_t)B * G >= 64 && (C / G) % 2 == 0) {
     gn_fused_small_kernel<<<B * G, 256, 0, s>>>((const f16*)x, (const f16*)gamma,
                                                 (const f16*)beta, HW, C, G, eps, silu, (f16*)out);

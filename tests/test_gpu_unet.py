@@ -29,9 +29,14 @@ def _init(model, seed):
 
 def test_norm_kernels(dev):
     g = torch.Generator().manual_seed(0)
-    # (3,5,7): one-launch small-tensor kernel; (1,5,7) and (1,64,64): statistics + apply kernels
-    for C, shp in [(320, (3, 5, 7)), (640, (3, 5, 7)), (1920, (3, 5, 7)), (2560, (3, 5, 7)),
-                   (640, (1, 5, 7)), (320, (1, 64, 64)), (960, (12, 32, 32))]:
+    # every channels-per-group of the UNet (10 ... 80) and the VAE's 16: the 16-byte super-group
+    # kernel where a super-group fits one workgroup's registers, else the one-launch half2 kernel
+    # ((3,5,7)) or the statistics + apply pair ((1,5,7), (1,64,64) at 320: 20480 chunks);
+    # DSU_GN_SUPER=0 sends everything down the older paths (tools/visit_r3_36.sh runs both)
+    for C, shp in [(320, (3, 5, 7)), (640, (3, 5, 7)), (1280, (3, 5, 7)), (1920, (3, 5, 7)),
+                   (2560, (3, 5, 7)), (640, (1, 5, 7)), (320, (1, 64, 64)), (960, (12, 32, 32)),
+                   (320, (2, 32, 32)), (640, (2, 16, 16)), (1280, (2, 8, 8)), (512, (1, 64, 64)),
+                   (256, (1, 70, 50))]:
         x = torch.randn(*shp, C, generator=g).half()
         w, b = (1 + 0.1 * torch.randn(C, generator=g)).half(), (0.1 * torch.randn(C, generator=g)).half()
         for silu in (False, True):
