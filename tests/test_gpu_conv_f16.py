@@ -90,10 +90,14 @@ def test_conv_f16_split_k_heuristic():
     """Host-only: the library splits K only where the output tiles leave the chip idle."""
     from drawingspinup_amd._lib import lib
     f = lib().dsu_conv2d_nhwc_f16_split_k
-    assert f(12, 32, 32, 320, 320, 3, 1, 1, 0) == 1          # 96 x 3 tiles: plain kernel
-    assert f(12, 4, 4, 1280, 1280, 3, 1, 1, 0) >= 8          # 2 x 10 tiles, 180 chunks
-    assert f(12, 8, 8, 1280, 1280, 3, 1, 1, 0) >= 4
+    # (64 x 64 tiles for these shapes; the split aims at half of the 512 workgroups that fill the chip)
+    assert f(12, 32, 32, 320, 320, 3, 1, 1, 0) == 1          # 192 x 5 tiles: plain kernel
+    s44 = f(12, 4, 4, 1280, 1280, 3, 1, 1, 0)                # 3 x 20 tiles, 180 chunks
+    assert 4 <= s44 <= 16 and 60 * s44 >= 256
+    s88 = f(12, 8, 8, 1280, 1280, 3, 1, 1, 0)                # 12 x 20 tiles
+    assert 2 <= s88 <= 4 and 240 * s88 >= 256
     assert f(12, 4, 4, 64, 1280, 1, 1, 0, 0) == 1            # 1 chunk: nothing to split
+    assert f(12, 64, 64, 320, 320, 3, 1, 1, 0) == 1          # 128 x 128 tiles (1152 of them), no split
 
 
 # ---------------------------------------------------------------------------------------------
