@@ -11,6 +11,7 @@ from scipy import ndimage as ndi
 from drawingspinup_amd import _lib
 from drawingspinup_amd.nsr import mesh as M
 from drawingspinup_amd.nsr import thinning as T
+from oracle import thinning_ref as R
 
 
 # ------------------------------------------------------------------------------------------------
@@ -294,3 +295,65 @@ def test_biharmonic_field_is_smoother_than_harmonic_at_the_handles():
     nb = np.argmin(np.abs(v[:, 0] - v[c, 0] - 0.025) + np.abs(v[:, 1] - v[c, 1]))
     assert w2[nb] > 0.9 > 0.7 > w1[nb] > 0.2
     assert w1.min() > -1e-12 and w1.max() <= 1 + 1e-12             # maximum principle for k = 1
+
+
+# ------------------------------------------------------------------------------------------------
+# the product against the independent restatements of oracle/thinning_ref.py
+# ------------------------------------------------------------------------------------------------
+def test_two_dimensional_deletion_rule_equals_lees_criteria_in_three_dimensions():
+    """csrc/thinning_host.hip decides with a 2-D rule (one 8-connected component among the 8
+    neighbours, a background pixel among the 4 edge neighbours).  Lee's criteria are 3-D: Euler
+    characteristic of the 26-connected object unchanged, one 26-connected component left in the
+    3x3x3 neighbourhood.  On a one-slice volume the two agree for every one of the 256
+    neighbourhoods (computed literally: cubical-complex Euler characteristic, flood fill)."""
+    # the Euler characteristic helper itself: solid block 1, ring 0, two blocks 2, hollow shell 2
+    blk = np.ones((3, 3, 3), bool)
+    assert R._euler_characteristic(blk) == 1
+    ring = np.ones((1, 3, 3), bool); ring[0, 1, 1] = False
+    assert R._euler_characteristic(ring) == 0
+    two = np.zeros((1, 1, 3), bool); two[0, 0, 0] = two[0, 0, 2] = True
+    assert R._euler_characteristic(two) == 2
+    shell = blk.copy(); shell[1, 1, 1] = False
+    assert R._euler_characteristic(shell) == 2
+    diag = np.zeros((1, 2, 2), bool); diag[0, 0, 0] = diag[0, 1, 1] = True      # 26-connected: one piece
+    assert R._euler_characteristic(diag) == 1 and R._components_26(diag) == 1
+    n_deletable = 0
+    for m in range(256):
+        nb = [(m >> k) & 1 for k in range(8)]
+        inv, one = R.lee_criteria_3d(nb)
+        assert (inv and one) == R.reduced_criteria_2d(nb), (m, inv, one)
+        n_deletable += inv and one
+    assert 100 < n_deletable < 140           # (simple points of the (8, 4) digital topology, minus nothing)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_skeleton_matches_the_literal_three_dimensional_thinning(seed):
+    rng = np.random.default_rng(seed)
+    img = ndi.binary_dilation(rng.random((22, 26)) > 0.82, iterations=2)
+    img = ndi.binary_opening(img) | (rng.random((22, 26)) > 0.97)
+    img = (img * 255).astype(np.uint8)
+    assert 60 < (img > 0).sum() < 572
+    assert np.array_equal(T.skeletonize(img), R.skeleton_lee_2d(img))
+
+
+def test_distance_transform_matches_the_float_chamfer():
+    rng = np.random.default_rng(3)
+    for shape in ((40, 40), (17, 53), (5, 3)):
+        mask = (ndi.binary_dilation(rng.random(shape) > 0.9, iterations=1) == 0).astype(np.uint8) * 255
+        if (mask == 0).sum() == 0:
+            mask[0, 0] = 0
+        got, want = T.distance_transform(mask), R.chamfer_5x5(mask)
+        assert np.abs(got - want).max() < 2e-3            # 16.16 fixed point of the weights vs float
+
+
+@pytest.mark.parametrize("k", [1, 2])
+def test_harmonic_matches_the_dense_angle_based_solve(k):
+    v, f = _uv_sphere(12, 8)
+    rng = np.random.default_rng(5)
+    v = v + rng.normal(scale=0.01, size=v.shape)                   # irregular, some obtuse triangles
+    b = np.sort(rng.choice(len(v), 12, replace=False))
+    bc = rng.normal(size=(12, 2))
+    got, want = T.harmonic(v, f, b, bc, k), R.harmonic_dense(v, f, b, bc, k)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-8 * np.abs(want).max())
+    m = T.massmatrix_voronoi(v, f)
+    assert abs(m.sum() - 0.5 * np.linalg.norm(np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]), axis=1).sum()) < 1e-12
