@@ -357,3 +357,37 @@ def test_harmonic_matches_the_dense_angle_based_solve(k):
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-8 * np.abs(want).max())
     m = T.massmatrix_voronoi(v, f)
     assert abs(m.sum() - 0.5 * np.linalg.norm(np.cross(v[f[:, 1]] - v[f[:, 0]], v[f[:, 2]] - v[f[:, 0]]), axis=1).sum()) < 1e-12
+
+
+def _canonical(v, f):
+    """mesh as a set of triangles of rounded vertex positions (cyclic order kept, rotation removed)."""
+    out = set()
+    for t in f:
+        p = [tuple(np.round(v[i], 9)) for i in t]
+        k = p.index(min(p))
+        out.add((p[k], p[(k + 1) % 3], p[(k + 2) % 3]))
+    return out
+
+
+@pytest.mark.parametrize("closed", [True, False])
+def test_remesh_takes_the_collapses_of_the_naive_restatement(closed):
+    """Vertices in general position (all edge costs distinct): the library's queue with lazy
+    deletion, vertex versions and lazily cleaned adjacency lists must take exactly the collapses
+    of oracle/decimate_ref.py, which recomputes every edge cost from scratch at every step."""
+    from oracle import decimate_ref as D
+    rng = np.random.default_rng(11)
+    if closed:
+        v, f = _uv_sphere(10, 8)
+        v = v * (1 + 0.15 * rng.normal(size=(len(v), 1))) + 0.01 * rng.normal(size=v.shape)
+        target = 60
+    else:
+        v, f = _grid(7, lambda x, y: 0.3 * np.sin(3 * x) * np.cos(2 * y))
+        v = v + 0.02 * rng.normal(size=v.shape)
+        target = 30
+    for keep in (True, False):
+        gv, gf = M.remesh(v, f, target, keep_manifold=keep)
+        wv, wf, used = D.decimate(v, f, target, 1.0, keep)
+        remap = {u: k for k, u in enumerate(used)}
+        wf = np.array([[remap[i] for i in t] for t in wf])
+        assert len(gf) == len(wf) and len(gv) == len(wv)
+        assert _canonical(gv, gf) == _canonical(wv, wf)
