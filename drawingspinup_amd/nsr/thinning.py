@@ -245,6 +245,15 @@ def thinning_processing(v, f, mask_u8, thinning_type="double", theta_1=11, theta
     mov_mask = skeleton * (distance <= theta_2)
     mov_mask_new = remove_intersection(mov_mask.copy(), skeleton, r)
     thin_coords = get_thin_coords(mov_mask_new, res)
+    if thin_coords.shape[0] == 0 or len(f) == 0:
+        # no thin limb: the reference's loop over the thin pixels marks nothing, the field's
+        # Dirichlet data are all zero and so is the field
+        if return_parts:
+            return v.copy(), {"distance": distance, "skeleton": skeleton, "mov_mask": mov_mask,
+                              "mov_mask_rm_inter": mov_mask_new, "thin_coords": thin_coords,
+                              "fix_mask": fix_mask, "offset_mask": np.zeros(len(v), bool),
+                              "offset_values": np.zeros_like(v), "d": np.zeros_like(v)}
+        return v.copy()
     coord_dists = get_coord_dist(thin_coords[:, 0:2], distance, res) / res
     dev = torch.device(device if device is not None else "cuda")
     off_v, off_m = get_offset_mask(torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev),
@@ -253,7 +262,7 @@ def thinning_processing(v, f, mask_u8, thinning_type="double", theta_1=11, theta
     offset_values, offset_mask = off_v.cpu().numpy(), off_m.cpu().numpy()
     s = fix_mask | offset_mask
     b = np.flatnonzero(s)
-    d = harmonic(v, f, b, offset_values[s], 2)
+    d = harmonic(v, f, b, offset_values[s], 2) if offset_mask.any() else np.zeros_like(v)
     out = v + d
     if return_parts:
         return out, {"distance": distance, "skeleton": skeleton, "mov_mask": mov_mask,

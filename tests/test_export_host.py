@@ -391,3 +391,18 @@ def test_remesh_takes_the_collapses_of_the_naive_restatement(closed):
         wf = np.array([[remap[i] for i in t] for t in wf])
         assert len(gf) == len(wf) and len(gv) == len(wv)
         assert _canonical(gv, gf) == _canonical(wv, wf)
+
+
+def test_thinning_of_a_character_without_thin_parts_is_the_identity():
+    """no skeleton pixel with a small distance value: nothing is marked, the deformation is zero
+    (decided on the host: no device needed)."""
+    res = 128
+    yy, xx = np.mgrid[0:res, 0:res]
+    mask = (((xx - 64) ** 2 + (yy - 64) ** 2 <= 50 ** 2) * 255).astype(np.uint8)
+    v, f = _uv_sphere(16, 12, 0.35)
+    out, parts = T.thinning_processing(v, f, mask, "double", device="cpu", return_parts=True)
+    assert np.array_equal(out, v) and out is not v
+    assert parts["thin_coords"].shape == (0, 2) and not parts["offset_mask"].any()
+    assert parts["fix_mask"].any()
+    ev, ef = np.zeros((0, 3)), np.zeros((0, 3), np.int64)
+    assert T.thinning_processing(ev, ef, mask).shape == (0, 3)
