@@ -1,0 +1,132 @@
+"""Fixture for the export's thinning: runs the REFERENCE's own
+`thinning_processing` (2_charactor_reconstructor/instant_nsr/utils/thinning_utils.py:199-247, with
+its get_end_points / remove_intersection / get_thin_coords / get_coord_dist /
+bilinear_interpolation / get_offset_mask) on a synthetic character — a slab of constant
+z-thickness with a thick body and two thin limbs.
+
+    python tests/golden/make_thinning_golden.py     # needs /root/reference; ~1 min
+
+The reference's own Python runs unchanged.  Its third-party calls are absent from this image and
+are served by the oracle's restatements: cv2.distanceTransform -> oracle/thinning_ref.chamfer_5x5,
+skimage skeletonize(method='lee') -> thinning_ref.skeleton_lee_2d, igl.harmonic ->
+thinning_ref.harmonic_dense, mesh_raycast -> oracle/mesh_post_ref.raycast, cv2.dilate /
+getStructuringElement -> mesh_post_ref, cv2.circle -> a filled disc.  Parity is therefore pinned
+to the REFERENCE'S GLUE (pixel conventions, thresholds, which vertices are constrained with what,
+how the pieces are chained) and unpinned for those packages' internals.
+The fixture stores the inputs (mesh, mask) and the reference's intermediate and final outputs.
+"""
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+UTILS = "/root/reference/2_charactor_reconstructor/instant_nsr/utils"
+from oracle import mesh_post_ref as R  # noqa: E402
+from oracle import thinning_ref as T   # noqa: E402
+RES, N, HALF = 256, 96, 0.025
+
+
+def stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def character_mask():
+    yy, xx = np.mgrid[0:RES, 0:RES]
+    body = (xx - 90) ** 2 + (yy - 128) ** 2 <= 60 ** 2
+    arm = (np.abs(yy - 128) <= 4) & (xx >= 90) & (xx <= 230)
+    leg = (np.abs(xx - 100) <= 3) & (yy >= 128) & (yy <= 245)
+    return ((body | arm | leg) * 255).astype(np.uint8)
+
+
+def slab_mesh(mask):
+    """{mask(x, y) and |z| < HALF} through the product's marching cubes and decimation (inputs only)."""
+    import torch
+    from drawingspinup_amd.nsr import mesh as M
+    m = torch.from_numpy(mask) > 0
+    g = torch.linspace(-0.5, 0.5, N)
+    col = ((g + 0.5) * (RES - 1)).round().long()
+    row = ((0.5 - g) * (RES - 1)).round().long()
+    inside = m[row[None, :], col[:, None]][:, :, None] & (g.abs() < HALF)[None, None, :]
+    v, f = M.marching_cubes(M.smooth_constrained(inside), 0.0)
+    v, f = M.remesh((v / (N - 1.0) - 0.5).numpy(), f.numpy(), 5000)
+    return v, f
+
+
+def circle(img, center, radius, color, thickness):
+    assert thickness == -1
+    cx, cy = center
+    H, W = img.shape[:2]
+    for dy in range(-radius, radius + 1):
+        y = cy + dy
+        if 0 <= y < H:
+            half = int(np.floor(np.sqrt(radius * radius - dy * dy)))
+            img[y, max(cx - half, 0):min(cx + half, W - 1) + 1] = color
+    return img
+
+
+def main():
+    mask = character_mask()
+    verts, faces = slab_mesh(mask)
+    recorded = {}
+
+    def distance_transform(img, dist_type, mask_size):
+        assert (dist_type, mask_size) == ("L2", 5)
+        recorded["distance"] = T.chamfer_5x5(img).astype(np.float32)
+        return recorded["distance"]
+
+    def skeletonize(img, method):
+        assert method == "lee"
+        recorded["skeleton"] = T.skeleton_lee_2d(img)
+        return recorded["skeleton"]
+
+    def harmonic(v, f, b, bc, k):
+        recorded["b"], recorded["d_bc"] = np.asarray(b).ravel().copy(), np.asarray(bc).copy()
+        recorded["d"] = T.harmonic_dense(v, f, np.asarray(b).ravel(), bc, k)
+        return recorded["d"]
+
+    stub("cv2", MORPH_ELLIPSE=R.MORPH_ELLIPSE, DIST_L2="L2", getStructuringElement=R.getStructuringElement,
+         erode=R.erode, dilate=R.dilate, flip=R.flip, circle=circle, distanceTransform=distance_transform,
+         imread=lambda path, flag: mask.copy(), imwrite=lambda *a: True)
+    stub("mesh_raycast", raycast=R.raycast)
+    stub("igl", harmonic=harmonic)
+    morph = stub("skimage.morphology", skeletonize=skeletonize)
+    stub("skimage", morphology=morph)
+    spec = importlib.util.spec_from_file_location("ref_thinning_utils", os.path.join(UTILS, "thinning_utils.py"))
+    tu = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(tu)
+
+    out = {"mask": mask, "verts": verts, "faces": faces}
+    # the helpers on their own (the reference's functions, stand-ins only for dilate / circle)
+    dist = T.chamfer_5x5(mask).astype(np.float32)
+    sk = T.skeleton_lee_2d(mask)
+    mov = sk * (dist <= 6)
+    out["end_points_skeleton"] = np.array(tu.get_end_points(sk), np.int64).reshape(-1, 2)
+    out["end_points_mov"] = np.array(tu.get_end_points(mov), np.int64).reshape(-1, 2)
+    out["mov_mask"] = mov
+    out["mov_mask_rm_inter"] = tu.remove_intersection(mov.copy(), sk, 11)
+    out["thin_coords"] = tu.get_thin_coords(out["mov_mask_rm_inter"], RES)
+    out["coord_dists_px"] = tu.get_coord_dist(out["thin_coords"][:, 0:2], dist, RES)
+    out["fix_dist_px"] = tu.get_coord_dist(verts[:, 0:2], dist, RES)
+    # the whole function, three thinning types
+    for ty in ("double", "front", "back"):
+        cfg = types.SimpleNamespace(output_dir="/tmp", input_dir="/tmp", thinning_type=ty)
+        res = tu.thinning_processing(verts.copy(), faces, cfg, save_cache=False)
+        out["thinned_" + ty] = res
+        out["b_" + ty], out["d_bc_" + ty] = recorded["b"], recorded["d_bc"]
+    out["distance"], out["skeleton"] = recorded["distance"], recorded["skeleton"]
+    np.savez_compressed(os.path.join(HERE, "thinning_reference.npz"), **out)
+    print("wrote thinning_reference.npz:", verts.shape, faces.shape, out["thin_coords"].shape,
+          {ty: (len(out["b_" + ty]), float(np.abs(out["thinned_" + ty] - verts).max())) for ty in ("double", "front", "back")})
+
+
+if __name__ == "__main__":
+    main()

@@ -13,6 +13,9 @@ from drawingspinup_amd.nsr import mesh as M
 from drawingspinup_amd.nsr import thinning as T
 from oracle import thinning_ref as R
 
+import os
+THIN = np.load(os.path.join(os.path.dirname(__file__), "golden", "thinning_reference.npz"))
+
 
 # ------------------------------------------------------------------------------------------------
 # remesh
@@ -406,3 +409,40 @@ def test_thinning_of_a_character_without_thin_parts_is_the_identity():
     assert parts["fix_mask"].any()
     ev, ef = np.zeros((0, 3)), np.zeros((0, 3), np.int64)
     assert T.thinning_processing(ev, ef, mask).shape == (0, 3)
+
+
+# ------------------------------------------------------------------------------------------------
+# against the REFERENCE's own thinning_utils.py (tests/golden/make_thinning_golden.py)
+# ------------------------------------------------------------------------------------------------
+def test_thinning_glue_matches_the_reference_functions():
+    """get_end_points / remove_intersection / get_thin_coords / get_coord_dist of
+    instant_nsr/utils/thinning_utils.py, run unchanged by the fixture generator, on the same
+    distance map and skeleton."""
+    mask, dist, sk = THIN["mask"], THIN["distance"], THIN["skeleton"]
+    res = mask.shape[0]
+    assert np.array_equal(np.array(T.get_end_points(sk)).reshape(-1, 2), THIN["end_points_skeleton"])
+    mov = sk * (dist <= 6)
+    assert np.array_equal(mov, THIN["mov_mask"])
+    assert np.array_equal(np.array(T.get_end_points(mov)).reshape(-1, 2), THIN["end_points_mov"])
+    cut = T.remove_intersection(mov.copy(), sk, 11)
+    assert np.array_equal(cut, THIN["mov_mask_rm_inter"])
+    tc = T.get_thin_coords(cut, res)
+    assert tc.dtype == THIN["thin_coords"].dtype and np.array_equal(tc, THIN["thin_coords"])
+    np.testing.assert_allclose(T.get_coord_dist(tc[:, 0:2], dist, res), THIN["coord_dists_px"], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(T.get_coord_dist(THIN["verts"][:, 0:2], dist, res), THIN["fix_dist_px"],
+                               rtol=0, atol=1e-12)
+    # the library's image steps on the fixture's mask against what the reference was served
+    assert np.array_equal(T.skeletonize(mask), sk)
+    assert np.abs(T.distance_transform(mask) - dist).max() < 2e-3
+
+
+@pytest.mark.parametrize("ty", ["double", "front", "back"])
+def test_harmonic_reproduces_the_reference_run(ty):
+    """the constrained vertices and their offsets as the reference handed them to igl.harmonic,
+    solved by nsr/thinning.harmonic (sparse) against the field the reference's run used (dense
+    angle-based restatement): the deformed vertices the reference returned."""
+    v, f = THIN["verts"], THIN["faces"]
+    d = T.harmonic(v, f, THIN["b_" + ty], THIN["d_bc_" + ty], 2)
+    want = THIN["thinned_" + ty] - v
+    assert np.abs(want).max() > 5e-3
+    np.testing.assert_allclose(d, want, rtol=0, atol=1e-9)
