@@ -123,6 +123,41 @@ def main():
         out["thinned_" + ty] = res
         out["b_" + ty], out["d_bc_" + ty] = recorded["b"], recorded["d_bc"]
     out["distance"], out["skeleton"] = recorded["distance"], recorded["skeleton"]
+
+    # ---- the reference's save_mesh with thinning + smoothing + nearest-vertex colours + shear
+    # (mesh_utils.py:25-73; trimesh stand-in and its dense Laplacian filter from
+    # make_mesh_post_golden.py; sklearn's NearestNeighbors is the real one)
+    spec2 = importlib.util.spec_from_file_location("mk_post", os.path.join(HERE, "make_mesh_post_golden.py"))
+    mk_post = importlib.util.module_from_spec(spec2)
+    spec2.loader.exec_module(mk_post)
+    exported = {}
+
+    class Trimesh:
+        def __init__(self, vertices=None, faces=None, vertex_colors=None, **kw):
+            self.vertices, self.faces, self.vertex_colors = vertices, faces, vertex_colors
+
+        def export(self, path):
+            exported.update(v=np.array(self.vertices), f=np.array(self.faces), c=np.array(self.vertex_colors))
+    stub("trimesh", Trimesh=Trimesh, smoothing=types.SimpleNamespace(filter_laplacian=mk_post.dense_filter_laplacian))
+    stub("instant_nsr")
+    stub("instant_nsr.utils")
+    stub("instant_nsr.utils.coloring_utils", color_projection=None, uv_mapping=None)
+    stub("instant_nsr.utils.thinning_utils", thinning_processing=tu.thinning_processing)
+    spec3 = importlib.util.spec_from_file_location("ref_mesh_utils", os.path.join(UTILS, "mesh_utils.py"))
+    mu = importlib.util.module_from_spec(spec3)
+    spec3.loader.exec_module(mu)
+    # save_mesh halves its input and swaps axes (x, y, z) -> (x, z, -y): feed it the world-convention
+    # vertices whose front-facing image is the slab mesh
+    world = np.stack([verts[:, 0], -verts[:, 2], verts[:, 1]], 1) * 2.0
+    colors = np.random.default_rng(4).random((len(verts), 3))
+    cfg = types.SimpleNamespace(output_dir="/tmp/_thinning_golden", input_dir="/tmp", thinning=True,
+                                thinning_type="double", smoothing=True, color_back_projection=False,
+                                shearing=True, ortho_scale=1.35, export_uv=False, save_name="m")
+    _tp = tu.thinning_processing
+    mu.thinning_processing = lambda v, f, config: _tp(v, f, config, save_cache=False)
+    mu.save_mesh(cfg, world.copy(), faces.copy(), colors.copy())
+    out["save_world"], out["save_colors"] = world, colors
+    out["save_out_v"], out["save_out_c"] = exported["v"], exported["c"]
     np.savez_compressed(os.path.join(HERE, "thinning_reference.npz"), **out)
     print("wrote thinning_reference.npz:", verts.shape, faces.shape, out["thin_coords"].shape,
           {ty: (len(out["b_" + ty]), float(np.abs(out["thinned_" + ty] - verts).max())) for ty in ("double", "front", "back")})

@@ -141,3 +141,23 @@ def test_thinning_processing_matches_the_reference_run(dev, ty):
     assert np.abs(want - v).max() > 5e-3
     assert np.abs(out - want).max() < 1e-4 and np.abs(out - want).mean() < 1e-6
     assert np.array_equal(parts["thin_coords"], GOLD["thin_coords"])
+
+
+def test_save_obj_with_thinning_matches_the_reference_save_mesh(dev, tmp_path):
+    """The reference's save_mesh (mesh_utils.py:25-73) with thinning + smoothing + nearest-vertex
+    colours + shear + ortho scale, run unchanged by the fixture generator, against save_obj with the
+    same switches: the order of the steps (thinning before smoothing, colours fetched from the
+    THINNED vertices, shear after colouring) and every convention in between."""
+    world, colors, faces = GOLD["save_world"], GOLD["save_colors"], GOLD["faces"]
+    p = M.save_obj(str(tmp_path / "m.obj"), torch.from_numpy(world).to(dev), torch.from_numpy(faces).to(dev),
+                   torch.from_numpy(colors).to(dev), ortho_scale=1.35, smoothing=True, shearing=True,
+                   thinning={"mask": GOLD["mask"], "type": "double"})
+    rows = [l.split() for l in open(p) if l.startswith("v ")]
+    got = np.array([[float(x) for x in r[1:7]] for r in rows])
+    want_v, want_c = GOLD["save_out_v"], GOLD["save_out_c"]
+    assert got.shape == (len(want_v), 6)
+    assert np.abs(got[:, :3] - want_v).max() < 2e-4 and np.abs(got[:, :3] - want_v).mean() < 5e-6
+    same = np.abs(got[:, 3:] - want_c).max(1) < 2e-6
+    assert same.mean() > 0.995                      # a nearest-vertex tie may resolve differently
+    fz = np.array([[int(x) for x in l.split()[1:4]] for l in open(p) if l.startswith("f ")])
+    assert np.array_equal(fz - 1, faces)
