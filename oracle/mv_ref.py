@@ -11,9 +11,12 @@ xformers==0.0.17 are absent and not installable), so this file restates:
   * the diffusers 0.19.3 building blocks the UNet is assembled from (Attention projections,
     FeedForward/GEGLU, ResnetBlock2D, Downsample2D/Upsample2D, Timesteps/TimestepEmbedding),
     from their published definitions.
-PARITY UNPINNED: the reference ships no tests/golden vectors for this path and its
-third-party pieces cannot be executed here; KATs are hand-derived (tests/test_oracle_mv.py,
-run on the CPU).
+PARITY: the GRAPH this file restates is pinned to the reference's own modules —
+tests/golden/mv_reference.npz is produced by running mvdiffusion/models/*.py unmodified (float64,
+CPU) over stand-ins for diffusers / xformers (oracle/stubs/), and tests/test_mv_reference_fixture.py
+holds UNetRef to it at 1e-9, output and per-block intermediates.  The LEAF OPS of diffusers 0.19.3
+/ xformers 0.0.17 stay "parity unpinned" (packages absent, restated from their published
+definitions here AND in the stubs); hand-derived KATs for them: tests/test_oracle_mv.py.
 Everything is float64 on the CPU (parameters are widened on use, so a full-width 910 M-parameter
 state_dict stays in its f16 storage).
 """
@@ -76,26 +79,35 @@ def joint_attention_core(query, key, value, heads):
 # Functional float64 UNet driven by a state_dict (diffusers 0.19.3 naming), written independently
 # of drawingspinup_amd.mv.unet: NCHW tensors, explicit permutes, explicit K/V repeat.
 # ----------------------------------------------------------------------------------------------
-def timestep_embedding(t, dim, flip_sin_to_cos=True, shift=0):
+def timestep_embedding(t, dim, flip_sin_to_cos=True, shift=0, dtype=torch.float64):
+    """diffusers get_timestep_embedding.  diffusers evaluates it in float32 whatever the model
+    dtype (unet_mv2d_condition.py:867-870 "`Timesteps` ... will always return f32 tensors");
+    dtype=torch.float32 reproduces that, the default keeps the exact float64 value."""
     half = dim // 2
-    exponent = -math.log(10000) * torch.arange(half, dtype=torch.float64) / (half - shift)
-    emb = t[:, None].double() * torch.exp(exponent)[None]
+    exponent = -math.log(10000) * torch.arange(half, dtype=dtype) / (half - shift)
+    emb = t[:, None].to(dtype) * torch.exp(exponent)[None]
     emb = torch.cat([torch.sin(emb), torch.cos(emb)], -1)
     if flip_sin_to_cos:
         emb = torch.cat([emb[:, half:], emb[:, :half]], -1)
-    return emb
+    return emb.double()
 
 
 class UNetRef:
     def __init__(self, sd, block_out_channels, down_types, up_types, layers_per_block=2, heads=8,
-                 groups=32, eps=1e-5, num_views=6, cd_attention_mid=True):
+                 groups=32, eps=1e-5, num_views=6, cd_attention_mid=True, temb_dtype=torch.float64):
         self.sd = dict(sd)               # widened to float64 on use (p())
+        self.temb_dtype = temb_dtype
+        self.taps = None                 # set to {} to record named intermediates
         self.boc, self.down_types, self.up_types = block_out_channels, down_types, up_types
         self.lpb, self.heads, self.groups, self.eps = layers_per_block, heads, groups, eps
         self.num_views, self.cd_mid = num_views, cd_attention_mid
 
     def p(self, name):
         return self.sd[name].double()
+
+    def tap(self, name, value):
+        if self.taps is not None:
+            self.taps[name] = value
 
     def lin(self, pre, x, bias=True):
         return F.linear(x, self.p(pre + ".weight"), self.p(pre + ".bias") if bias else None)
@@ -125,22 +137,31 @@ class UNetRef:
                 self.lin(pre + ".to_v", ctx, False))
 
     def block(self, pre, h, ctx):             # BasicMVTransformerBlock.forward
-        q, k, v = self.attn_proj(pre + ".attn1", self.ln(pre + ".norm1", h))
-        h = self.lin(pre + ".attn1.to_out.0", mv_attention_core(q, k, v, self.heads,
-                                                                 self.num_views)) + h
+        n1 = self.ln(pre + ".norm1", h)
+        self.tap(pre + ".norm1", n1)
+        q, k, v = self.attn_proj(pre + ".attn1", n1)
+        a1 = self.lin(pre + ".attn1.to_out.0", mv_attention_core(q, k, v, self.heads, self.num_views))
+        self.tap(pre + ".attn1", a1)
+        h = a1 + h
         if self.cd_mid:
             q, k, v = self.attn_proj(pre + ".attn_joint_mid", self.ln(pre + ".norm_joint_mid", h))
-            h = self.lin(pre + ".attn_joint_mid.to_out.0",
-                         joint_attention_core(q, k, v, self.heads)) + h
+            aj = self.lin(pre + ".attn_joint_mid.to_out.0", joint_attention_core(q, k, v, self.heads))
+            self.tap(pre + ".attn_joint_mid", aj)
+            h = aj + h
         q, k, v = self.attn_proj(pre + ".attn2", self.ln(pre + ".norm2", h), ctx)
         o = memory_efficient_attention(head_to_batch_dim(q, self.heads),
                                        head_to_batch_dim(k, self.heads),
                                        head_to_batch_dim(v, self.heads))
-        h = self.lin(pre + ".attn2.to_out.0", batch_to_head_dim(o, self.heads)) + h
+        a2 = self.lin(pre + ".attn2.to_out.0", batch_to_head_dim(o, self.heads))
+        self.tap(pre + ".attn2", a2)
+        h = a2 + h
         n = self.ln(pre + ".norm3", h)
         proj = self.lin(pre + ".ff.net.0.proj", n)
         a, g = proj.chunk(2, dim=-1)
-        return self.lin(pre + ".ff.net.2", a * F.gelu(g)) + h
+        ff = self.lin(pre + ".ff.net.2", a * F.gelu(g))
+        self.tap(pre + ".ff", ff)
+        self.tap(pre + ".out", ff + h)
+        return ff + h
 
     def transformer(self, pre, x, ctx):       # TransformerMV2DModel.forward
         b, c, hh, ww = x.shape
@@ -155,24 +176,31 @@ class UNetRef:
     def __call__(self, sample, t, ctx, class_labels):
         x, ctx, cl = sample.double(), ctx.double(), class_labels.double()
         B = x.shape[0]
-        temb = timestep_embedding(t.reshape(-1).expand(B), self.boc[0])
+        temb = timestep_embedding(t.reshape(-1).expand(B), self.boc[0], dtype=self.temb_dtype)
         emb = self.lin("time_embedding.linear_2", F.silu(self.lin("time_embedding.linear_1", temb)))
-        emb = emb + self.lin("class_embedding.linear_2",
-                             F.silu(self.lin("class_embedding.linear_1", cl)))
+        self.tap("time_embedding", emb)
+        cemb = self.lin("class_embedding.linear_2", F.silu(self.lin("class_embedding.linear_1", cl)))
+        self.tap("class_embedding", cemb)
+        emb = emb + cemb
         x = self.conv("conv_in", x)
+        self.tap("conv_in", x)
         skips = [x]
         for i, typ in enumerate(self.down_types):
             for j in range(self.lpb):
                 x = self.resnet(f"down_blocks.{i}.resnets.{j}", x, emb)
+                self.tap(f"down_blocks.{i}.resnets.{j}", x)
                 if typ.startswith("CrossAttn"):
                     x = self.transformer(f"down_blocks.{i}.attentions.{j}", x, ctx)
+                    self.tap(f"down_blocks.{i}.attentions.{j}", x)
                 skips.append(x)
             if i != len(self.down_types) - 1:
                 x = self.conv(f"down_blocks.{i}.downsamplers.0.conv", x, stride=2)
                 skips.append(x)
+            self.tap(f"down_blocks.{i}", x)
         x = self.resnet("mid_block.resnets.0", x, emb)
         x = self.transformer("mid_block.attentions.0", x, ctx)
         x = self.resnet("mid_block.resnets.1", x, emb)
+        self.tap("mid_block", x)
         for i, typ in enumerate(self.up_types):
             for j in range(self.lpb + 1):
                 x = torch.cat([x, skips.pop()], 1)
@@ -182,6 +210,7 @@ class UNetRef:
             if i != len(self.up_types) - 1:
                 x = F.interpolate(x, scale_factor=2.0, mode="nearest")
                 x = self.conv(f"up_blocks.{i}.upsamplers.0.conv", x)
+            self.tap(f"up_blocks.{i}", x)
         x = F.silu(self.gn("conv_norm_out", x, self.eps))
         return self.conv("conv_out", x)
 
