@@ -571,9 +571,12 @@ class NeuSModel(nn.Module):
             xs = lin[x0:x0 + slab]
             pts = torch.cat([xs[:, None, None].expand(-1, yz.shape[0], 1),
                              yz[None].expand(xs.shape[0], -1, -1)], -1).reshape(-1, 3)
-            # scale_anything(x, (0,1), (vmin, vmax))
-            lo = torch.tensor(vmin, device=dev)
-            hi = torch.tensor(vmax, device=dev)
-            pts = (pts - 0.0) / (1.0 - 0.0) * (hi - lo) + lo
+            # scale_anything(x, (0,1), (vmin, vmax)) with the reference's type promotion
+            # (geometry.py:85-89): the box corners are float64 scalars, so the span is formed
+            # in float64 and only then rounded to the float32 the lattice is multiplied in
+            lo = torch.tensor(vmin, dtype=torch.float64).float().to(dev)
+            span = (torch.tensor(vmax, dtype=torch.float64)
+                    - torch.tensor(vmin, dtype=torch.float64)).float().to(dev)
+            pts = (pts - 0.0) / (1.0 - 0.0) * span + lo
             level[x0 * res * res:(x0 + xs.shape[0]) * res * res] = self.geometry.forward_level(pts)
         return level.view(res, res, res)

@@ -72,3 +72,51 @@ def test_smoothing_of_an_empty_volume(dev):
     b = torch.zeros(8, 8, 8, dtype=torch.bool, device=dev)
     out = M.smooth_constrained(b)
     assert out.shape == (8, 8, 8) and bool((out < 0).all())
+
+
+def test_isosurface_glue_on_device_matches_reference_geometry_py(dev):
+    """The device run of nsr.mesh.isosurface (HIP smoothing, tensor-program marching cubes, device
+    bicubic resize / crop) against tests/golden/isosurface_reference.npz = the REFERENCE's own
+    geometry.py:33-117 (see tests/test_mesh_host.py for the host run): faces bit-exact, vertices
+    1e-7 (the device Jacobi sums in a different order than scipy)."""
+    import os
+    from tests.test_mesh_host import _Bits
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "isosurface_reference.npz"))
+
+    class DevBits(_Bits):
+        def isosurface_levels(self, vmin, vmax, res):
+            return super().isosurface_levels(vmin, vmax, res).to(dev)
+
+    model = DevBits(z)
+    fine, coarse = M.isosurface(model, torch.from_numpy(z["front_mask"]).to(dev))
+    assert fine["verts"].is_cuda
+    assert np.array_equal(coarse["faces"].cpu().numpy(), z["coarse_faces"])
+    assert np.array_equal(fine["faces"].cpu().numpy(), z["faces"])
+    np.testing.assert_allclose(fine["verts"].cpu().numpy(), z["verts"], rtol=0, atol=1e-7)
+
+
+def test_isosurface_lattice_points_match_reference_grid(dev):
+    """NeuSModel.isosurface_levels evaluates the SDF on the lattice the reference builds with
+    grid_vertices() + scale_anything (geometry.py:40-48,85-89): same x-major order, coordinates
+    within one float32 ulp (linspace on the device vs the host)."""
+    import os
+    from drawingspinup_amd.nsr.model import NeuSModel
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "isosurface_reference.npz"))
+    res = int(z["res"])
+    model = NeuSModel().to(dev)
+    seen = []
+    model.geometry.forward_level = lambda pts: (seen.append(pts.clone()), pts[:, 0] * 0)[1]
+    model.isosurface_levels([-1.0] * 3, [1.0] * 3, res, chunk=70000)
+    coarse = torch.cat(seen, 0).cpu().numpy()
+    seen.clear()
+    # the fine box as the reference held it: float64 corners (here from the fixture's fine mesh
+    # box: the lattice corners it produced)
+    lo, hi = z["fine_pts"].min(0), z["fine_pts"].max(0)
+    model.isosurface_levels(z["fine_vmin"].astype(np.float64), z["fine_vmax"].astype(np.float64), res,
+                            chunk=70000)
+    fine = torch.cat(seen, 0).cpu().numpy()
+    idx = z["pts_index"]
+    assert coarse.shape == (res ** 3, 3)
+    np.testing.assert_allclose(coarse[idx], z["coarse_pts"], rtol=0, atol=1.2e-7)
+    np.testing.assert_allclose(fine[idx], z["fine_pts"], rtol=0, atol=2.4e-7)
+    assert lo.shape == hi.shape == (3,)

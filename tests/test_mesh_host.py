@@ -232,3 +232,51 @@ def test_mesh_post_processing_matches_reference_save_mesh(tmp_path):
     np.testing.assert_allclose([float(x) for x in first[1:4]],
                                np.array([z["verts"][0, 0], z["verts"][0, 2], -z["verts"][0, 1]]) * 0.5 * 1.35,
                                atol=1e-8)
+
+
+class _Bits:
+    """stand-in model for nsr.mesh.isosurface: levels come from the fixture's inside bits (the
+    reference reads the level volume only through `level <= 0`, geometry.py:55,58), in call
+    order coarse -> fine; records the boxes it was asked for."""
+
+    def __init__(self, z):
+        from drawingspinup_amd.nsr.model import Cfg
+        self.res = int(z["res"])
+        self.config = Cfg({"radius": float(z["radius"]),
+                           "geometry": {"isosurface": {"resolution": self.res, "threshold": 0.0}}})
+        n = self.res ** 3
+        self.bits = [np.unpackbits(z["coarse_inside"])[:n], np.unpackbits(z["fine_inside"])[:n]]
+        self.boxes = []
+
+    def isosurface_levels(self, vmin, vmax, res):
+        inside = torch.from_numpy(self.bits[len(self.boxes)].astype(bool))
+        self.boxes.append(([float(v) for v in vmin], [float(v) for v in vmax]))
+        one = torch.ones(res ** 3)
+        return torch.where(inside, -one, one).view(res, res, res)
+
+
+def test_isosurface_glue_matches_reference_geometry_py():
+    """nsr.mesh.isosurface / MarchingCubeHelper / crop_front_mask against the REFERENCE's own
+    geometry.py:33-117 run unmodified (tests/golden/make_isosurface_golden.py; mcubes / cv2.resize
+    served by oracle/mcubes_ref.py): coarse mesh, refit fine box, cropped front mask, and the fine
+    mesh — face index arrays bit-exact, vertices to 1e-12."""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "isosurface_reference.npz"))
+    model = _Bits(z)
+    fm = torch.from_numpy(z["front_mask"])
+    fine, coarse = M.isosurface(model, fm)
+    res = int(z["res"])
+    # coarse pass: whole box, no mask
+    assert model.boxes[0] == ([-1.0] * 3, [1.0] * 3)
+    assert np.array_equal(coarse["faces"].numpy(), z["coarse_faces"])
+    np.testing.assert_allclose(coarse["verts"].numpy(), z["coarse_verts01"] * 2 - 1, rtol=0, atol=1e-12)
+    # refit box: lattice corners of the reference's fine pass are its float32 box
+    np.testing.assert_allclose(np.float32(model.boxes[1][0]), z["fine_vmin"], rtol=0, atol=1e-7)
+    np.testing.assert_allclose(np.float32(model.boxes[1][1]), z["fine_vmax"], rtol=0, atol=1e-7)
+    crop = M.crop_front_mask(fm, model.boxes[1][0], model.boxes[1][1])
+    assert np.array_equal(crop.numpy(), z["cropped_mask"])
+    # fine pass
+    assert fine["faces"].shape == z["faces"].shape
+    assert np.array_equal(fine["faces"].numpy(), z["faces"])
+    np.testing.assert_allclose(fine["verts"].numpy(), z["verts"], rtol=0, atol=1e-12)
+    assert fine["verts"].dtype == torch.float64 and res == 64
