@@ -20,6 +20,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .. import ops
+from . import preprocess as PP
 from .unet import (Downsample2D, Upsample2D, conv_nhwc, group_norm)
 
 
@@ -275,19 +276,22 @@ class MVDiffusionImagePipeline:
 
     @torch.no_grad()
     def _encode_image(self, images):
-        """images (B,3,H,W) in [0,1].  The reference feeds 12 copies of one image through CLIP
-        and the VAE (mv.py:70); identical rows are encoded once and broadcast."""
-        dev, dt = self.device, torch.float16
+        """pipeline_mvdiffusion_image.py:150-182.  images (B,3,H,W) float in [0,1]; mv.py:70 hands
+        them over in the weight dtype (f16).  Every row goes through the reference's 8-bit PIL
+        detour (`to_pil_image`: mul(255) in the tensor's dtype, truncated — pipeline :358) before
+        the CLIP preprocessing (Pillow's antialiased bicubic to 224, /255, normalise) and the VAE
+        encode (k/255 -> f16 -> *2-1): mv/preprocess.py, integer arithmetic pinned to Pillow.
+        The reference feeds 12 copies of one image through CLIP and the VAE (mv.py:70);
+        identical rows are encoded once and broadcast."""
+        dt = torch.float16
         first = images[:1]
         same = bool((images == first).all())
-        src = first if same else images
-        # CLIPImageProcessor: resize 224 bicubic, centre crop, normalise
-        x = F.interpolate(src.float(), size=(224, 224), mode="bicubic", align_corners=False)
-        mean = torch.tensor([0.48145466, 0.4578275, 0.40821073], device=dev).view(1, 3, 1, 1)
-        std = torch.tensor([0.26862954, 0.26130258, 0.27577711], device=dev).view(1, 3, 1, 1)
-        emb = self.image_encoder(pixel_values=((x.clamp(0, 1) - mean) / std).to(dt)).image_embeds
+        src = (first if same else images).to(dt)
+        u8 = PP.to_pil_u8(src)                                        # (b,H,W,3) uint8
+        pix = PP.clip_pixel_values(u8).to(dt)
+        emb = self.image_encoder(pixel_values=pix).image_embeds
         emb = emb.unsqueeze(1)
-        lat = self.vae.encode_mode((src * 2.0 - 1.0).to(dt)) * self.vae.scaling_factor
+        lat = self.vae.encode_mode(PP.vae_input(u8, dt)) * self.vae.scaling_factor
         if same:
             emb = emb.expand(images.shape[0], -1, -1)
             lat = lat.expand(images.shape[0], -1, -1, -1)

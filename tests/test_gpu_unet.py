@@ -352,3 +352,55 @@ def test_unet_vs_reference_module_fixture(dev):
     print("intermediates rel-L2:", {k: "%.1e" % v for k, v in worst.items()})
     assert rel < 5e-3
     assert len(worst) >= 11 and max(worst.values()) < 1e-2
+
+
+def test_pipeline_vs_reference_pipeline_fixture(dev):
+    """drawingspinup_amd.mv.pipeline.MVDiffusionImagePipeline (HIP UNet, f16) against the
+    REFERENCE's own MVDiffusionImagePipeline.__call__ driving its own UNet in float64
+    (tests/golden/mv_pipeline_reference.npz, make_mv_pipeline_golden.py): same f16 input batch,
+    camera embeddings, injected initial latents and per-step variance noise; 3 DDIM steps with
+    eta = 1, decode, denormalise.  Latents after each step rel-L2 < 5e-3, images |d| < 2e-2."""
+    import json
+    import os
+    import numpy as np
+    from drawingspinup_amd.mv.pipeline import MVDiffusionImagePipeline
+    from oracle import mv_weights
+    from oracle.mv_pipeline_aux import (LinearClip, LinearVAE, aux_state, camera_embeddings,
+                                        det_noise, input_image)
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "mv_pipeline_reference.npz"))
+    cfg = json.loads(str(z["cfg_json"]))
+    names_shapes = [(str(n), tuple(int(v) for v in str(s).split(",")) if str(s) else ())
+                    for n, s in zip(z["names"], z["shapes"])]
+    unet = UNetMV2DConditionModel(
+        sample_size=cfg["sample_size"], in_channels=cfg["in_channels"],
+        out_channels=cfg["out_channels"], block_out_channels=tuple(cfg["block_out_channels"]),
+        layers_per_block=cfg["layers_per_block"], cross_attention_dim=cfg["cross_attention_dim"],
+        attention_head_dim=cfg["attention_head_dim"], norm_num_groups=cfg["norm_num_groups"],
+        projection_class_embeddings_input_dim=cfg["projection_class_embeddings_input_dim"],
+        num_views=cfg["num_views"], cd_attention_mid=cfg["cd_attention_mid"],
+        down_block_types=tuple(cfg["down_block_types"]), up_block_types=tuple(cfg["up_block_types"]))
+    unet.load_state_dict({k: v.float() for k, v in mv_weights.synth_state_dict(names_shapes).items()},
+                         strict=True)
+    unet = unet.half().to(dev).eval()
+    vae = aux_state(LinearVAE().double().eval(), "aux.vae.").half().to(dev)
+    clip = aux_state(LinearClip().double().eval(), "aux.clip.").half().to(dev)
+    pipe = MVDiffusionImagePipeline(unet, vae, clip)
+    steps = int(z["steps"])
+    imgs = input_image()[None].expand(12, -1, -1, -1).contiguous()
+    noise = torch.stack([det_noise("draw.%d" % (i + 1), (12, 4, 32, 32)) for i in range(steps)]).half()
+    got = []
+    out = pipe(imgs.to(dev), camera_embeddings().to(dev), num_inference_steps=steps, guidance_scale=1.0,
+               eta=1.0, latents=det_noise("draw.0", (12, 4, 32, 32)).half(), step_noise=noise,
+               output_type="pt", callback=lambda i, t, lat: got.append(lat.float().cpu().double()))
+    assert [int(t) for t in pipe.scheduler.timesteps] == z["timesteps"].tolist()
+    rels = []
+    for i, lat in enumerate(got):
+        want = torch.from_numpy(z["lat_%d" % (i + 1)]).double()
+        rels.append(float((lat - want).norm() / want.norm()))
+    want_img = torch.from_numpy(z["out"].astype(np.float32))
+    d = (out.float().cpu()[z["keep"]] - want_img).abs()
+    print("pipeline vs reference pipeline: latents rel-L2", ["%.1e" % r for r in rels],
+          "image max|d| %.2e mean|d| %.2e" % (float(d.max()), float(d.mean())))
+    assert out.shape == (12, 3, 256, 256) and len(got) == steps
+    assert max(rels) < 5e-3
+    assert float(d.max()) < 2e-2
