@@ -11,8 +11,10 @@ through the hot path on each rank (weak scaling, one drawing per GPU per step):
  -> 24-frame 512x512 stylisation (stage-1 GeneratorJ_RIC + stage-2 GeneratorJ per frame)
 on synthetic 512x512 drawings and random-init weights.  Inside the timed region as well: the
 contour stage's TELEA inpainting tail (host code of the library) and the export's smoothing /
-marching cubes / vertex colours (device).  Not inside (stated in config.workload): mesh
-decimation / thinning of save_mesh, Blender rendering, PNG I/O.
+marching cubes (device), the fine stage's quadric remeshing to 50 000 faces (host code of the
+library) and save_mesh's smoothing / colour back-projection / shear — the reference YAML's export
+switches for a uid outside the thinning list.  Not inside (stated in config.workload): Blender
+rendering, PNG / OBJ file I/O.
 `--config nsr50k` (BASELINE configs[2] micro-benchmark): one step = one NSR optimisation
 iteration with 50 000 rays marched through a 128^3 occupancy grid (synthetic sphere).
 `--config frames` (BASELINE configs[3]): one step = 24 frames through stage 1 + stage 2, the
@@ -278,25 +280,27 @@ def _roofline(timer, extra=None):
 
 
 def bench_drawing(args, ddist, rank, world, dev, timer):
-    from drawingspinup_amd.drawing import DrawingPipeline, synthetic_drawing, synthetic_frames
+    from drawingspinup_amd.drawing import (DrawingPipeline, synthetic_drawing, synthetic_edges,
+                                           synthetic_frames)
     pipe = DrawingPipeline(dev, seed=0, mv_steps=args.mv_steps, nsr_steps=args.nsr_steps,
                            n_frames=args.frames)
     bcast_bytes = sum(ddist.broadcast_module(m, 0) for m in pipe.shared_modules())
     stage_t = {"contour": 0.0, "mv": 0.0, "nsr": 0.0, "style": 0.0}
-    sub_t = {"nsr_fit": 0.0, "nsr_export": 0.0}
+    sub_t = {"nsr_fit": 0.0, "nsr_export": 0.0, "nsr_post": 0.0}
     pipe.time_substages = True               # one extra synchronize between fit and export
 
     # inputs are generated before the clock starts and wait in HBM (the reference reads them
     # from disk; PNG decoding is listed as not timed)
     def make_inputs(seed):
-        return (synthetic_drawing(seed, device=dev), synthetic_frames(seed, args.frames, device=dev))
+        fr = synthetic_frames(seed, args.frames, device=dev)
+        return (synthetic_drawing(seed, device=dev), fr, synthetic_edges(fr))
     inputs = {(False, w): make_inputs(1000 + rank * 100 + w) for w in range(args.warmup)}
     inputs.update({(True, s): make_inputs(rank * 100 + s) for s in range(args.steps)})
     torch.cuda.synchronize()
 
     def one_drawing(s, timed):
         seed = (rank * 100 + s) if timed else (1000 + rank * 100 + s)
-        drawing, frames_in = inputs[(timed, s)]
+        drawing, frames_in, edges_in = inputs[(timed, s)]
         torch.cuda.synchronize(); t0 = time.time()
         cleaned = pipe.remove_contour(drawing)
         torch.cuda.synchronize(); t1 = time.time()
@@ -304,7 +308,7 @@ def bench_drawing(args, ddist, rank, world, dev, timer):
         torch.cuda.synchronize(); t2 = time.time()
         system, inside = pipe.reconstruct(normals, colors, cleaned, 123456 + seed)
         torch.cuda.synchronize(); t3 = time.time()
-        frames = pipe.stylize(frames_in)
+        frames = pipe.stylize(frames_in, edges_in)
         torch.cuda.synchronize(); t4 = time.time()
         if timed:
             for k, v in zip(stage_t, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
@@ -343,9 +347,12 @@ def bench_drawing(args, ddist, rank, world, dev, timer):
         "data": "synthetic",
         "config": {"workload": "one drawing per GPU: contour removal (FFC-ResNet generator, masks, host "
                                "TELEA inpainting, 512^2) -> 6-view diffusion (%d DDIM steps, B=12) -> NSR "
-                               "recon (%d steps, 2x512^3 export: smoothing, marching cubes, vertex colours) "
-                               "-> %d-frame stage1+stage2 stylisation; NOT timed: CPU mesh post-processing "
-                               "(decimation, thinning), Blender, PNG I/O" % (args.mv_steps, args.nsr_steps, args.frames),
+                               "recon (%d steps, 2x512^3 export: smoothing, marching cubes, quadric remeshing "
+                               "to 50 000 faces, then save_mesh's Laplacian smoothing + colour "
+                               "back-projection + shear: the reference YAML's export switches for a uid "
+                               "outside the thinning list) -> %d-frame stage1+stage2 stylisation (stage 2 "
+                               "on the edge-overlaid stage-1 output); NOT timed: Blender, PNG / OBJ file "
+                               "I/O" % (args.mv_steps, args.nsr_steps, args.frames),
                    "drawings_per_step": world, "parallelism": f"replica-per-drawing x{world}",
                    "stage_seconds_rank0": per, "weights_broadcast_bytes": bcast_bytes},
         "roofline": roof,
@@ -401,18 +408,19 @@ def bench_nsr50k(args, ddist, rank, world, dev, timer):
 def bench_frames(args, ddist, rank, world, dev, timer):
     """BASELINE configs[3]: 24 frames 512x512 through stage 1 + stage 2, frame f on rank f mod N,
     stage 2 on the rank of its stage-1 frame (no exchange), outputs gathered to rank 0."""
-    from drawingspinup_amd.drawing import DrawingPipeline, synthetic_frames
+    from drawingspinup_amd.drawing import DrawingPipeline, synthetic_edges, synthetic_frames
     pipe = DrawingPipeline(dev, seed=0, n_frames=args.frames, with_mv=False, with_contour=False)
     for m in (pipe.gen1, pipe.gen2):
         ddist.broadcast_module(m, 0)
     frames = synthetic_frames(0, args.frames, device=dev)
+    edges = synthetic_edges(frames)
     mine = ddist.shard(list(range(args.frames)), rank, world)
     per_rank = (args.frames + world - 1) // world
 
     def step(s, timed):
         out = torch.zeros(per_rank, 4, frames.shape[2], frames.shape[3], dtype=torch.uint8, device=dev)
         if len(mine):
-            out[:len(mine)] = pipe.stylize(frames[mine])
+            out[:len(mine)] = pipe.stylize(frames[mine], edges[mine])
         return ddist.gather_tensor(out)                 # equal shapes: padded to ceil(frames / N)
 
     elapsed, _ = _timed_loop(args, ddist, dev, timer, step)

@@ -49,6 +49,22 @@ def synthetic_frames(seed, n_frames=24, size=512, device="cuda"):
     return torch.stack(frames).to(device)
 
 
+def synthetic_edges(frames):
+    """The `edge/NNNN.png` maps of run_render.py:31-57,117-120 for synthetic frames: per-channel
+    3x3 Sobel magnitude of the position map (background set to 2), max over channels, > 0.3 is an
+    edge; stored inverted (255 = no edge, 0 = edge) as `cv2.imwrite(..., 255 - edge)` does.
+    frames (n,6,H,W) with the mask at channel 3 and pos-XY in [-1,1] at 4:6 -> (n,H,W) uint8."""
+    mask = frames[:, 3:4]
+    pos = (frames[:, 4:6] + 1) / 2                                  # the PNG's [0,1] values
+    pos = torch.where(mask < 1, torch.full_like(pos, 2.0), pos)
+    kx = torch.tensor([[-1.0, 0, 1], [-2, 0, 2], [-1, 0, 1]], device=frames.device)
+    k = torch.stack([kx, kx.t()])[:, None]                           # (2,1,3,3): d/dx, d/dy
+    p = F.pad(pos.reshape(-1, 1, *pos.shape[-2:]), (1, 1, 1, 1), mode="reflect")   # cv2 BORDER_REFLECT_101
+    g = F.conv2d(p, k)
+    val = (g[:, 0] ** 2 + g[:, 1] ** 2).sqrt().reshape(pos.shape[0], 2, *pos.shape[-2:]).amax(1)
+    return torch.where(val > 0.3, 0, 255).to(torch.uint8)
+
+
 def to_image_space(x):
     """custom_transforms.py:8-9 on the device: clip -> uint8."""
     return ((x.clamp(-1, 1) + 1) / 2 * 255).to(torch.uint8)
@@ -58,13 +74,14 @@ class DrawingPipeline:
     """Holds the shared read-only weights (diffusion UNet/VAE/CLIP) and runs drawings."""
 
     def __init__(self, device="cuda", seed=0, mv_steps=75, nsr_steps=3000, n_frames=24,
-                 with_clip=True, export_resolution=512, with_mv=True, with_contour=True):
+                 with_clip=True, export_resolution=512, with_mv=True, with_contour=True, mesh_post=True):
         self.device = torch.device(device)
         self.mv_steps, self.nsr_steps, self.n_frames = mv_steps, nsr_steps, n_frames
         self.style_batch = int(os.environ.get("DSU_STYLE_BATCH", "4"))   # frames per generator call
         self.time_substages = False          # bench.py: split the NSR stage into fit / export
         self.substage_seconds = {}
         self.export_resolution = export_resolution
+        self.mesh_post = mesh_post           # the reference's export switches (remesh, smooth, cbp, shear)
         self.mv = build_random_pipeline(self.device, seed, with_clip=with_clip) if with_mv else None
         torch.manual_seed(seed + 1)
         self.gen1 = build_model("GeneratorJ_RIC", STYLE_ARGS, self.device).eval()
@@ -172,26 +189,53 @@ class DrawingPipeline:
         # export (neus_ortho.py:183-200): smoothed binary volumes, front-mask cutting with the
         # drawing's own alpha (char/mask.png, rotated as ortho.py:155-156), marching cubes, colours
         front = (F.interpolate(drawing_rgba[3:4][None], size=(size, size), mode="nearest")[0, 0] * 255).to(torch.uint8)
-        mesh = system.export_mesh(torch.rot90(front, k=-1, dims=(0, 1)).contiguous(), self.export_resolution)
+        # the switches of configs/neuralangelo-ortho-wmask.yaml:12-20,45-46 as recon.py runs a uid
+        # that is not in the thinning list: remeshing to 50 000 faces inside the fine stage
+        # (geometry.py:63-64), no texture-network colours when colour back-projection is on
+        # (neus.py:224-236)
+        mesh = system.export_mesh(torch.rot90(front, k=-1, dims=(0, 1)).contiguous(), self.export_resolution,
+                                  with_colors=not self.mesh_post, face_count=50000 if self.mesh_post else None)
         self.last_mesh = mesh
         if self.time_substages:
             torch.cuda.synchronize(dev)
-            self.substage_seconds = {"nsr_fit": t1 - t0, "nsr_export": time.time() - t1}
+        t2 = time.time()
+        if self.mesh_post and mesh["faces"].shape[0]:
+            # save_mesh (mesh_utils.py:25-73): Laplacian smoothing, colour back-projection from the
+            # predicted front / back views (2048^2, coloring_utils.py:62,100), shear, ortho scale;
+            # the OBJ text write itself stays outside (file I/O)
+            from .nsr.mesh import post_process_mesh
+            big = lambda t: (F.interpolate(t[None].float(), size=(2048, 2048), mode="bicubic",
+                                           align_corners=False)[0].clamp(0, 1) * 255).to(torch.uint8)
+            cbp = {"color_front": big(colors[0]).permute(1, 2, 0).contiguous(),
+                   "color_back": big(colors[3]).permute(1, 2, 0).contiguous(),
+                   "mask_front": big(drawing_rgba[3:4])[0].contiguous()}
+            v, f, c = post_process_mesh(mesh["verts"], mesh["faces"], None, ortho_scale=1.35,
+                                        smoothing=True, shearing=True, color_back_projection=cbp)
+            self.last_mesh_post = {"verts": v, "faces": f, "colors": c}
+        if self.time_substages:
+            torch.cuda.synchronize(dev)
+            self.substage_seconds = {"nsr_fit": t1 - t0, "nsr_export": t2 - t1, "nsr_post": time.time() - t2}
         return system, mesh["binary"]
 
     # ---------------------------------------------------------------- stage 3: test_stage1/2.py
     @torch.no_grad()
-    def stylize(self, frames):
-        """frames (n,6,H,W).  Stage 1, quantised to uint8 like the PNG hand-off, then stage 2 on the
-        re-normalised stage-1 RGB (+ mask + pos) — test_stage1.py / test_stage2.py loop over the
-        frames one by one; the generators are per-image functions in eval mode, so the frames
-        go through in chunks of `style_batch` (same per-frame results, and the 64^2 / 128^2
-        levels of the U-net get enough tiles to fill the chip)."""
+    def stylize(self, frames, edges=None):
+        """frames (n,6,H,W); edges (n,H,W) uint8 (255 = no edge) or None.  Stage 1, quantised to
+        uint8 like the PNG hand-off, the edge map painted black onto it (DatasetFullImages with
+        use_edge: overlap_edge_on_img, data.py:34-37, custom_transforms.py:31-36), then stage 2 on
+        the re-normalised RGB (+ mask + pos) — test_stage1.py / test_stage2.py loop over the frames
+        one by one; the generators are per-image functions in eval mode, so the frames go through
+        in chunks of `style_batch` (same per-frame results, and the 64^2 / 128^2 levels of the
+        U-net get enough tiles to fill the chip)."""
         outs = []
         for i in range(0, frames.shape[0], self.style_batch):
             x = frames[i:i + self.style_batch]
             s1 = self.gen1(x)
-            q = to_image_space(s1).float() / 255.0 * 2 - 1                 # PNG round trip
+            q8 = to_image_space(s1)                                         # PNG round trip
+            if edges is not None:
+                e = edges[i:i + self.style_batch]
+                q8 = torch.where((e < 255)[:, None], torch.zeros_like(q8), q8)
+            q = q8.float() / 255.0 * 2 - 1
             s2 = self.gen2(torch.cat([q, x[:, 3:]], 1))
             outs.append(torch.cat([to_image_space(s2), (x[:, 3:4] * 255).to(torch.uint8)], 1))
         return torch.cat(outs)
@@ -200,5 +244,6 @@ class DrawingPipeline:
         drawing = synthetic_drawing(seed, device=self.device)
         normals, colors = self.multiview(drawing, 123456 + seed)
         system, inside = self.reconstruct(normals, colors, drawing, 123456 + seed)
-        frames = self.stylize(synthetic_frames(seed, self.n_frames, device=self.device))
+        fr = synthetic_frames(seed, self.n_frames, device=self.device)
+        frames = self.stylize(fr, synthetic_edges(fr))
         return {"views": colors, "inside_voxels": inside.sum(), "frames": frames}

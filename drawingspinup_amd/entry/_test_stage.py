@@ -8,10 +8,8 @@ import torch
 from PIL import Image
 
 from ..style import build_model
+from . import config as C
 from . import data as D
-
-GEN_ARGS = dict(use_bias=False, tanh=True, append_smoothers=True, resnet_blocks=7,
-                filters=[32, 64, 128, 128, 128, 64], input_channels=3)   # configs/config_stage{1,2}.yaml
 
 
 def run(stage, argv=None):
@@ -23,18 +21,26 @@ def run(stage, argv=None):
         ap.add_argument("--no_edge", action="store_true")
         ap.add_argument("--no_alpha", action="store_true")
     ap.add_argument("--checkpoint_id", type=int, default=99999)
-    ap.add_argument("--root_dir", default="../dataset/AnimatedDrawings/preprocessed")
+    ap.add_argument("--root_dir", default=None, help="override of the job's root_dir")
     ap.add_argument("--random_init", action="store_true", help="no checkpoint: random weights")
     args = ap.parse_args(argv)
+    # test_stage1.py:23-26: configs/config_stage<N>.yaml relative to the working directory (the
+    # reference hard-codes the path); the shipped values when that file is not there
+    config = C.load_stage_job(stage)
+    if args.root_dir is not None:
+        config["root_dir"] = args.root_dir
+    args.root_dir = config["root_dir"]
     use_mask, use_pos = not args.no_mask, not args.no_pos
     use_edge = stage == 2 and not args.no_edge
     log_name = f"logs_stage{stage}" + ("_mask" if use_mask else "") + ("_pos" if use_pos else "") \
         + ("_edge" if use_edge else "")
-    gen_args = dict(GEN_ARGS)
+    gen_args = dict(config["generator"]["args"])
     gen_args["input_channels"] += int(use_mask) + 2 * int(use_pos)
-    pre_dir = "color" if stage == 1 else "res_stage1_mask_pos"           # trainer.pre_dir of the yamls
-    dev = torch.device("cuda:0")
-    gen = build_model("GeneratorJ_RIC" if stage == 1 else "GeneratorJ", gen_args, dev)
+    pre_dir = config["trainer"]["pre_dir"]
+    dev = torch.device(config.get("device") or "cuda:0")
+    if dev.type != "cuda":
+        raise RuntimeError("the style nets run on the HIP kernels: job.device must be a GPU")
+    gen = build_model(config["generator"]["type"], gen_args, dev)
     ckpt = os.path.join(args.root_dir, args.uid, "mesh", log_name, "model_%05d.pth" % args.checkpoint_id)
     if not args.random_init:
         gen.load_state_dict(torch.load(ckpt, map_location=dev))

@@ -1,10 +1,8 @@
 """Shared body of train_stage1.py / train_stage2.py (3_style_translator/train_stage{1,2}.py).
 
-The job description is the reference's configs/config_stage{1,2}.yaml; pass --config to read
-such a file, otherwise the shipped values below are used.
+The job description is the reference's configs/config_stage{1,2}.yaml (entry/config.py).
 """
 import argparse
-import copy
 import os
 import time
 
@@ -12,32 +10,13 @@ import torch
 
 from ..style.training import ModelLogger, Trainer, build_model, build_optimizer
 
-_OPT = {"type": "Adam", "args": {"lr": 0.0004, "betas": [0.9, 0.999], "weight_decay": 0.00001}}
+from . import config as C
 
 
 def default_job(stage):
-    """configs/config_stage1.yaml / config_stage2.yaml."""
-    return {
-        "generator": {"type": "GeneratorJ_RIC" if stage == 1 else "GeneratorJ",
-                      "args": dict(use_bias=False, tanh=True, append_smoothers=True,
-                                   resnet_blocks=7, filters=[32, 64, 128, 128, 128, 64],
-                                   input_channels=3)},
-        "opt_generator": copy.deepcopy(_OPT),
-        "discriminator": {"type": "DiscriminatorN_IN", "args": dict(num_filters=12, n_layers=2)},
-        "opt_discriminator": copy.deepcopy(_OPT),
-        "perception_loss": {"weight": 6.0,
-                            "perception_model": {"type": "PerceptualVGG19",
-                                                 "args": dict(feature_layers=[0, 3, 5],
-                                                              use_normalization=False)}},
-        "trainer": dict(batch_size=40, num_workers=1, epochs=3 if stage == 1 else 2,
-                        reconstruction_weight=4.0, adversarial_weight=0.5, use_image_loss=True,
-                        reconstruction_criterion="L1Loss", adversarial_criterion="MSELoss",
-                        log_interval=1000, patch_size=32,
-                        pre_dir="color" if stage == 1 else "res_stage1_mask_pos",
-                        post_name="ffc_resnet_inpainted" if stage == 1 else "texture_with_bg"),
-        "device": "cuda:0",
-        "root_dir": "../dataset/AnimatedDrawings/preprocessed",
-    }
+    """configs/config_stage<N>.yaml as shipped (entry/config.BUILTIN)."""
+    import copy
+    return copy.deepcopy(C.BUILTIN[f"config_stage{stage}"]["job"])
 
 
 def run(stage, argv=None):
@@ -54,12 +33,9 @@ def run(stage, argv=None):
                     help="train against RANDOM vgg19 features (no ImageNet file available)")
     args = ap.parse_args(argv)
 
-    if args.config:
-        import yaml
-        with open(args.config) as f:
-            config = yaml.load(f, Loader=yaml.FullLoader)["job"]
-    else:
-        config = default_job(stage)
+    # train_stage1.py:18-21: configs/config_stage<N>.yaml of the working directory (the reference
+    # hard-codes the path), --config for another file, the shipped values when neither exists
+    config = C.load_stage_job(stage, args.config)
     config["data_root"] = os.path.join(config["root_dir"], args.uid, "mesh", "blender_render")
     use_mask, use_pos = not args.no_mask, not args.no_pos
     use_edge = stage == 2 and not args.no_edge

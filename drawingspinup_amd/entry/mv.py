@@ -1,4 +1,10 @@
-"""`python mv.py --uid U [--all]` of the reference (2_charactor_reconstructor/mv.py:161-181)."""
+"""`python mv.py [--config configs/mvdiffusion-joint-ortho-6views.yaml] --uid U [--all]` of the
+reference (2_charactor_reconstructor/mv.py:161-181).  The YAML file (loaded as mv.py:21-26 does,
+entry/config.py) supplies seed, data_root, uid_list_file, views, resolution, the dataset's
+img_wh and the pipeline's eta / guidance_scale / num_inference_steps; the remaining flags are
+overrides for runs outside a reference checkout (None = the config's value).  The checkpoint is
+`pretrained_model_name_or_path` when it names a local diffusers-layout directory ('./ckpts',
+yaml:2) — the hub id the reference downloads is not reachable from here."""
 import argparse
 import json
 import os
@@ -12,13 +18,14 @@ from . import data as D
 
 
 def main(argv=None):
-    ap = argparse.ArgumentParser()
+    ap = argparse.ArgumentParser(description="mv generation")
+    ap.add_argument("--config", default="./configs/mvdiffusion-joint-ortho-6views.yaml")   # mv.py:164
     ap.add_argument("--uid", default="0dd66be9d0534b93a092d8c4c4dfd30a")
     ap.add_argument("--all", action="store_true")
     ap.add_argument("--img_fn", default="char/ffc_resnet_inpainted.png")
     ap.add_argument("--save_folder", default="mv")
-    ap.add_argument("--data_root", default="../dataset/AnimatedDrawings/preprocessed")
-    ap.add_argument("--uid_list_file", default="../dataset/AnimatedDrawings/drawings_uids.json")
+    ap.add_argument("--data_root", default=None)
+    ap.add_argument("--uid_list_file", default=None)
     ap.add_argument("--pose_dir", default=None, help=".../mvdiffusion/data/fixed_poses/nine_views")
     ap.add_argument("--pretrained", default=None,
                     help="local diffusers-layout directory of the Wonder3D checkpoint "
@@ -29,9 +36,22 @@ def main(argv=None):
     ap.add_argument("--random_init", action="store_true",
                     help="run with random weights for whatever was not given (smoke tests only: the "
                          "outputs are noise)")
-    ap.add_argument("--seed", type=int, default=123456)         # configs/mvdiffusion-joint-ortho-6views.yaml:1
-    ap.add_argument("--num_inference_steps", type=int, default=75)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--num_inference_steps", type=int, default=None)
     args = ap.parse_args(argv)
+    from . import config as C
+    conf = C.load_config(args.config)
+    for key in ("data_root", "uid_list_file", "seed"):
+        if getattr(args, key) is not None:
+            conf[key] = getattr(args, key)
+    kw = dict(conf["pipe_validation_kwargs"])                   # eta, guidance_scale, num_inference_steps
+    if args.num_inference_steps is not None:
+        kw["num_inference_steps"] = args.num_inference_steps
+    if list(conf["views"]) != D.VIEWS or int(conf["validation_dataset"]["num_views"]) != 6:
+        raise NotImplementedError("views: the six Wonder3D views in the shipped order only")
+    if args.pretrained is None and os.path.isdir(str(conf["pretrained_model_name_or_path"])):
+        args.pretrained = conf["pretrained_model_name_or_path"]
+    args.data_root, args.uid_list_file, args.seed = conf["data_root"], conf["uid_list_file"], int(conf["seed"])
     rank, world, local = ddist.init()
     dev = torch.device("cuda", local)
     from ..mv import checkpoint as ck
@@ -63,12 +83,13 @@ def main(argv=None):
             single = single.convert("RGBA")
         if uid in D.ADD_GRAY_UIDS:                          # mv.py:59-62
             single = D.add_gray(single)
-        imgs, cam = D.mv_batch(single, args.pose_dir)
+        imgs, cam = D.mv_batch(single, args.pose_dir, size=int(conf["validation_dataset"]["img_wh"][0]))
         g = torch.Generator(device=dev).manual_seed(args.seed)
-        out = pipe(imgs.to(dev), cam.to(dev), generator=g, guidance_scale=1.0, output_type="pt",
-                   eta=1.0, num_inference_steps=args.num_inference_steps)
+        # mv.py:70-86: the batch in the weight dtype (f16), output_type 'pt', one image per prompt
+        out = pipe(imgs.to(dev, torch.float16), cam.to(dev, torch.float16), generator=g, output_type="pt",
+                   num_images_per_prompt=1, **kw)
         D.write_mv_outputs(os.path.join(args.data_root, uid, args.save_folder), out[:6], out[6:], single,
-                           uid=uid)
+                           res=tuple(conf["resolution"]), uid=uid)
         print(uid, flush=True)
 
 

@@ -1,12 +1,15 @@
-"""`python recon.py --uid U [--all]` of the reference (2_charactor_reconstructor/recon.py:44-62):
-3000 optimisation steps, then the export (neus_ortho.py:183-200): 2 x 512^3 SDF volumes, constrained
-smoothing, front-mask cutting (char/mask.png rotated as ortho.py:155-156), marching cubes, vertex
-colours, written as <uid>/mesh/it3000-mc512-f50000_c[_r][_t][_s][_cbp].obj.  The reference's config
-switches are flags here: quadric decimation of the fine mesh (`--remeshing`, `_r`: host function of
-the library), the thinning deformation (`--thinning`, `_t`: nsr/thinning.py, only for the uids of
-`--thinning_uid_list_file` as recon.py:53-65 does), Laplacian smoothing (`--smoothing`, `_s`),
-colour back-projection (`--color_back_projection`, `_cbp`: device kernels, nsr/mesh_post.py) and
-shear (`--shearing`)."""
+"""`python recon.py [--config configs/neuralangelo-ortho-wmask.yaml] --uid U [--all]` of the
+reference (2_charactor_reconstructor/recon.py:24-65): the YAML file is the source of every setting
+(loaded as recon.py:16-21 does, entry/config.py), so a bare `recon --uid U` runs what the
+reference runs: 3000 optimisation steps, then the export of neus_ortho.py:183-200 with the
+shipped switches ON — front-mask cutting (`_c`), quadric remeshing to `face_count` faces (`_r`),
+thinning for the uids of `dataset.thinning_uid_list_file` only (`_t`, recon.py:53-65), Laplacian
+smoothing (`_s`), shearing, colour back-projection (`_cbp`) — written as
+<data_root>/<uid>/mesh/it3000-mc512-f50000_c_r[_t]_s_cbp.obj.
+
+The extra flags below are overrides for runs outside a reference checkout (tests, synthetic
+data); left unset, the config decides.
+"""
 import argparse
 import json
 import os
@@ -16,69 +19,120 @@ import torch
 
 from .. import dist as ddist
 from ..nsr.system import OrthoNeuSSystem
+from . import config as C
 from . import data as D
 
 
-def main(argv=None):
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--uid", default="0dd66be9d0534b93a092d8c4c4dfd30a")
-    ap.add_argument("--all", action="store_true")
-    ap.add_argument("--data_root", default="../dataset/AnimatedDrawings/preprocessed")
-    ap.add_argument("--uid_list_file", default="../dataset/AnimatedDrawings/drawings_uids.json")
-    ap.add_argument("--pose_dir", default=None, help=".../instant_nsr/datasets/fixed_poses")
-    ap.add_argument("--max_steps", type=int, default=3000)
-    ap.add_argument("--seed", type=int, default=123456)          # recon.py:30
-    # model.geometry.remeshing / face_count (configs/neuralangelo-ortho-wmask.yaml:45-46)
-    ap.add_argument("--remeshing", action="store_true")
-    ap.add_argument("--face_count", type=int, default=50000)
-    # export.thinning / thinning_type (yaml:15-17); applied to the uids of the thinning list only
-    ap.add_argument("--thinning", action="store_true")
-    ap.add_argument("--thinning_type", default="double", choices=["double", "front", "back"])
+def _bool_flag(ap, name, help=None):
+    g = ap.add_mutually_exclusive_group()
+    g.add_argument("--" + name, dest=name, action="store_true", default=None, help=help)
+    g.add_argument("--no-" + name, dest=name, action="store_false")
+
+
+def parse(argv=None):
+    ap = argparse.ArgumentParser(description="reconstruction")
+    ap.add_argument("--config", default="./configs/neuralangelo-ortho-wmask.yaml")      # recon.py:47
+    ap.add_argument("--uid", default="0dd66be9d0534b93a092d8c4c4dfd30a", help="image uid")
+    ap.add_argument("--all", action="store_true", help="process all examples")
+    # overrides (not in the reference's CLI; None = take the config's value)
+    ap.add_argument("--data_root", default=None)
+    ap.add_argument("--uid_list_file", default=None)
     ap.add_argument("--thinning_uid_list_file", default=None)
-    # export.smoothing / export.shearing of the reference's config (mesh_utils.py:42-58); all of
-    # these are off by default here (the reference's yaml has them on)
-    ap.add_argument("--smoothing", action="store_true")
-    ap.add_argument("--shearing", action="store_true")
-    # export.color_back_projection (coloring_utils.py:91-138) from <uid>/mv/{color,mask}/*.png
-    ap.add_argument("--color_back_projection", action="store_true")
+    ap.add_argument("--pose_dir", default=None, help="dataset.cam_pose_dir")
+    ap.add_argument("--max_steps", type=int, default=None, help="trainer.max_steps")
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--face_count", type=int, default=None)
+    ap.add_argument("--resolution", type=int, default=None, help="model.geometry.isosurface.resolution")
+    ap.add_argument("--thinning_type", default=None, choices=["double", "front", "back"])
+    for name in ("remeshing", "thinning", "smoothing", "shearing", "color_back_projection"):
+        _bool_flag(ap, name)
+    ap.add_argument("overrides", nargs="*", help="OmegaConf-style dotlist, e.g. trainer.max_steps=100")
     args = ap.parse_args(argv)
+    conf = C.load_config(args.config, cli_args=args.overrides)
+    ds, ex, geo = conf["dataset"], conf["export"], conf["model"]["geometry"]
+    for key, dst, name in (("data_root", ds, "data_root"), ("uid_list_file", ds, "uid_list_file"),
+                           ("thinning_uid_list_file", ds, "thinning_uid_list_file"),
+                           ("pose_dir", ds, "cam_pose_dir"), ("seed", conf, "seed"),
+                           ("face_count", geo, "face_count"), ("remeshing", geo, "remeshing"),
+                           ("thinning", ex, "thinning"), ("smoothing", ex, "smoothing"),
+                           ("shearing", ex, "shearing"), ("thinning_type", ex, "thinning_type"),
+                           ("color_back_projection", ex, "color_back_projection")):
+        if getattr(args, key) is not None:
+            dst[name] = getattr(args, key)
+    if args.max_steps is not None:
+        conf["trainer"]["max_steps"] = args.max_steps
+        sch = conf["system"]["scheduler"]["schedulers"][1]["args"]        # ${calc_exp_lr_decay_rate:...}
+        sch["gamma"] = 0.1 ** (1.0 / (args.max_steps - conf["system"]["constant_steps"]))
+    if args.resolution is not None:
+        geo["isosurface"]["resolution"] = args.resolution
+    return args, conf
+
+
+def uids_and_thinning(args, conf):
+    """recon.py:52-65: the uid list and, per uid, whether export.thinning survives."""
+    ds = conf["dataset"]
+    if conf["export"]["thinning"]:
+        with open(ds["thinning_uid_list_file"]) as f:             # the reference opens it unconditionally
+            thinning_uids = set(json.load(f))
+    else:
+        thinning_uids = set()
+    if args.all:
+        with open(ds["uid_list_file"]) as f:
+            uids = json.load(f)
+    else:
+        uids = [args.uid]
+    return [(u, bool(conf["export"]["thinning"]) and u in thinning_uids) for u in uids]
+
+
+def recon(uid, thinning, conf, dev):
+    ds, ex, geo = conf["dataset"], conf["export"], conf["model"]["geometry"]
+    mv = os.path.join(ds["data_root"], uid, "mv")                    # config.dataset.input_dir
+    out = os.path.join(ds["data_root"], uid, "mesh")                 # config.export.output_dir
+    pose_dir = ds["cam_pose_dir"] if os.path.isdir(str(ds["cam_pose_dir"])) else None
+    data = D.load_mv_prediction(mv, dev, pose_dir, size=tuple(ds["imSize"]), uid=uid)
+    model_config, system_config = C.nsr_configs(conf)
+    system = OrthoNeuSSystem(model_config, system_config, device=dev, seed=int(conf["seed"]))
+    system.fit(data, max_steps=int(conf["trainer"]["max_steps"]),
+               log_every=int(conf["trainer"].get("log_every_n_steps", 0) or 0) * 5)
+    front = fm = None
+    if geo["front_cutting"]:                                         # dataset.load_front_mask (recon.py:29)
+        from PIL import Image
+        fm = np.array(Image.open(os.path.join(ds["data_root"], uid, "char", "mask.png")).convert("L"))
+        front = torch.from_numpy(np.ascontiguousarray(np.rot90(fm, k=-1))).to(dev)   # cv2.ROTATE_90_CLOCKWISE
+    cbp_on = bool(ex["color_back_projection"])
+    mesh = system.export_mesh(front, face_count=int(geo["face_count"]) if geo["remeshing"] else None,
+                              with_colors=not cbp_on)                # neus.py:224-236: rgb = None with cbp
+    if thinning and fm is None:
+        raise RuntimeError("export.thinning needs char/mask.png (thinning_utils.py:196-200)")
+    run = C.Cfg(C._plain(conf))
+    run["export"]["thinning"] = thinning
+    name = C.export_save_name(run, system.global_step)
+    cbp = None
+    if cbp_on:
+        from PIL import Image
+
+        def big(sub, view, mode):                                    # coloring_utils.py:62,100
+            im = Image.open(os.path.join(mv, sub, view + ".png")).convert(mode)
+            return torch.from_numpy(np.array(im.resize((2048, 2048), Image.LANCZOS))).to(dev)
+        cbp = {"color_front": big("color", "front", "RGB"), "color_back": big("color", "back", "RGB"),
+               "mask_front": big("mask", "front", "L")}
+    from ..nsr.mesh import save_obj
+    os.makedirs(out, exist_ok=True)
+    path = save_obj(os.path.join(out, name + ".obj"), mesh["verts"], mesh["faces"], mesh["vert_colors"],
+                    ortho_scale=float(ex["ortho_scale"]), smoothing=bool(ex["smoothing"]),
+                    shearing=bool(ex["shearing"]), color_back_projection=cbp,
+                    thinning={"mask": fm, "type": ex["thinning_type"]} if thinning else None)
+    torch.save(system.model.state_dict(), os.path.join(out, f"it{system.global_step}.ckpt"))
+    return path
+
+
+def main(argv=None):
+    args, conf = parse(argv)
     rank, world, local = ddist.init()
     dev = torch.device("cuda", local)
-    uids = json.load(open(args.uid_list_file)) if args.all else [args.uid]
-    thinning_uids = None
-    if args.thinning and args.thinning_uid_list_file:
-        thinning_uids = set(json.load(open(args.thinning_uid_list_file)))
-    for uid in ddist.shard(uids, rank, world):
-        ds = D.load_mv_prediction(os.path.join(args.data_root, uid, "mv"), dev, args.pose_dir, uid=uid)
-        system = OrthoNeuSSystem(device=dev, seed=args.seed)
-        system.fit(ds, max_steps=args.max_steps, log_every=500)
-        front = fm = None
-        fm_path = os.path.join(args.data_root, uid, "char", "mask.png")
-        if os.path.isfile(fm_path):
-            from PIL import Image
-            fm = np.array(Image.open(fm_path).convert("L"))
-            front = torch.from_numpy(np.ascontiguousarray(np.rot90(fm, k=-1))).to(dev)   # cv2.ROTATE_90_CLOCKWISE
-        mesh = system.export_mesh(front, face_count=args.face_count if args.remeshing else None)
-        thin = args.thinning and fm is not None and (thinning_uids is None or uid in thinning_uids)
-        out = os.path.join(args.data_root, uid, "mesh")
-        os.makedirs(out, exist_ok=True)
-        from ..nsr.mesh import save_obj
-        name = system.export_name(front is not None) + ("_r" if args.remeshing else "") \
-            + ("_t" if thin else "") + ("_s" if args.smoothing else "") \
-            + ("_cbp" if args.color_back_projection else "")                     # neus_ortho.py:183-194
-        cbp = None
-        if args.color_back_projection:
-            from PIL import Image
-            mv = os.path.join(args.data_root, uid, "mv")
-            big = lambda sub, view, mode: torch.from_numpy(np.array(
-                Image.open(os.path.join(mv, sub, view + ".png")).convert(mode)
-                .resize((2048, 2048), Image.LANCZOS))).to(dev)                   # coloring_utils.py:62,100
-            cbp = {"color_front": big("color", "front", "RGB"), "color_back": big("color", "back", "RGB"),
-                   "mask_front": big("mask", "front", "L")}
-        save_obj(os.path.join(out, name + ".obj"), mesh["verts"], mesh["faces"], mesh["vert_colors"],
-                 smoothing=args.smoothing, shearing=args.shearing, color_back_projection=cbp,
-                 thinning={"mask": fm, "type": args.thinning_type} if thin else None)
-        torch.save(system.model.state_dict(), os.path.join(out, f"it{system.global_step}.ckpt"))
+    work = uids_and_thinning(args, conf)
+    for uid, thinning in ddist.shard(work, rank, world):
+        recon(uid, thinning, conf, dev)
         print(uid, flush=True)
 
 

@@ -621,18 +621,19 @@ def nearest_vertex_colors(old_verts, new_verts, colors):
     return np.asarray(colors)[idx]
 
 
-def save_obj(path, verts, faces, colors=None, ortho_scale=1.35, smoothing=False, shearing=False,
-             color_back_projection=None, thinning=None):
-    """save_mesh (mesh_utils.py:25-73): halve, swap to the front-facing convention (x right, y up,
-    z front), [Laplacian smoothing], [colour back-projection | nearest-vertex colour transfer],
-    [shear], ortho_scale, OBJ with per-vertex colours (trimesh's export of `vertex_colors`:
-    `v x y z r g b`, faces 1-based).  The bracketed steps are opt-in (the reference's config has
-    them on).  color_back_projection: dict(color_front, mask_front, color_back) of (res,res[,3])
-    uint8 device tensors — the LANCZOS-resized <uid>/mv PNGs — runs nsr/mesh_post.color_projection
-    (coloring_utils.py:91-138) on the device instead of the nearest-vertex transfer
-    (mesh_utils.py:48-53).  thinning: dict(mask=(res,res) uint8 character mask, type='double' |
-    'front' | 'back') runs nsr/thinning.thinning_processing (mesh_utils.py:38-39) first; the
-    nearest-vertex colour transfer then reads the thinned vertices, as the reference's does."""
+def post_process_mesh(verts, faces, colors=None, ortho_scale=1.35, smoothing=False, shearing=False,
+                      color_back_projection=None, thinning=None):
+    """save_mesh (mesh_utils.py:25-73) up to the file write: halve, swap to the front-facing
+    convention (x right, y up, z front), [thinning], [Laplacian smoothing], [colour back-projection
+    | nearest-vertex colour transfer], [shear], ortho_scale.  Returns (verts (N,3) f64, faces (M,3)
+    i64 0-based, colors (N,3) f32 or None) as numpy arrays.  The bracketed steps follow the
+    reference's export.* switches (all on in its YAML).  color_back_projection: dict(color_front,
+    mask_front, color_back) of (res,res[,3]) uint8 device tensors — the LANCZOS-resized <uid>/mv
+    PNGs — runs nsr/mesh_post.color_projection (coloring_utils.py:91-138) on the device instead of
+    the nearest-vertex transfer (mesh_utils.py:48-53).  thinning: dict(mask=(res,res) uint8
+    character mask, type='double' | 'front' | 'back') runs nsr/thinning.thinning_processing
+    (mesh_utils.py:38-39) first; the nearest-vertex colour transfer then reads the thinned
+    vertices, as the reference's does."""
     v = verts.detach().cpu().numpy().astype(np.float64) * 0.5
     old = np.zeros_like(v)
     old[:, 0], old[:, 1], old[:, 2] = v[:, 0], v[:, 2], -v[:, 1]
@@ -658,16 +659,30 @@ def save_obj(path, verts, faces, colors=None, ortho_scale=1.35, smoothing=False,
                              cbp["color_back"], res=cbp["color_front"].shape[0]).float().cpu().numpy()
     if shearing and len(out):
         out = shear_transformation(out)
-    out = out * ortho_scale
-    f = fz + 1
+    return out * ortho_scale, fz, c
+
+
+def write_obj(path, verts, faces, colors=None):
+    """trimesh's OBJ export of a mesh with `vertex_colors` (mesh_utils.py:60-73): `v x y z r g b`,
+    faces 1-based."""
     os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    lines = []
+    if colors is not None:
+        for p, q in zip(verts, colors):
+            lines.append("v %.8f %.8f %.8f %.6f %.6f %.6f\n" % (p[0], p[1], p[2], q[0], q[1], q[2]))
+    else:
+        for p in verts:
+            lines.append("v %.8f %.8f %.8f\n" % (p[0], p[1], p[2]))
+    for t in faces + 1:
+        lines.append("f %d %d %d\n" % (t[0], t[1], t[2]))
     with open(path, "w") as fh:
-        if c is not None:
-            for p, q in zip(out, c):
-                fh.write("v %.8f %.8f %.8f %.6f %.6f %.6f\n" % (p[0], p[1], p[2], q[0], q[1], q[2]))
-        else:
-            for p in out:
-                fh.write("v %.8f %.8f %.8f\n" % (p[0], p[1], p[2]))
-        for t in f:
-            fh.write("f %d %d %d\n" % (t[0], t[1], t[2]))
+        fh.writelines(lines)
     return path
+
+
+def save_obj(path, verts, faces, colors=None, ortho_scale=1.35, smoothing=False, shearing=False,
+             color_back_projection=None, thinning=None):
+    """save_mesh (mesh_utils.py:25-73) = post_process_mesh + write_obj."""
+    out, fz, c = post_process_mesh(verts, faces, colors, ortho_scale, smoothing, shearing,
+                                   color_back_projection, thinning)
+    return write_obj(path, out, fz, c)

@@ -30,11 +30,23 @@ def test_entry_points_chain(dev, tmp_path):
         assert files == sorted(f"{v}.png" for v in ("front", "front_right", "right", "back", "left", "front_left"))
     assert Image.open(os.path.join(root, uid, "mv", "color", "front.png")).size == (1024, 1024)
     _drawing().split()[-1].save(os.path.join(root, uid, "char", "mask.png"))     # front mask (ortho.py:153-156)
-    recon.main(["--uid", uid, "--data_root", root, "--max_steps", "20"])
+    import json
+    thin_list = os.path.join(root, "drawings_uids_thinning.json")
+    json.dump(["some-other-uid"], open(thin_list, "w"))
+    # the reference's CLI (--config / --uid) + the two path overrides a synthetic directory needs;
+    # every export switch comes from the YAML: remeshing to 50000 faces, smoothing, shearing and
+    # colour back-projection on, thinning only for the uids of the thinning list (recon.py:53-65)
+    recon.main(["--config", "./configs/neuralangelo-ortho-wmask.yaml", "--uid", uid, "--data_root", root,
+                "--thinning_uid_list_file", thin_list, "--max_steps", "20"])
     # recon.py's product: the mesh file, named as neus_ortho.py:184-196 names it
-    obj = open(os.path.join(root, uid, "mesh", "it20-mc512-f50000_c.obj")).read().splitlines()
+    obj = open(os.path.join(root, uid, "mesh", "it20-mc512-f50000_c_r_s_cbp.obj")).read().splitlines()
     nv, nf = sum(l.startswith("v ") for l in obj), sum(l.startswith("f ") for l in obj)
-    assert nv > 1000 and nf > 2000
+    assert nv > 1000 and 2000 < nf <= 50000                          # model.geometry.face_count
+    # a uid of the thinning list gets the `_t` step and suffix
+    json.dump([uid], open(thin_list, "w"))
+    recon.main(["--uid", uid, "--data_root", root, "--thinning_uid_list_file", thin_list,
+                "--max_steps", "4", "--resolution", "256"])
+    assert os.path.isfile(os.path.join(root, uid, "mesh", "it4-mc256-f50000_c_r_t_s_cbp.obj"))
     assert len(obj[0].split()) == 7                                   # v x y z r g b
     idx = np.array([[int(t) for t in l.split()[1:]] for l in obj if l.startswith("f ")])
     assert idx.min() == 1 and idx.max() == nv                         # 1-based, every vertex used
