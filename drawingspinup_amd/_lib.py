@@ -133,6 +133,10 @@ _PROTOS = {
     "dsu_point_bin_fill": [P, c_i64, c_f32, c_f32, c_f32, c_i32, P, P, P, P],
     "dsu_knn8_blend": [P, c_i64, P, P, c_i64, c_f32, c_f32, c_f32, c_i32, P, P, P, P],
     "dsu_mesh_decimate_quadric": [P, c_i64, P, c_i64, c_i64, C.c_double, c_i32, P, P, P, P],
+    "dsu_mesh_decimate_quadric_q": [P, c_i64, P, c_i64, c_i64, C.c_double, c_i32, P, P, P, P, P],
+    "dsu_mesh_decimate_parallel_workspace_bytes": [c_i64, c_i64],
+    "dsu_mesh_decimate_parallel": [P, c_i64, P, c_i64, c_i64, c_i64, C.c_double, c_i32, c_i32, P, P, P, P,
+                                   c_i64, P],
     "dsu_distance_transform_l2_5x5": [P, c_i32, c_i32, P],
     "dsu_skeletonize_lee_2d": [P, c_i32, c_i32, P],
     "dsu_nsr_draws": [C.c_uint64, c_i64, c_i32, c_i32, c_i32, c_i32, P, P, P, P, c_i32, P, P, P],

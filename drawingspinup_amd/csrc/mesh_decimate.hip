@@ -144,12 +144,10 @@ void edge_target(const Mesh& m, int32_t v0, int32_t v1, double& cost, V3& vbar) 
 
 }  // namespace
 
-extern "C" {
-
-int dsu_mesh_decimate_quadric(const double* verts, int64_t n_verts, const int32_t* faces,
-                              int64_t n_faces, int64_t target_faces, double boundary_weight,
-                              int32_t flags, double* out_verts, int64_t* out_n_verts,
-                              int32_t* out_faces, int64_t* out_n_faces) {
+static int decimate_impl(const double* verts, int64_t n_verts, const int32_t* faces,
+                         int64_t n_faces, int64_t target_faces, double boundary_weight,
+                         int32_t flags, const double* init_quadrics, double* out_verts,
+                         int64_t* out_n_verts, int32_t* out_faces, int64_t* out_n_faces) {
   if (n_verts < 0 || n_faces < 0 || target_faces < 0 || (n_verts && !verts) || (n_faces && !faces) ||
       !out_n_verts || !out_n_faces || (n_verts && !out_verts) || (n_faces && !out_faces) ||
       n_verts > INT32_MAX || n_faces > INT32_MAX || !(boundary_weight >= 0.0))
@@ -188,7 +186,7 @@ int dsu_mesh_decimate_quadric(const double* verts, int64_t n_verts, const int32_
     if (!m.f_alive[t]) continue;
     const V3 cr = m.tri_cross(t);
     const double l = norm(cr);
-    if (l > 0.0) {
+    if (l > 0.0 && !init_quadrics) {
       const V3 n = cr * (1.0 / l);
       const double area = 0.5 * l, d = -dot(n, m.v[m.f[3 * t]]);
       for (int k = 0; k < 3; ++k) m.q[m.f[3 * t + k]].add_plane(n, d, area);
@@ -199,7 +197,17 @@ int dsu_mesh_decimate_quadric(const double* verts, int64_t n_verts, const int32_
       edge_tri[key] = t;
     }
   }
-  if (boundary_weight > 0.0) {
+  if (init_quadrics) {
+    // quadrics accumulated by earlier collapses (dsu_mesh_decimate_parallel): (n_verts,10) in this
+    // file's member order a00 a01 a02 a11 a12 a22 b0 b1 b2 c
+    for (int64_t i = 0; i < n_verts; ++i) {
+      const double* p = init_quadrics + 10 * i;
+      Quadric& q = m.q[i];
+      q.a00 = p[0]; q.a01 = p[1]; q.a02 = p[2]; q.a11 = p[3]; q.a12 = p[4]; q.a22 = p[5];
+      q.b0 = p[6]; q.b1 = p[7]; q.b2 = p[8]; q.c = p[9];
+    }
+  }
+  if (boundary_weight > 0.0 && !init_quadrics) {
     for (const auto& kv : edge_count) {
       if (kv.second != 1) continue;
       const int32_t t = edge_tri[kv.first];
@@ -333,6 +341,24 @@ int dsu_mesh_decimate_quadric(const double* verts, int64_t n_verts, const int32_
   *out_n_verts = nv;
   *out_n_faces = nf;
   return DSU_OK;
+}
+
+extern "C" {
+
+int dsu_mesh_decimate_quadric(const double* verts, int64_t n_verts, const int32_t* faces,
+                              int64_t n_faces, int64_t target_faces, double boundary_weight,
+                              int32_t flags, double* out_verts, int64_t* out_n_verts,
+                              int32_t* out_faces, int64_t* out_n_faces) {
+  return decimate_impl(verts, n_verts, faces, n_faces, target_faces, boundary_weight, flags, nullptr,
+                       out_verts, out_n_verts, out_faces, out_n_faces);
+}
+
+int dsu_mesh_decimate_quadric_q(const double* verts, int64_t n_verts, const int32_t* faces,
+                                int64_t n_faces, int64_t target_faces, double boundary_weight,
+                                int32_t flags, const double* vertex_quadrics, double* out_verts,
+                                int64_t* out_n_verts, int32_t* out_faces, int64_t* out_n_faces) {
+  return decimate_impl(verts, n_verts, faces, n_faces, target_faces, boundary_weight, flags,
+                       vertex_quadrics, out_verts, out_n_verts, out_faces, out_n_faces);
 }
 
 }  // extern "C"

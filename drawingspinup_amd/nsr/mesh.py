@@ -460,25 +460,76 @@ def resize_cubic_u8(img, out_hw):
 # ------------------------------------------------------------------------------------------------
 # MarchingCubeHelper / isosurface / export
 # ------------------------------------------------------------------------------------------------
-def remesh(verts, faces, face_count, boundary_weight=1.0, keep_manifold=True):
-    """mesh_utils.py:10-22 (`trimesh.simplify_quadratic_decimation(face_count)` -> Open3D's quadric
-    decimation): (N,3) float verts, (M,3) int faces -> (verts float64, faces int64), collapsed until
-    the face count is <= face_count (or no admissible collapse is left).  Host arrays in and out —
-    `dsu_mesh_decimate_quadric` (restated from the published method; trimesh / Open3D are absent:
-    unpinned — see the kernel file's header for what is kept and what is added)."""
+def _remesh_host(v, f, face_count, boundary_weight, keep_manifold, quadrics=None):
     import ctypes as C
     from .. import _lib, ops
-    v = np.ascontiguousarray(np.asarray(verts.detach().cpu() if torch.is_tensor(verts) else verts,
-                                        dtype=np.float64))
-    f = np.ascontiguousarray(np.asarray(faces.detach().cpu() if torch.is_tensor(faces) else faces)
-                             .astype(np.int32))
     ov, of = np.empty_like(v), np.empty_like(f)
     nv, nf = C.c_int64(0), C.c_int64(0)
     p = lambda a: a.ctypes.data_as(C.c_void_p)
-    ops.check(_lib.lib().dsu_mesh_decimate_quadric(
-        p(v), v.shape[0], p(f), f.shape[0], int(face_count), float(boundary_weight),
-        0 if keep_manifold else 1, p(ov), C.byref(nv), p(of), C.byref(nf)), "dsu_mesh_decimate_quadric")
+    flags = 0 if keep_manifold else 1
+    if quadrics is None:
+        ops.check(_lib.lib().dsu_mesh_decimate_quadric(
+            p(v), v.shape[0], p(f), f.shape[0], int(face_count), float(boundary_weight), flags,
+            p(ov), C.byref(nv), p(of), C.byref(nf)), "dsu_mesh_decimate_quadric")
+    else:
+        ops.check(_lib.lib().dsu_mesh_decimate_quadric_q(
+            p(v), v.shape[0], p(f), f.shape[0], int(face_count), float(boundary_weight), flags,
+            p(quadrics), p(ov), C.byref(nv), p(of), C.byref(nf)), "dsu_mesh_decimate_quadric_q")
     return ov[:nv.value].copy(), of[:nf.value].astype(np.int64)
+
+
+# the device rounds stop at PARALLEL_STOP x face_count and never go below PARALLEL_FLOOR x
+# face_count; the serial queue (seeded with the accumulated quadrics) takes the last stretch and
+# lands on the exact count
+PARALLEL_STOP, PARALLEL_FLOOR, PARALLEL_MIN_FACES = 1.25, 1.0, 20000
+last_remesh_stats = {}
+
+
+def remesh(verts, faces, face_count, boundary_weight=1.0, keep_manifold=True):
+    """mesh_utils.py:10-22 (`trimesh.simplify_quadratic_decimation(face_count)` -> Open3D's quadric
+    decimation): (N,3) float verts, (M,3) int faces -> (verts float64, faces int64) numpy arrays,
+    collapsed until the face count is <= face_count (or no admissible collapse is left).
+    Device tensors (the export path: 1-3 M triangles from the 512^3 marching cubes): rounds of
+    independent collapses on the GPU down to 1.25 x face_count (`dsu_mesh_decimate_parallel`), then
+    the serial queue for the last stretch.  Host arrays: the serial queue alone
+    (`dsu_mesh_decimate_quadric`; restated from the published method — trimesh / Open3D are absent:
+    unpinned, see the kernel files' headers for what is kept and what is added)."""
+    import ctypes as C
+    from .. import _lib, ops
+    on_device = torch.is_tensor(verts) and verts.is_cuda
+    n_faces = int(faces.shape[0])
+    if not on_device or n_faces <= max(PARALLEL_MIN_FACES, PARALLEL_STOP * face_count):
+        v = np.ascontiguousarray(np.asarray(verts.detach().cpu() if torch.is_tensor(verts) else verts,
+                                            dtype=np.float64))
+        f = np.ascontiguousarray(np.asarray(faces.detach().cpu() if torch.is_tensor(faces) else faces)
+                                 .astype(np.int32))
+        return _remesh_host(v, f, face_count, boundary_weight, keep_manifold)
+    dev = verts.device
+    v = verts.detach().to(torch.float64).contiguous().clone()
+    f = faces.detach().to(dev, torch.int32).contiguous().clone()
+    nv = v.shape[0]
+    lib = _lib.lib()
+    ws_bytes = int(lib.dsu_mesh_decimate_parallel_workspace_bytes(nv, n_faces))
+    if ws_bytes < 0:
+        raise ops.DsuError("dsu_mesh_decimate_parallel_workspace_bytes: unsupported size")
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    quad = torch.empty(nv, 10, dtype=torch.float64, device=dev)
+    out_nf = C.c_int64(0)
+    stats = (C.c_int32 * 3)()
+    ops.check(lib.dsu_mesh_decimate_parallel(
+        v.data_ptr(), nv, f.data_ptr(), n_faces, int(PARALLEL_STOP * face_count),
+        int(PARALLEL_FLOOR * face_count), float(boundary_weight), 0 if keep_manifold else 1, 200,
+        quad.data_ptr(), C.byref(out_nf), stats, ws.data_ptr(), ws_bytes,
+        torch.cuda.current_stream(dev).cuda_stream), "dsu_mesh_decimate_parallel")
+    f = f[:out_nf.value]
+    # only the vertices still in use travel to the host
+    used, inv = torch.unique(f.reshape(-1).long(), return_inverse=True)
+    last_remesh_stats.update(input_faces=n_faces, device_faces=int(out_nf.value), rounds=int(stats[0]),
+                             collapses=int(stats[1]), rejected=int(stats[2]))
+    hv = np.ascontiguousarray(v[used].cpu().numpy())
+    hq = np.ascontiguousarray(quad[used].cpu().numpy())
+    hf = np.ascontiguousarray(inv.reshape(-1, 3).to(torch.int32).cpu().numpy())
+    return _remesh_host(hv, hf, face_count, boundary_weight, keep_manifold, quadrics=hq)
 
 
 class MarchingCubeHelper:

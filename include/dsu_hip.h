@@ -813,6 +813,31 @@ int dsu_mesh_decimate_quadric(const double* verts, int64_t n_verts, const int32_
                               int32_t flags, double* out_verts, int64_t* out_n_verts,
                               int32_t* out_faces, int64_t* out_n_faces);
 
+/* The same, seeded with per-vertex quadrics (n_verts,10: a00 a01 a02 a11 a12 a22 b0 b1 b2 c of
+ * [A b; b^T c]) instead of computing them from the input triangles — the finishing pass after
+ * dsu_mesh_decimate_parallel, whose collapses have accumulated them. */
+int dsu_mesh_decimate_quadric_q(const double* verts, int64_t n_verts, const int32_t* faces,
+                                int64_t n_faces, int64_t target_faces, double boundary_weight,
+                                int32_t flags, const double* vertex_quadrics, double* out_verts,
+                                int64_t* out_n_verts, int32_t* out_faces, int64_t* out_n_faces);
+
+/* The bulk of the same `remesh` call (mesh_utils.py:10-22; geometry.py:63-64 hands it the 512^3
+ * marching-cubes mesh, 1-3 M triangles) ON THE DEVICE: rounds of independent quadric edge collapses
+ * with the serial function's admissibility rules (csrc/mesh_decimate_gpu.hip).  verts (n_verts,3)
+ * f64 and faces (n_faces,3) i32 are DEVICE arrays updated in place: surviving vertices keep their
+ * index (positions move), the live triangles are compacted to the first *out_n_faces rows.
+ * Rounds run while the live count is above stop_faces (at most max_rounds) and a round never takes
+ * the count below floor_faces (<= stop_faces); the caller finishes with
+ * dsu_mesh_decimate_quadric_q(out_quadrics) which lands on the exact target.  out_quadrics:
+ * (n_verts,10) f64 device or NULL.  out_stats: host int32[3] = rounds, collapses, rejections, or
+ * NULL.  Synchronises the stream (one count per round is read back).  flags as above. */
+int64_t dsu_mesh_decimate_parallel_workspace_bytes(int64_t n_verts, int64_t n_faces);
+int dsu_mesh_decimate_parallel(double* verts, int64_t n_verts, int32_t* faces, int64_t n_faces,
+                               int64_t stop_faces, int64_t floor_faces, double boundary_weight,
+                               int32_t flags, int32_t max_rounds, double* out_quadrics,
+                               int64_t* out_n_faces, int32_t* out_stats, void* workspace,
+                               int64_t workspace_bytes, void* stream);
+
 /* Image-side host steps of thinning_processing (instant_nsr/utils/thinning_utils.py:205-218) on
  * HOST arrays (H,W) uint8, non-zero = character:
  *   cv2.distanceTransform(mask, cv2.DIST_L2, 5)            -> out (H,W) float32
