@@ -10,10 +10,11 @@
 //   1. vertex -> triangle lists (CSR) of the live mesh; one "owner" half-edge per edge;
 //   2. cost + target of every edge (identical arithmetic to the serial code: edge_target);
 //   3. the cheapest `budget` edges are candidates, ranked by (cost, edge order);
-//   4. every candidate writes its rank into all vertices of its closed neighbourhood
-//      (v0, v1 and their one-rings) with atomicMin; a candidate that still owns ALL of them is
-//      selected: selected collapses have pairwise disjoint neighbourhoods, so their flip tests,
-//      link conditions and updates cannot see each other;
+//   4. every candidate writes a (hashed, unique) priority into all vertices of its closed
+//      neighbourhood (v0, v1 and their one-rings) with atomicMin; a candidate whose two END POINTS
+//      still carry its priority is selected: no selected collapse has an end point equal or
+//      adjacent to another's, so their flip tests, link conditions and updates cannot see each
+//      other (see collapse_kernel);
 //   5. selected + admissible collapses are applied in place; dead triangles are compacted away.
 // A collapse rejected by the flip / link tests is remembered (direct-mapped table keyed by the
 // edge, valid while neither end point's neighbourhood changed) so that it does not keep winning
@@ -31,6 +32,8 @@
 
 #include <math.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <hipcub/hipcub.hpp>
 
@@ -260,41 +263,75 @@ __device__ inline void edge_ends(const Mesh& m, int32_t h, int32_t& v0, int32_t&
   v1 = a < b ? b : a;
 }
 
-// candidate of rank r (position in the cost order) stamps r on every vertex of its neighbourhood
+// Priority of a candidate inside the independent-set selection: a hash of (edge, round) — NOT its
+// cost rank.  Costs vary smoothly over the surface (and tie on regular meshes), so "the cheapest
+// edge of its neighbourhood wins" leaves one winner per monotone chain: a few dozen collapses per
+// round on a 150 k-triangle sphere.  The cost decides who is a candidate (the cheapest `ncand`
+// edges); a locally random, globally unique 64-bit priority decides which non-conflicting subset
+// of them goes first.
+__device__ inline unsigned long long priority_of(int32_t v0, int32_t v1, uint32_t round, uint32_t r) {
+  unsigned long long k = ekey(v0, v1) ^ ((unsigned long long)round * 0x9e3779b97f4a7c15ull);
+  k ^= k >> 31; k *= 0xbf58476d1ce4e5b9ull; k ^= k >> 29; k *= 0x94d049bb133111ebull; k ^= k >> 32;
+  return (k << 32) | r;                                      // unique: r is the candidate's index
+}
+
+// every candidate stamps its priority on all vertices of its closed neighbourhood (v0, v1, rings)
+// Several selection passes share one round's lists, edge list and cost order.  After a pass, the
+// lists of the end points of applied collapses are stale (v1 is gone, v0 gained triangles) and so
+// is every triangle that held a v1: a candidate is `dirty` — skipped until the next round — when
+// any vertex of its closed neighbourhood was an end point of a collapse applied earlier in this
+// round (`touched[v] == round`).  Everything a clean candidate reads is as it was at round start.
+__device__ inline bool is_dirty(const Mesh& m, int32_t v0, int32_t v1, const uint32_t* touched, uint32_t round) {
+  for (int pass = 0; pass < 2; ++pass) {
+    const int32_t v = pass ? v1 : v0;
+    for (int32_t i = m.voff[v]; i < m.voff[v + 1]; ++i) {
+      const int32_t t = m.vfaces[i];
+      for (int k = 0; k < 3; ++k)
+        if (touched[m.F[3 * t + k]] == round) return true;
+    }
+  }
+  return touched[v0] == round || touched[v1] == round;
+}
+
 __global__ void claim_kernel(Mesh m, const int32_t* edges, const uint32_t* sorted_idx, const uint32_t* sorted_cost,
-                             int64_t ncand, uint32_t* claim) {
+                             int64_t ncand, uint32_t round, uint32_t seed, const uint32_t* touched,
+                             unsigned long long* claim) {
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < ncand; r += (int64_t)gridDim.x * blockDim.x) {
     if (sorted_cost[r] == 0x7f800000u) continue;            // +inf: remembered rejection
     int32_t v0, v1;
     edge_ends(m, edges[sorted_idx[r]], v0, v1);
+    if (is_dirty(m, v0, v1, touched, round)) continue;
+    const unsigned long long pr = priority_of(v0, v1, seed, (uint32_t)r);
     for (int pass = 0; pass < 2; ++pass) {
       const int32_t v = pass ? v1 : v0;
       for (int32_t i = m.voff[v]; i < m.voff[v + 1]; ++i) {
         const int32_t t = m.vfaces[i];
-        for (int k = 0; k < 3; ++k) atomicMin(&claim[m.F[3 * t + k]], (uint32_t)r);
+        for (int k = 0; k < 3; ++k) atomicMin(&claim[m.F[3 * t + k]], pr);
       }
     }
   }
 }
 
-// selected (owns its whole neighbourhood) -> admissibility tests of the serial code -> apply
+// Selected = both END POINTS still carry this candidate's priority.  If an end point of another
+// candidate B lies in the closed neighbourhood of A, A stamped it and B stamped one of A's end
+// points (adjacency is symmetric), so at most one of the two keeps both of its end points: selected
+// collapses never have an end point equal or adjacent to another's.  That is all they need: a
+// collapse moves v0, deletes v1 and rewrites only triangles around v1; its tests read the
+// positions of ring vertices (not moved: not end points of a selected collapse) and the triangles
+// around v0 / v1 (not rewritten: they would have to contain another collapse's v1, which would
+// then be a ring vertex).  Rings may overlap.
+// selected -> admissibility tests of the serial code -> apply
 __global__ void collapse_kernel(Mesh m, const int32_t* edges, const uint32_t* sorted_idx, const uint32_t* sorted_cost,
-                                int64_t ncand, const uint32_t* claim, int link_test, uint8_t* f_alive,
-                                Reject* rej, uint32_t n_slots, uint32_t* vver, int32_t* counters) {
+                                int64_t ncand, uint32_t round, uint32_t seed, const unsigned long long* claim,
+                                int link_test, uint8_t* f_alive, Reject* rej, uint32_t n_slots, uint32_t* vver,
+                                uint32_t* touched_next, const uint32_t* touched, int32_t* counters) {
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < ncand; r += (int64_t)gridDim.x * blockDim.x) {
     if (sorted_cost[r] == 0x7f800000u) continue;
     int32_t v0, v1;
     edge_ends(m, edges[sorted_idx[r]], v0, v1);
-    bool mine = true;
-    for (int pass = 0; pass < 2 && mine; ++pass) {
-      const int32_t v = pass ? v1 : v0;
-      for (int32_t i = m.voff[v]; i < m.voff[v + 1] && mine; ++i) {
-        const int32_t t = m.vfaces[i];
-        for (int k = 0; k < 3; ++k)
-          if (claim[m.F[3 * t + k]] != (uint32_t)r) { mine = false; break; }
-      }
-    }
-    if (!mine) continue;
+    const unsigned long long pr = priority_of(v0, v1, seed, (uint32_t)r);
+    if (claim[v0] != pr || claim[v1] != pr) continue;
+    if (is_dirty(m, v0, v1, touched, round)) continue;      // (its claim was never written: belt and braces)
     double cost; D3 vbar;
     edge_target(m, v0, v1, cost, vbar);
     const int32_t b0 = m.voff[v0], e0 = m.voff[v0 + 1], b1 = m.voff[v1], e1 = m.voff[v1 + 1];
@@ -365,7 +402,7 @@ __global__ void collapse_kernel(Mesh m, const int32_t* edges, const uint32_t* so
       const int32_t v = pass ? v1 : v0;
       for (int32_t i = m.voff[v]; i < m.voff[v + 1]; ++i) {
         const int32_t t = m.vfaces[i];
-        for (int k = 0; k < 3; ++k) vver[m.F[3 * t + k]] = vver[m.F[3 * t + k]] + 1;   // owned: plain RMW
+        for (int k = 0; k < 3; ++k) atomicAdd(&vver[m.F[3 * t + k]], 1u);   // rings may be shared
       }
     }
     int removed = 0;
@@ -381,6 +418,8 @@ __global__ void collapse_kernel(Mesh m, const int32_t* edges, const uint32_t* so
     }
     m.P[3 * v0] = vbar.x; m.P[3 * v0 + 1] = vbar.y; m.P[3 * v0 + 2] = vbar.z;
     for (int i = 0; i < 10; ++i) m.Q[10 * (int64_t)v0 + i] += m.Q[10 * (int64_t)v1 + i];
+    touched_next[v0] = round;                                // visible to the NEXT pass (separate array:
+    touched_next[v1] = round;                                // this pass's dirty tests read `touched`)
     atomicAdd(&counters[0], 1);
     atomicAdd(&counters[2], removed);
   }
@@ -394,7 +433,7 @@ inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 struct Layout {
   size_t off_Q, off_F2, off_voff, off_cursor, off_vfaces, off_flag, off_edges, off_iota, off_cost, off_cost2,
-      off_idx, off_idx2, off_claim, off_vver, off_rej, off_counters, off_nsel, off_cub, cub_bytes, total;
+      off_idx, off_idx2, off_claim, off_vver, off_touched, off_touched2, off_rej, off_counters, off_nsel, off_cub, cub_bytes, total;
   uint32_t n_slots;
 };
 
@@ -414,8 +453,10 @@ Layout make_layout(int64_t nv, int64_t nf) {
   L.off_cost2 = take((size_t)nf * 3 * sizeof(uint32_t));
   L.off_idx = take((size_t)nf * 3 * sizeof(uint32_t));
   L.off_idx2 = take((size_t)nf * 3 * sizeof(uint32_t));
-  L.off_claim = take((size_t)nv * sizeof(uint32_t));
+  L.off_claim = take((size_t)nv * sizeof(unsigned long long));
   L.off_vver = take((size_t)nv * sizeof(uint32_t));
+  L.off_touched = take((size_t)nv * sizeof(uint32_t));
+  L.off_touched2 = take((size_t)nv * sizeof(uint32_t));
   L.n_slots = (uint32_t)(nv * 2 + 1024);
   L.off_rej = take((size_t)L.n_slots * sizeof(Reject));
   L.off_counters = take(64);
@@ -480,13 +521,16 @@ int dsu_mesh_decimate_parallel(double* verts, int64_t n_verts, int32_t* faces, i
   uint32_t* cost2 = (uint32_t*)(w + L.off_cost2);
   uint32_t* idx = (uint32_t*)(w + L.off_idx);
   uint32_t* idx2 = (uint32_t*)(w + L.off_idx2);
-  uint32_t* claim = (uint32_t*)(w + L.off_claim);
+  unsigned long long* claim = (unsigned long long*)(w + L.off_claim);
   uint32_t* vver = (uint32_t*)(w + L.off_vver);
+  uint32_t* touched = (uint32_t*)(w + L.off_touched);
+  uint32_t* touched2 = (uint32_t*)(w + L.off_touched2);
   Reject* rej = (Reject*)(w + L.off_rej);
   int32_t* counters = (int32_t*)(w + L.off_counters);
   int32_t* nsel = (int32_t*)(w + L.off_nsel);
   void* cub = (void*)(w + L.off_cub);
   const int T = 256;
+  const int PASSES = 4;                     // selection passes per round (see is_dirty)
   const int link_test = !(flags & 1);
 
   int32_t* F = faces;                       // live triangles, compacted in place (through F2)
@@ -522,6 +566,8 @@ int dsu_mesh_decimate_parallel(double* verts, int64_t n_verts, int32_t* faces, i
   int rc = compact_faces();
   if (rc) return rc;
   DSU_HIP_TRY(hipMemsetAsync(vver, 0, (size_t)n_verts * sizeof(uint32_t), s));
+  DSU_HIP_TRY(hipMemsetAsync(touched, 0xff, (size_t)n_verts * sizeof(uint32_t), s));
+  DSU_HIP_TRY(hipMemsetAsync(touched2, 0xff, (size_t)n_verts * sizeof(uint32_t), s));
   DSU_HIP_TRY(hipMemsetAsync(rej, 0xff, (size_t)L.n_slots * sizeof(Reject), s));
   iota_kernel<<<dsu_capped_blocks(3 * nf, T), T, 0, s>>>(iota, 3 * nf);
   if ((rc = build_csr())) return rc;
@@ -551,17 +597,26 @@ int dsu_mesh_decimate_parallel(double* verts, int64_t n_verts, int32_t* faces, i
       return DSU_ELAUNCH;
     int64_t ncand = budget < ne / 2 ? budget : ne / 2;
     if (ncand < 1) ncand = 1;
-    DSU_HIP_TRY(hipMemsetAsync(claim, 0xff, (size_t)n_verts * sizeof(uint32_t), s));
     DSU_HIP_TRY(hipMemsetAsync(counters, 0, 64, s));
-    claim_kernel<<<dsu_capped_blocks(ncand, T), T, 0, s>>>(m, edges, idx2, cost2, ncand, claim);
     DSU_HIP_TRY(hipMemsetAsync(flag, 1, (size_t)nf, s));
-    collapse_kernel<<<dsu_capped_blocks(ncand, T), T, 0, s>>>(m, edges, idx2, cost2, ncand, claim, link_test, flag, rej,
-                                                              L.n_slots, vver, counters);
-    DSU_CHECK_LAUNCH();
+    for (int pass = 0; pass < PASSES; ++pass) {
+      const uint32_t seed = (uint32_t)rounds * 16u + (uint32_t)pass;
+      DSU_HIP_TRY(hipMemsetAsync(claim, 0xff, (size_t)n_verts * sizeof(unsigned long long), s));
+      claim_kernel<<<dsu_capped_blocks(ncand, T), T, 0, s>>>(m, edges, idx2, cost2, ncand, (uint32_t)rounds, seed,
+                                                             touched, claim);
+      collapse_kernel<<<dsu_capped_blocks(ncand, T), T, 0, s>>>(m, edges, idx2, cost2, ncand, (uint32_t)rounds, seed,
+                                                                claim, link_test, flag, rej, L.n_slots, vver,
+                                                                touched2, touched, counters);
+      DSU_CHECK_LAUNCH();
+      DSU_HIP_TRY(hipMemcpyAsync(touched, touched2, (size_t)n_verts * sizeof(uint32_t), hipMemcpyDeviceToDevice, s));
+    }
     int32_t hc[3];
     DSU_HIP_TRY(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, s));
     DSU_HIP_TRY(hipStreamSynchronize(s));
     ++rounds;
+    if (getenv("DSU_DECIMATE_DEBUG"))
+      fprintf(stderr, "[decimate] round %d nf %lld ne %lld ncand %lld applied %d rejected %d removed %d\n", rounds,
+              (long long)nf, (long long)ne, (long long)ncand, hc[0], hc[1], hc[2]);
     applied_total += hc[0];
     rejected_total += hc[1];
     if (hc[0] == 0) {
@@ -571,7 +626,11 @@ int dsu_mesh_decimate_parallel(double* verts, int64_t n_verts, int32_t* faces, i
       continue;
     }
     stall = 0;
+    const int64_t before = nf;
     if ((rc = compact_faces())) return rc;
+    // a round that removes under 0.5 % of a mesh already within 4x of the target (candidates
+    // clustered in one place): the serial queue is the faster way from here
+    if ((before - nf) * 200 < before && nf <= 4 * stop_faces) break;
     if (nf == 0) break;
     if ((rc = build_csr())) return rc;
   }

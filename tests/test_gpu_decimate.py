@@ -2,7 +2,7 @@
 tensors) held to the contracts the serial host queue is held to in tests/test_export_host.py: exact
 face count, closed 2-manifold of the same genus, orientation, vertices on the input surface, faces
 spent where the surface bends, boundary outline kept, deterministic — plus an export-scale mesh
-(marching cubes of a 256^3 volume, ~0.5 M triangles) with the time of the call."""
+(marching cubes of a 384^3 volume, ~0.8 M triangles) with the time of the call."""
 import time
 
 import numpy as np
@@ -23,7 +23,7 @@ def test_parallel_remesh_sphere_contract(dev):
     v, f = _uv_sphere(320, 240)                                       # 153 k triangles
     v2, f2 = M.remesh(*_dev(v, f, dev), 3000)
     st = dict(M.last_remesh_stats)
-    assert st["input_faces"] == len(f) and 3000 <= st["device_faces"] <= 3750 and st["rounds"] >= 5
+    assert st["input_faces"] == len(f) and 3000 <= st["device_faces"] <= 12000 and st["rounds"] >= 5
     assert f2.shape == (3000, 3) and f2.dtype == np.int64 and v2.dtype == np.float64
     assert f2.min() == 0 and f2.max() == v2.shape[0] - 1 and len(np.unique(f2)) == v2.shape[0]
     u, c = _edge_counts(f2)
@@ -63,15 +63,15 @@ def test_parallel_remesh_spends_faces_where_the_surface_bends(dev):
 
 
 def test_parallel_remesh_at_export_scale(dev):
-    """A marching-cubes mesh of the size class the export produces (a blobby shape on a 256^3
+    """A marching-cubes mesh of the size class the export produces (a blobby shape on a 384^3
     lattice), down to the reference's face_count = 50 000."""
-    n = 256
+    n = 384
     c = torch.linspace(-1, 1, n, device=dev)
     x, y, z = torch.meshgrid(c, c, c, indexing="ij")
-    vol = 0.55 - torch.sqrt((x / 0.8) ** 2 + (y / 0.6) ** 2 + (z / 0.7) ** 2) \
+    vol = 0.9 - torch.sqrt((x / 0.95) ** 2 + (y / 0.8) ** 2 + (z / 0.9) ** 2) \
         + 0.08 * torch.sin(9 * x) * torch.sin(7 * y + 1) * torch.sin(8 * z + 2)
     v, f = M.marching_cubes(vol.double(), 0.0)
-    assert f.shape[0] > 300000
+    assert f.shape[0] > 600000
     torch.cuda.synchronize()
     t0 = time.time()
     v2, f2 = M.remesh(v, f, 50000)
