@@ -353,6 +353,10 @@ struct dsu_nsr_driver {
   bool pf_valid[3] = {false, false, false};
   int64_t pf_step[3] = {-1, -1, -1};
   int32_t pf_rays[3] = {0, 0, 0};
+  // what else the marched set depends on (a set issued for other settings is not reused)
+  int32_t pf_randomized[3] = {0, 0, 0}, pf_occ_res[3] = {0, 0, 0};
+  const void* pf_occ[3] = {nullptr, nullptr, nullptr};
+  int64_t last_step = INT64_MIN;              // the sample-loss accumulators are pre-zeroed for last_step + 1
   bool initialised = false;                   // effective weights / inv_s / zeroed accumulators
   float aabb[6];
   int32_t rowcap;
@@ -561,6 +565,19 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
   const int p = (int)(a->step % 3);
   Prefetch& f = L.pf[p];
   float* terms = L.terms + 8 * (int)(a->step & 1);   // two sets: the optimizer kernel pre-zeroes the next one
+  // any error return below leaves no "valid" prefetched set behind (its `ready` event may never
+  // have been recorded: the next call would read stale counts)
+  struct Guard {
+    dsu_nsr_driver* d;
+    bool ok = false;
+    ~Guard() {
+      if (!ok) for (int k = 0; k < 3; ++k) d->pf_valid[k] = false;
+    }
+  } guard{d};
+  if (d->initialised && a->step != d->last_step + 1)
+    // the previous step pre-zeroed the accumulators of `last_step + 1`, not of this step (the
+    // caller moved global_step: resume, tests): zero this step's set here
+    DSU_HIP(hipMemsetAsync(terms + 4, 0, 3 * sizeof(float), s));
   if (!d->initialised) {
     // zeroed accumulators and optimizer moments
     DSU_HIP(hipMemsetAsync(L.g_geo, 0, (N_GEO + N_TEX + 1) * sizeof(float), s));
@@ -575,7 +592,9 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
   // ---- this step's samples: prefetched by the previous call, or produced now
   const bool injected = a->inj_index || a->inj_x || a->inj_y || a->inj_jitter || a->inj_pts_random ||
                         a->inj_perturb;
-  if (d->pf_valid[p] && d->pf_step[p] == a->step && d->pf_rays[p] == a->n_rays && !injected) {
+  if (d->pf_valid[p] && d->pf_step[p] == a->step && d->pf_rays[p] == a->n_rays && !injected &&
+      d->pf_randomized[p] == a->randomized && d->pf_occ[p] == a->occ_binary &&
+      d->pf_occ_res[p] == a->occ_res) {
     // the host waits: no device-side cross-queue barrier on the main stream is needed afterwards
     DSU_HIP(hipEventSynchronize(d->ready[p]));
   } else {
@@ -620,13 +639,16 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
     na.inj_index = na.inj_x = na.inj_y = nullptr;
     na.inj_jitter = na.inj_pts_random = na.inj_perturb = nullptr;
     DSU_TRY(enqueue_march(d, q, a->step + 1, next_rays, na, false, d->side));
+    d->pf_step[q] = a->step + 1;
+    d->pf_rays[q] = next_rays;
+    d->pf_randomized[q] = a->randomized;
+    d->pf_occ[q] = a->occ_binary;
+    d->pf_occ_res[q] = a->occ_res;
     if (d->pack_gate == 0) {
       DSU_TRY(enqueue_pack(d, q, next_rays, na, false, d->side));
       DSU_HIP(hipEventRecord(d->ready[q], d->side));
+      d->pf_valid[q] = true;                  // only once `ready[q]` is on the side stream
     }
-    d->pf_valid[q] = true;
-    d->pf_step[q] = a->step + 1;
-    d->pf_rays[q] = next_rays;
   }
 
   const float* pts = c.sort_bits ? f.sorted : f.points;
@@ -651,6 +673,7 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
     DSU_HIP(hipStreamWaitEvent(d->side, d->fwd_done, 0));
     DSU_TRY(enqueue_pack(d, q, next_rays, na, false, d->side));
     DSU_HIP(hipEventRecord(d->ready[q], d->side));
+    d->pf_valid[q] = true;
   }
   if (n_s > 0) {
     dsu_tex_mlp tex{c.tex[0], c.tex[1], c.tex[2], c.tex[3], c.tex[4], c.tex[5]};
@@ -697,6 +720,7 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
     DSU_HIP(hipStreamWaitEvent(d->side, d->gate, 0));          // recorded inside the call above
     DSU_TRY(enqueue_pack(d, q, next_rays, na, false, d->side));
     DSU_HIP(hipEventRecord(d->ready[q], d->side));
+    d->pf_valid[q] = true;
   }
   // ---- optimizer: the hash table (active levels; level / decay bookkeeping is the caller's) ...
   if (a->table_p)
@@ -705,6 +729,8 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
                             a->table_eps, a->table_wd, a->table_bc1, a->table_bc2_sqrt, s));
   // ... and the small tensors
   DSU_TRY(launch_small_update(d, a, 1, s));
+  d->last_step = a->step;
+  guard.ok = true;
   return DSU_OK;
 }
 

@@ -720,7 +720,9 @@ class OrthoNeuSSystem:
             self.train_num_rays = int(a.out_next_n_rays)
         topt.commit_step(lr_tab)               # the update itself was launched by the driver
         self.global_step += 1
-        t = drv.terms2[(self.global_step - 1) & 1]
+        # a copy: the driver's two term sets are reused two steps later (and three of the eight
+        # floats are zeroed one step later), a result kept across steps must not change under it
+        t = drv.terms2[(self.global_step - 1) & 1].clone()
         L = self.config.loss
         terms = {"rgb_mse": t[0]}
         if L.lambda_rgb_l1:

@@ -148,3 +148,36 @@ def test_native_step_timing_counters(dev):
     assert 0.05 < t["sdf_fd_bwd"][1] / 5 < 5.0                 # ms per launch
     assert t["sdf_fd_bwd"][2] > 5 * 50000 * (7 * 4 * 32 + 84) * 0.5      # algorithmic bytes
     S.native_timing["totals"].clear()
+
+
+def test_native_step_results_are_snapshots_and_survive_a_step_jump(dev):
+    """(a) What training_step returns stays what it was: the driver's two sets of loss terms are
+    reused two steps later and partly zeroed one step later, the result is a copy.  (b) When the
+    caller moves global_step (resume, tests) the sample-loss accumulators of the new step were not
+    pre-zeroed by its predecessor: the driver zeroes them itself — eikonal / sparsity / smoothness
+    equal the Python-sequenced step's, not twice them."""
+    a, ds = _system(dev, 9, "fused")
+    b, _ = _system(dev, 9, "native")
+    b.model.load_state_dict(a.model.state_dict())
+    kept = []
+    for s in range(4):
+        inj = _inject(ds, int(a.train_num_rays), 300 + s, dev)
+        torch.manual_seed(2000 + s)
+        a.training_step_fused(dict(inj))
+        torch.manual_seed(2000 + s)
+        r = b.training_step_native(dict(inj))
+        kept.append((r, {k: float(r[k]) for k in ("rgb_mse", "eikonal", "sparsity", "loss")}))
+    for r, snap in kept:                                   # read AFTER the later steps ran
+        for k, v in snap.items():
+            assert float(r[k]) == v, k
+    # jump by an even number of steps: same parity of the term set, no pre-zeroing happened
+    a.global_step += 4
+    b.global_step += 4
+    inj = _inject(ds, int(a.train_num_rays), 777, dev)
+    torch.manual_seed(3000)
+    ra = a.training_step_fused(dict(inj))
+    torch.manual_seed(3000)
+    rb = b.training_step_native(dict(inj))
+    for k in ("eikonal", "sparsity", "normal_smooth", "rgb_mse"):
+        va, vb = float(ra[k]), float(rb[k])
+        assert abs(va - vb) <= 2e-3 * max(abs(va), 1e-3), (k, va, vb)
