@@ -244,16 +244,22 @@ def run(args):
         torch.distributed.destroy_process_group()
 
 
+def _sync(dev):
+    """device-wide synchronise (a no-op for the CPU tensors of the gloo tests)."""
+    if torch.device(dev).type == "cuda":
+        torch.cuda.synchronize(dev)
+
+
 def _timed_loop(args, ddist, dev, timer, body):
     for w in range(args.warmup):
         body(w, False)
-    ddist.barrier(); torch.cuda.synchronize()
+    ddist.barrier(); _sync(dev)
     timer.enabled = True
     t0 = time.time()
     last = None
     for s in range(args.steps):
         last = body(s, True)
-    torch.cuda.synchronize(); ddist.barrier()
+    _sync(dev); ddist.barrier()
     elapsed = ddist.max_over_ranks(time.time() - t0, dev)
     timer.enabled = False
     return elapsed, last
@@ -279,13 +285,16 @@ def _roofline(timer, extra=None):
     return top
 
 
-def bench_drawing(args, ddist, rank, world, dev, timer):
+def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
+    """`pipe`: a DrawingPipeline-like object (tests/test_dist_gloo.py drives this function over gloo
+    with a stub); None builds the real one."""
     from drawingspinup_amd.drawing import (DrawingPipeline, synthetic_drawing, synthetic_edges,
                                            synthetic_frames)
-    pipe = DrawingPipeline(dev, seed=0, mv_steps=args.mv_steps, nsr_steps=args.nsr_steps,
-                           n_frames=args.frames)
+    if pipe is None:
+        pipe = DrawingPipeline(dev, seed=0, mv_steps=args.mv_steps, nsr_steps=args.nsr_steps,
+                               n_frames=args.frames)
     bcast_bytes = sum(ddist.broadcast_module(m, 0) for m in pipe.shared_modules())
-    stage_t = {"contour": 0.0, "mv": 0.0, "nsr": 0.0, "style": 0.0}
+    stage_t = {"contour": 0.0, "mv": 0.0, "nsr": 0.0, "style": 0.0, "gather": 0.0}
     sub_t = {"nsr_fit": 0.0, "nsr_export": 0.0, "nsr_post": 0.0}
     pipe.time_substages = True               # one extra synchronize between fit and export
 
@@ -296,31 +305,40 @@ def bench_drawing(args, ddist, rank, world, dev, timer):
         return (synthetic_drawing(seed, device=dev), fr, synthetic_edges(fr))
     inputs = {(False, w): make_inputs(1000 + rank * 100 + w) for w in range(args.warmup)}
     inputs.update({(True, s): make_inputs(rank * 100 + s) for s in range(args.steps)})
-    torch.cuda.synchronize()
+    _sync(dev)
+    gathered = {}
 
     def one_drawing(s, timed):
         seed = (rank * 100 + s) if timed else (1000 + rank * 100 + s)
         drawing, frames_in, edges_in = inputs[(timed, s)]
-        torch.cuda.synchronize(); t0 = time.time()
+        _sync(dev); t0 = time.time()
         cleaned = pipe.remove_contour(drawing)
-        torch.cuda.synchronize(); t1 = time.time()
+        _sync(dev); t1 = time.time()
         normals, colors = pipe.multiview(cleaned, 123456 + seed)
-        torch.cuda.synchronize(); t2 = time.time()
+        _sync(dev); t2 = time.time()
         system, inside = pipe.reconstruct(normals, colors, cleaned, 123456 + seed)
-        torch.cuda.synchronize(); t3 = time.time()
+        _sync(dev); t3 = time.time()
         frames = pipe.stylize(frames_in, edges_in)
-        torch.cuda.synchronize(); t4 = time.time()
+        _sync(dev); t4 = time.time()
+        # the per-rank gather of OUTPUTS to rank 0 (north_star): the twelve predicted
+        # views (12x3x256^2) and the stylised frames (n x 4 x 512^2 uint8), inside the clock.  The
+        # mesh stays with its rank (the reference writes it to disk per uid).
+        views = ddist.gather_tensor(torch.cat([normals, colors]).to(torch.float16))
+        out_frames = ddist.gather_tensor(frames)
+        _sync(dev); t5 = time.time()
         if timed:
-            for k, v in zip(stage_t, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+            for k, v in zip(stage_t, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4)):
                 stage_t[k] += v
             for k in sub_t:
                 sub_t[k] += pipe.substage_seconds.get(k, 0.0)
+            if views is not None:
+                gathered["views"], gathered["frames"] = views, out_frames
         return colors, inside.sum(), frames
 
     elapsed, last = _timed_loop(args, ddist, dev, timer, one_drawing)
-    ddist.gather_tensor(last[1].reshape(1).float())          # per-rank gather of small outputs only
     if rank != 0:
         return None
+    assert len(gathered["views"]) == world and len(gathered["frames"]) == world
     per = {k: v / args.steps for k, v in stage_t.items()}
     per.update({k: v / args.steps for k, v in sub_t.items()})
     stages = {
@@ -354,7 +372,9 @@ def bench_drawing(args, ddist, rank, world, dev, timer):
                                "on the edge-overlaid stage-1 output); NOT timed: Blender, PNG / OBJ file "
                                "I/O" % (args.mv_steps, args.nsr_steps, args.frames),
                    "drawings_per_step": world, "parallelism": f"replica-per-drawing x{world}",
-                   "stage_seconds_rank0": per, "weights_broadcast_bytes": bcast_bytes},
+                   "stage_seconds_rank0": per, "weights_broadcast_bytes": bcast_bytes,
+                   "gathered_bytes_per_step": sum(t.numel() * t.element_size() for k in gathered
+                                                  for t in gathered[k])},
         "roofline": roof,
     }
     if not args.no_cpu_baseline and world == 1:
@@ -405,14 +425,16 @@ def bench_nsr50k(args, ddist, rank, world, dev, timer):
             "roofline": _roofline(timer)}
 
 
-def bench_frames(args, ddist, rank, world, dev, timer):
+def bench_frames(args, ddist, rank, world, dev, timer, pipe=None, size=512):
     """BASELINE configs[3]: 24 frames 512x512 through stage 1 + stage 2, frame f on rank f mod N,
-    stage 2 on the rank of its stage-1 frame (no exchange), outputs gathered to rank 0."""
+    stage 2 on the rank of its stage-1 frame (no exchange), outputs gathered to rank 0.
+    `pipe` / `size`: stub pipeline and frame size of the gloo test."""
     from drawingspinup_amd.drawing import DrawingPipeline, synthetic_edges, synthetic_frames
-    pipe = DrawingPipeline(dev, seed=0, n_frames=args.frames, with_mv=False, with_contour=False)
+    if pipe is None:
+        pipe = DrawingPipeline(dev, seed=0, n_frames=args.frames, with_mv=False, with_contour=False)
     for m in (pipe.gen1, pipe.gen2):
         ddist.broadcast_module(m, 0)
-    frames = synthetic_frames(0, args.frames, device=dev)
+    frames = synthetic_frames(0, args.frames, size, device=dev)
     edges = synthetic_edges(frames)
     mine = ddist.shard(list(range(args.frames)), rank, world)
     per_rank = (args.frames + world - 1) // world
@@ -423,9 +445,11 @@ def bench_frames(args, ddist, rank, world, dev, timer):
             out[:len(mine)] = pipe.stylize(frames[mine], edges[mine])
         return ddist.gather_tensor(out)                 # equal shapes: padded to ceil(frames / N)
 
-    elapsed, _ = _timed_loop(args, ddist, dev, timer, step)
+    elapsed, parts = _timed_loop(args, ddist, dev, timer, step)
     if rank != 0:
         return None
+    # rank 0 puts the shards back in frame order (frame f = row f // N of rank f % N's part)
+    ordered = torch.stack([parts[f % world][f // world] for f in range(args.frames)])
     fps = args.frames * args.steps / elapsed
     return {"metric": "stylised frames/sec (512x512, stage 1 + stage 2)", "value": fps,
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -434,7 +458,8 @@ def bench_frames(args, ddist, rank, world, dev, timer):
             "config": {"workload": "%d frames 512x512 per step through GeneratorJ_RIC + GeneratorJ, "
                                    "frames sharded round-robin over the ranks, outputs gathered to "
                                    "rank 0" % args.frames,
-                       "frames_per_rank": len(mine), "parallelism": f"frame-shard x{world}"},
+                       "frames_per_rank": len(mine), "parallelism": f"frame-shard x{world}",
+                       "gathered_frames_checksum": int(ordered.to(torch.int64).sum())},
             "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F32_MFMA_PEAK_TF,
                          "achieved": 0.84 * fps, "frac": 0.84 * fps / F32_MFMA_PEAK_TF,
                          "traffic": None, "kernels": timer.summary()[:3]}}

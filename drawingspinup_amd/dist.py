@@ -23,6 +23,11 @@ def init(backend=None):
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
+        # the ranks of one node share its host cores: the host steps of a drawing (TELEA tail, the
+        # serial finish of the decimation, sparse solves, torch's intra-op pools) get an equal
+        # share instead of N pools of `cores` threads each
+        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(max(1, cores // world))
     return rank, world, local
 
 

@@ -54,3 +54,105 @@ def test_broadcast_shard_gather_world2():
     assert m0 == [0, 2, 4, 6, 8] and m1 == [1, 3, 5, 7, 9]
     assert g0 == [20.0, 25.0] and g1 is None          # gathered on rank 0 only
     assert t0 == 2.0 and t1 == 2.0                    # max over ranks
+
+
+# ------------------------------------------------------------------------------------------------
+# bench.py's N > 1 paths themselves (the timed loop, the frame shard / pad / gather / re-order of
+# `--config frames`, the output gather of `--config drawing`) over gloo, with a stub in place of
+# the GPU pipeline: the 8-GPU runs are the driver's, this is what can be executed here.
+# ------------------------------------------------------------------------------------------------
+class _StubTimer:
+    enabled = False
+
+    def summary(self):
+        return []
+
+
+class _StubPipe:
+    """DrawingPipeline's interface on CPU tensors; every output is a fixed function of its input
+    and of the (broadcast) weights, so rank 0 can check what it gathered."""
+
+    def __init__(self, rank):
+        torch.manual_seed(500 + rank)                                 # different until broadcast
+        self.gen1 = torch.nn.Conv2d(6, 3, 1)
+        self.gen2 = torch.nn.Conv2d(6, 3, 1)
+        self.time_substages, self.substage_seconds = False, {}
+
+    def shared_modules(self):
+        return [self.gen1, self.gen2]
+
+    def remove_contour(self, d):
+        return d
+
+    def multiview(self, drawing, seed):
+        base = torch.nn.functional.interpolate(drawing[None, :3], size=(16, 16))[0]
+        n = torch.stack([base * (0.1 * (v + 1)) for v in range(6)])
+        return n, 1.0 - n
+
+    def reconstruct(self, normals, colors, drawing, seed):
+        self.substage_seconds = {"nsr_fit": 0.0, "nsr_export": 0.0, "nsr_post": 0.0}
+        return None, (colors > 0.5)
+
+    @torch.no_grad()
+    def stylize(self, frames, edges=None):
+        s1 = torch.tanh(self.gen1(frames))
+        q = ((s1.clamp(-1, 1) + 1) / 2 * 255).to(torch.uint8)
+        if edges is not None:
+            q = torch.where((edges < 255)[:, None], torch.zeros_like(q), q)
+        s2 = torch.tanh(self.gen2(torch.cat([q.float() / 255 * 2 - 1, frames[:, 3:]], 1)))
+        rgb = ((s2.clamp(-1, 1) + 1) / 2 * 255).to(torch.uint8)
+        return torch.cat([rgb, (frames[:, 3:4] * 255).to(torch.uint8)], 1)
+
+
+def _bench_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import bench
+    from drawingspinup_amd import dist as ddist
+    from drawingspinup_amd.drawing import synthetic_edges, synthetic_frames
+    r, w, _ = ddist.init(backend="gloo")
+    threads = torch.get_num_threads()
+    dev = torch.device("cpu")
+    pipe = _StubPipe(rank)
+    args = bench.parse(["--gpus", str(world), "--config", "frames", "--frames", "5", "--steps", "2",
+                        "--warmup", "1"])
+    out_f = bench.bench_frames(args, ddist, r, w, dev, _StubTimer(), pipe=pipe, size=32)
+    want = None
+    if r == 0:                                # what one process computes for all five frames
+        fr = synthetic_frames(0, 5, 32, device=dev)
+        want = int(pipe.stylize(fr, synthetic_edges(fr)).to(torch.int64).sum())
+    args = bench.parse(["--gpus", str(world), "--config", "drawing", "--frames", "3", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"])
+    out_d = bench.bench_drawing(args, ddist, r, w, dev, _StubTimer(), pipe=pipe)
+    ddist.barrier()
+    q.put((rank, threads, out_f, want, out_d))
+    torch.distributed.destroy_process_group()
+
+
+def test_bench_frames_and_drawing_paths_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, th0, f0, want, d0), (_, th1, f1, _, d1) = res
+    cores = len(os.sched_getaffinity(0))
+    assert th0 == th1 == max(1, cores // 2)                # the ranks split the host cores
+    assert f1 is None and d1 is None                       # only rank 0 reports
+    # frames: 5 frames over 2 ranks = 3 + 2 (padded to 3), gathered and put back in frame order
+    assert f0["n_gpus"] == 2 and f0["scaling"] == "strong" and f0["steps"] == 2
+    assert f0["config"]["frames_per_rank"] == 3
+    assert f0["config"]["gathered_frames_checksum"] == want
+    assert abs(f0["value"] - 5 * 2 / (f0["ms_per_step"] * 2e-3)) < 1e-6 * f0["value"]
+    # drawing: one drawing per rank per step, whole-job value, the views and frames of BOTH ranks
+    assert d0["n_gpus"] == 2 and d0["scaling"] == "weak" and d0["config"]["drawings_per_step"] == 2
+    assert abs(d0["value"] - 2 * 2 / (d0["ms_per_step"] * 2e-3)) < 1e-6 * d0["value"]
+    per_rank = 12 * 3 * 16 * 16 * 2 + 3 * 4 * 512 * 512
+    assert d0["config"]["gathered_bytes_per_step"] == 2 * per_rank
+    assert d0["config"]["weights_broadcast_bytes"] > 0 and "gather" in d0["config"]["stage_seconds_rank0"]
