@@ -228,8 +228,9 @@ class FFCResNetGenerator(nn.Module):
 
     def forward(self, x):
         # on the device, in eval mode: the library's own convolution kernel for every layer
-        # (contour/ffc_hip.py); DSU_CONTOUR=torch keeps the torch operators (A/B, training)
-        if x.is_cuda and not self.training and os.environ.get("DSU_CONTOUR", "hip") != "torch":
+        # (contour/ffc_hip.py).  The torch operators below are the host form BASELINE config 1 names
+        # ("predict.py on CPU PyTorch") and the training-mode graph.
+        if x.is_cuda and not self.training:
             from . import ffc_hip
             return ffc_hip.generator_forward(self, x)
         return self.model(x)

@@ -15,4 +15,14 @@ const char* dsu_strerror(int code) {
 
 int dsu_abi_version(void) { return 1; }
 
+// 1 in a variant build with the A/B environment switches compiled in (-DDSU_AB_SWITCHES), 0 in the
+// product library
+int dsu_ab_switches(void) {
+#ifdef DSU_AB_SWITCHES
+  return 1;
+#else
+  return 0;
+#endif
+}
+
 }  // extern "C"

@@ -13,6 +13,26 @@
     if (e__ != hipSuccess) return DSU_ELAUNCH;               \
   } while (0)
 
+// A/B switches (alternative kernels, placement experiments, debug output) exist only in variant
+// builds: `python -m drawingspinup_amd.build --variant ab -DDSU_AB_SWITCHES` compiles the
+// environment look-ups in, the product library takes the defaults as constants (tools/ drives
+// the variants through DSU_HIP_LIB).
+#ifdef DSU_AB_SWITCHES
+#include <stdlib.h>
+#include <string.h>
+static inline int dsu_ab_int(const char* name, int dflt) {
+  const char* e = getenv(name);
+  return e ? atoi(e) : dflt;
+}
+static inline bool dsu_ab_is(const char* name, const char* value) {
+  const char* e = getenv(name);
+  return e && strcmp(e, value) == 0;
+}
+#else
+static inline int dsu_ab_int(const char*, int dflt) { return dflt; }
+static inline bool dsu_ab_is(const char*, const char*) { return false; }
+#endif
+
 static inline int dsu_blocks_for(int64_t n, int threads) {
   return (int)((n + threads - 1) / threads);
 }

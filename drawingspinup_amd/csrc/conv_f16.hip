@@ -448,10 +448,7 @@ int conv_out_dim(int in, int k, int stride, int pad) { return (in + 2 * pad - k)
 // 64 x 64 workgroup tiles when the 128 x 128 tiling would leave the chip under-filled
 // (DSU_CONV_SMALL_MAX_TILES: A/B switch, 0 = always 128 x 128)
 bool small_tiles(int64_t npix, int64_t O) {
-  static const int64_t max_big = [] {
-    const char* e = getenv("DSU_CONV_SMALL_MAX_TILES");
-    return e ? (int64_t)atoll(e) : (int64_t)512;
-  }();
+  static const int64_t max_big = dsu_ab_int("DSU_CONV_SMALL_MAX_TILES", 512);
   const int64_t big = ((npix + TN_BIG - 1) / TN_BIG) * ((O + TM_BIG - 1) / TM_BIG);
   return big < max_big;
 }
@@ -480,10 +477,7 @@ int32_t dsu_conv2d_nhwc_f16_split_k(int32_t B, int32_t H, int32_t W, int32_t C, 
   const int chunks = (k * k * C + BK - 1) / BK;
   const int64_t fill = tile == 64 ? 512 : 256;       // 64-tiles: four workgroups fit a CU
   if (tiles >= fill || chunks < 8) return 1;         // the output tiles already fill the chip
-  static const int64_t target_pct = [] {             // DSU_CONV_SPLIT_TARGET: A/B switch (percent of fill)
-    const char* e = getenv("DSU_CONV_SPLIT_TARGET");
-    return e ? (int64_t)atoll(e) : (int64_t)50;
-  }();
+  static const int64_t target_pct = dsu_ab_int("DSU_CONV_SPLIT_TARGET", 50);   // A/B: percent of fill
   if (target_pct <= 0) return 1;
   // (measured on the UNet forward: 12.2 ms without split-K, 11.1 / 10.8 / 10.6 ms aiming at 2 x / 1 x /
   // 0.5 x fill — the f32 partials of a split cost a write and a read of the whole output each)

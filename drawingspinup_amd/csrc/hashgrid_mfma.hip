@@ -1358,17 +1358,13 @@ extern "C" int64_t dsu_sdf_fd_bwd_workspace_bytes_valu(const dsu_hashgrid_cfg*, 
 // Default (measured round 2, N = 262 144 ray-ordered samples at the training step size, 4/5/6 levels):
 //   fused 0.60 / 0.72 / 0.85 ms, two kernels 0.54 / 0.61 / 0.71 ms -> two kernels.
 // DSU_BWD_SPLIT=0 selects the fused kernel.
-static bool bwd_split() {          // read per call: the tests run both forms in one process
-  const char* e = getenv("DSU_BWD_SPLIT");
-  return !(e && atoi(e) == 0);
+static bool bwd_split() {          // read per call: the variant tests run both forms in one process
+  return dsu_ab_int("DSU_BWD_SPLIT", 1) != 0;
 }
 
 static bool use_valu(bool forward) {
   static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("DSU_SDF_IMPL");
-    v = !e ? 0 : (strcmp(e, "valu") == 0 ? 1 : (strcmp(e, "mfma") == 0 ? 2 : 0));
-  }
+  if (v < 0) v = dsu_ab_is("DSU_SDF_IMPL", "valu") ? 1 : (dsu_ab_is("DSU_SDF_IMPL", "mfma") ? 2 : 0);
   return v == 1 || (v == 0 && forward);
 }
 
@@ -1500,7 +1496,7 @@ int dsu_sdf_fd_bwd_sorted_mid(const dsu_hashgrid_cfg* cfg, const void* table_f16
   hipStream_t s = (hipStream_t)stream;
   const float eps2 = (float)((double)eps * (double)eps);
   const int blocks = dsu_capped_blocks(n, 256, BWD_MFMA_MAX_BLOCKS);
-  const int ablate = getenv("DSU_BWD_ABLATE") ? atoi(getenv("DSU_BWD_ABLATE")) : 0;
+  const int ablate = dsu_ab_int("DSU_BWD_ABLATE", 0);
   if (bwd_split()) {
     const size_t shm1 = (size_t)BWD_CACHE_OFF * sizeof(float);         // no gradient cache
     const size_t shm2 = (size_t)SC_LDS_F * sizeof(float);
@@ -1524,15 +1520,9 @@ int dsu_sdf_fd_bwd_sorted_mid(const dsu_hashgrid_cfg* cfg, const void* table_f16
       // same-cell run merge (DPP segmented sums over 16 lanes) only where neighbouring lanes of the
       // Morton order can share a cell: DSU_SC_MERGE_LEVELS (default: all levels)
       static int merge_lv = -1;
-      if (merge_lv < 0) {
-        const char* e = getenv("DSU_SC_MERGE_LEVELS");
-        merge_lv = e ? atoi(e) : 64;
-      }
+      if (merge_lv < 0) merge_lv = dsu_ab_int("DSU_SC_MERGE_LEVELS", 64);
       static int centre_acc = -1;      // DSU_SC_CENTRE=0: every evaluation emitted on its own (A/B)
-      if (centre_acc < 0) {
-        const char* e = getenv("DSU_SC_CENTRE");
-        centre_acc = e ? atoi(e) != 0 : 1;
-      }
+      if (centre_acc < 0) centre_acc = dsu_ab_int("DSU_SC_CENTRE", 1) != 0;
       k2<<<dim3(sblocks), dim3(SC_THREADS), shm2, s>>>(m, pts, n, radius, eps, active_levels,
                                                       dinbuf, grad_table, merge_lv, centre_acc);
       reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 63) / 64), dim3(1024), 0, s>>>(

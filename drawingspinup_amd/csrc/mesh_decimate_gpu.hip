@@ -614,7 +614,7 @@ int dsu_mesh_decimate_parallel(double* verts, int64_t n_verts, int32_t* faces, i
     DSU_HIP_TRY(hipMemcpyAsync(hc, counters, sizeof(hc), hipMemcpyDeviceToHost, s));
     DSU_HIP_TRY(hipStreamSynchronize(s));
     ++rounds;
-    if (getenv("DSU_DECIMATE_DEBUG"))
+    if (dsu_ab_int("DSU_DECIMATE_DEBUG", 0))
       fprintf(stderr, "[decimate] round %d nf %lld ne %lld ncand %lld applied %d rejected %d removed %d\n", rounds,
               (long long)nf, (long long)ne, (long long)ncand, hc[0], hc[1], hc[2]);
     applied_total += hc[0];

@@ -370,7 +370,7 @@ int dsu_groupnorm_nhwc_f16(const void* x, const void* gamma, const void* beta, i
   {
     // super-group form: groups of >= 8 channels whose super-group has <= 4 groups and fits the
     // registers of one 1024-thread workgroup (DSU_GN_SUPER=0: A/B switch)
-    static const bool use_super = [] { const char* e = getenv("DSU_GN_SUPER"); return !e || atoi(e) != 0; }();
+    static const bool use_super = dsu_ab_int("DSU_GN_SUPER", 1) != 0;
     const int cpg = C / G;
     int SG = cpg;
     while (SG % 8 != 0) SG += cpg;

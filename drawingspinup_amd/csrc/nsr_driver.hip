@@ -519,8 +519,8 @@ int dsu_nsr_driver_create(const dsu_nsr_driver_cfg* cfg, dsu_nsr_driver** out) {
   }
   d->rowcap = march_row_capacity(cfg->radius, cfg->render_step_size);
   int lo = 0, hi = 0;
-  if (const char* e = getenv("DSU_NSR_SIDE_PRIO")) d->side_high_priority = atoi(e) != 0;
-  if (const char* e = getenv("DSU_NSR_PACK_GATE")) d->pack_gate = atoi(e);
+  d->side_high_priority = dsu_ab_int("DSU_NSR_SIDE_PRIO", 1) != 0;
+  d->pack_gate = dsu_ab_int("DSU_NSR_PACK_GATE", 1);
   bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
             hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking,
                                         d->side_high_priority ? hi : lo) == hipSuccess;

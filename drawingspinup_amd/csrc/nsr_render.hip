@@ -627,10 +627,7 @@ Aabb make_aabb(const float* a6, int res = 1) {
 // multiplies instead of IEEE divisions), skip-chain length (DSU_MARCH_SB=4|8, default 4)
 static int march_sb() {
   static int v = 0;
-  if (!v) {
-    const char* e = getenv("DSU_MARCH_SB");
-    v = (e && atoi(e) == 8) ? 8 : 4;
-  }
+  if (!v) v = dsu_ab_int("DSU_MARCH_SB", 4) == 8 ? 8 : 4;
   return v;
 }
 // rays per workgroup (= lanes of the one wave that marches them): DSU_MARCH_THREADS=16|32|64.  A
@@ -639,8 +636,7 @@ static int march_sb() {
 static int march_threads() {
   static int v = 0;
   if (!v) {
-    const char* e = getenv("DSU_MARCH_THREADS");
-    const int t = e ? atoi(e) : 64;
+    const int t = dsu_ab_int("DSU_MARCH_THREADS", 64);
     v = (t == 16 || t == 32) ? t : 64;
   }
   return v;

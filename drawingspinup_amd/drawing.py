@@ -77,7 +77,7 @@ class DrawingPipeline:
                  with_clip=True, export_resolution=512, with_mv=True, with_contour=True, mesh_post=True):
         self.device = torch.device(device)
         self.mv_steps, self.nsr_steps, self.n_frames = mv_steps, nsr_steps, n_frames
-        self.style_batch = int(os.environ.get("DSU_STYLE_BATCH", "4"))   # frames per generator call
+        self.style_batch = 4                 # frames per generator call
         self.time_substages = False          # bench.py: split the NSR stage into fit / export
         self.substage_seconds = {}
         self.export_resolution = export_resolution

@@ -28,8 +28,8 @@ DEFAULT_SYSTEM_CONFIG = Cfg({     # configs/neuralangelo-ortho-wmask.yaml:86-141
 
 VIEWS = ["front", "front_right", "right", "back", "left", "front_left"]
 # Morton bins per axis (2^bits) for the sorted evaluation order of the geometry network in the
-# fused step; DSU_SPATIAL_SORT=0 keeps the marcher's ray-major order (A/B runs).
-_SPATIAL_SORT_BITS = int(os.environ.get("DSU_SPATIAL_SORT", "6"))
+# fused step (0 would keep the marcher's ray-major order).
+_SPATIAL_SORT_BITS = 6
 
 # capacity (samples) of the fixed-size buffers the prefetch path packs into: 2x the schedule's
 # target of 2^18 samples per step; a step that exceeds it is re-packed on the main stream
@@ -472,11 +472,10 @@ class OrthoNeuSSystem:
         self.global_step = 0
         oc = self.config.optimizer
         # the hash table has its own fused optimizer step (TableAdamW, same AdamW update);
-        # DSU_TABLE_ADAM=0 leaves it in the torch optimizer (A/B runs)
         enc = self.model.geometry.hashgrid
         self.table_opt = None
         self.keep_table_grad = False
-        if self.device.type == "cuda" and os.environ.get("DSU_TABLE_ADAM", "1") != "0":
+        if self.device.type == "cuda":
             self.table_opt = TableAdamW(enc, dict(oc.params)["geometry"], tuple(oc.betas), oc.eps)
             # whoever reads the parameters (checkpoint, export) sees the masked levels with their
             # lazily accumulated weight decay applied
@@ -487,31 +486,32 @@ class OrthoNeuSSystem:
                   for n, lr in oc.params.items()]
         # same update rule as the reference's torch.optim.AdamW; the fused (single-launch per
         # group) implementation on the GPU instead of ~10 foreach launches per group
-        fused = self.device.type == "cuda" and os.environ.get("DSU_ADAM", "fused") == "fused"
+        fused = self.device.type == "cuda"
         self.optimizer = torch.optim.AdamW(groups, lr=oc.lr, betas=tuple(oc.betas), eps=oc.eps,
                                            **({"fused": True} if fused else {}))
         self._base_lrs = [g["lr"] for g in groups]
-        # the small tensors' AdamW as one launch (DSU_SMALL_ADAM=0: torch's fused optimizer)
+        # the small tensors' AdamW as one launch
         self.small_opt = None
-        if self.device.type == "cuda" and os.environ.get("DSU_SMALL_ADAM", "1") != "0":
+        if self.device.type == "cuda":
             self.small_opt = SmallAdamW(self.optimizer, tuple(oc.betas), oc.eps)
         # ExponentialLR gamma = 0.1 ** (1 / (max_steps - constant_steps))  (recon.py:13)
         self._gamma = 0.1 ** (1.0 / (self.config.max_steps - self.config.constant_steps))
         self.dataset = None
         self.last = {}
-        self.use_loss_graph = os.environ.get("DSU_NO_GRAPH", "0") != "1" and self.device.type == "cuda"
+        self.use_loss_graph = self.device.type == "cuda"
         self._loss_graph = None
         # "fused": forward and backward of a step driven kernel by kernel (no autograd graph
         # except for the texture MLP and the tiny weight-norm / variance chains);
         # "autograd": the op-by-op step through torch.autograd (cross-check, same numbers)
         # "native": the step sequenced by the library (NativeStepDriver) whenever no draws are
         # injected; "fused": the same kernels sequenced from here
-        self.step_mode = os.environ.get("DSU_STEP", "native")
+        self.step_mode = "native"
+        self.native_with_injected_draws = False     # tests: injected draws through the native driver
         self._native, self._python_steps = None, 0
-        self.use_prefetch = os.environ.get("DSU_PREFETCH", "1") != "0" and self.device.type == "cuda"
-        self.fused_batch = os.environ.get("DSU_FUSED_BATCH", "1") != "0"
+        self.use_prefetch = self.device.type == "cuda"
+        self.fused_batch = True
         self._side, self._prefetched = None, None
-        self.pack_on_side_stream = os.environ.get("DSU_PACK_PREFETCH", "1") != "0"
+        self.pack_on_side_stream = True
         self._packed = {}
         self._stats_pinned = [torch.empty(2, dtype=torch.int32).pin_memory() for _ in range(2)] \
             if self.device.type == "cuda" and torch.cuda.is_available() else None
@@ -643,7 +643,7 @@ class OrthoNeuSSystem:
         # Python-sequenced when the first step comes with injected draws (tests of that path).
         if native_ok and (self._native is not None
                           or (self._python_steps == 0 and not (inject and "batch" in inject)
-                              and (not inject or os.environ.get("DSU_STEP") == "native"))):
+                              and (not inject or self.native_with_injected_draws))):
             return self.training_step_native(inject)
         self._python_steps += 1
         if self.step_mode in ("fused", "native") and fusable:

@@ -873,16 +873,17 @@ def conv_weight_okc(weight):
 
 _TILE_COUNTERS = {}
 _N_TILE_COUNTERS = 1 << 16
+SPLITK_FIXUP = False          # in-kernel split-K fix-up instead of the separate reduce launch (A/B)
 
 
 def _tile_counters(device):
     """Zeroed, persistent per (device, stream) int32 buffer for the in-kernel split-K fix-up (the
-    kernel resets what it touches; launches that share a buffer must share a stream).  OFF unless
-    DSU_SPLITK_FIXUP=1: the device-scope release / acquire around the ticket writes back and
-    invalidates the XCD's L2 per workgroup — the UNet forward took 26.6 ms with it against 12.6 ms
-    with the separate reduce launches (profiles/round3_unet_splitk_fixup.txt)."""
-    import os
-    if os.environ.get("DSU_SPLITK_FIXUP", "0") != "1":
+    kernel resets what it touches; launches that share a buffer must share a stream).  Only when
+    SPLITK_FIXUP is set (tests / tools; off in the product): the device-scope release / acquire
+    around the ticket writes back and invalidates the XCD's L2 per workgroup — the UNet forward
+    took 26.6 ms with it against 12.6 ms with the separate reduce launches
+    (profiles/round3_unet_splitk_fixup.txt)."""
+    if not SPLITK_FIXUP:
         return None
     key = (str(device), stream().value)
     t = _TILE_COUNTERS.get(key)

@@ -30,6 +30,9 @@ extern "C" {
 #define DSU_MAX_LEVELS 16
 
 const char* dsu_strerror(int code);
+/* 1 when the library was built with the A/B environment switches (variant builds for tools/), 0
+ * for the product library: it reads no DSU_* environment variable. */
+int dsu_ab_switches(void);
 /* ABI version of this header; bumped on any signature change. */
 int dsu_abi_version(void);
 

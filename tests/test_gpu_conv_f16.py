@@ -65,7 +65,7 @@ def test_conv_f16_split_k_matches_plain(dev, split, fixup, monkeypatch):
     reduce/epilogue kernel) against the single-pass kernel and torch, on a 4x4-level UNet shape with
     the full fused epilogue and on an O that is not a multiple of 4.  The fix-up form is run
     three times on the same counters: they must come back to zero."""
-    monkeypatch.setenv("DSU_SPLITK_FIXUP", "1" if fixup else "0")
+    monkeypatch.setattr(ops, "SPLITK_FIXUP", fixup)
     B, C, O, H, W = 3, 1280, 640, 4, 4
     x, w, b = _r((B, C, H, W), 14), _r((O, C, 3, 3), 15, (C * 9) ** -0.5), _r((O,), 16, 0.1)
     tv, res = _r((B, O), 17, 0.5), _r((B, O, H, W), 18)
