@@ -133,6 +133,7 @@ _PROTOS = {
     "dsu_point_bin_fill": [P, c_i64, c_f32, c_f32, c_f32, c_i32, P, P, P, P],
     "dsu_knn8_blend": [P, c_i64, P, P, c_i64, c_f32, c_f32, c_f32, c_i32, P, P, P, P],
     "dsu_ab_switches": [],
+    "dsu_umbrella_implicit_solve": [P, P, c_i64, C.c_double, P, P, P, c_i32, P],
     "dsu_mesh_decimate_quadric": [P, c_i64, P, c_i64, c_i64, C.c_double, c_i32, P, P, P, P],
     "dsu_mesh_decimate_quadric_q": [P, c_i64, P, c_i64, c_i64, C.c_double, c_i32, P, P, P, P, P],
     "dsu_mesh_decimate_parallel_workspace_bytes": [c_i64, c_i64],

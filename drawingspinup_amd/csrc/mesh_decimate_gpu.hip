@@ -222,18 +222,27 @@ __global__ void owner_flags_kernel(Mesh m, uint8_t* flag) {
   }
 }
 
-struct Reject {     // direct-mapped memory of rejected collapses
-  unsigned long long key;
-  uint32_t ver0, ver1;
-};
+// Direct-mapped memory of rejected collapses, one 64-bit word per slot:
+//   [63:48] round of the rejection | [47:0] hash of (edge, version of v0, version of v1)
+// written with atomicMax: a later round replaces an earlier one, and when several rejections of one
+// round fall into one slot the larger hash stays — the same one on every run (a plain store would
+// keep whichever writer came last).  A look-up compares the low 48 bits with the hash of the
+// edge's CURRENT versions.
+typedef unsigned long long Reject;
 
 __device__ inline unsigned long long ekey(int32_t a, int32_t b) {
   const uint32_t lo = a < b ? a : b, hi = a < b ? b : a;
   return ((unsigned long long)lo << 32) | hi;
 }
+__device__ inline unsigned long long mix64(unsigned long long k) {
+  k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+  return k;
+}
 __device__ inline uint32_t slot_of(unsigned long long key, uint32_t n_slots) {
-  key ^= key >> 33; key *= 0xff51afd7ed558ccdull; key ^= key >> 33;
-  return (uint32_t)(key % n_slots);
+  return (uint32_t)(mix64(key) % n_slots);
+}
+__device__ inline unsigned long long reject_tag(unsigned long long key, uint32_t ver0, uint32_t ver1) {
+  return mix64(key ^ mix64(((unsigned long long)ver0 << 32) | ver1)) & 0xffffffffffffull;
 }
 
 // cost of every owner half-edge, as the float32 bit pattern of max(cost, 0) (monotone as an
@@ -249,8 +258,7 @@ __global__ void edge_cost_kernel(Mesh m, const int32_t* edges, int64_t ne, const
     edge_target(m, v0, v1, cost, vb);
     float c = (float)(cost > 0.0 ? cost : 0.0);
     const unsigned long long key = ekey(v0, v1);
-    const Reject r = rej[slot_of(key, n_slots)];
-    if (r.key == key && r.ver0 == vver[v0] && r.ver1 == vver[v1]) c = INFINITY;
+    if ((rej[slot_of(key, n_slots)] & 0xffffffffffffull) == reject_tag(key, vver[v0], vver[v1])) c = INFINITY;
     cost_bits[e] = __float_as_uint(c);
     edge_idx[e] = (uint32_t)e;
   }
@@ -295,12 +303,17 @@ __device__ inline bool is_dirty(const Mesh& m, int32_t v0, int32_t v1, const uin
 
 __global__ void claim_kernel(Mesh m, const int32_t* edges, const uint32_t* sorted_idx, const uint32_t* sorted_cost,
                              int64_t ncand, uint32_t round, uint32_t seed, const uint32_t* touched,
+                             const Reject* rej, uint32_t n_slots, const uint32_t* vver,
                              unsigned long long* claim) {
   for (int64_t r = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; r < ncand; r += (int64_t)gridDim.x * blockDim.x) {
     if (sorted_cost[r] == 0x7f800000u) continue;            // +inf: remembered rejection
     int32_t v0, v1;
     edge_ends(m, edges[sorted_idx[r]], v0, v1);
     if (is_dirty(m, v0, v1, touched, round)) continue;
+    {                                                       // rejected in an earlier pass of this round
+      const unsigned long long key = ekey(v0, v1);
+      if ((rej[slot_of(key, n_slots)] & 0xffffffffffffull) == reject_tag(key, vver[v0], vver[v1])) continue;
+    }
     const unsigned long long pr = priority_of(v0, v1, seed, (uint32_t)r);
     for (int pass = 0; pass < 2; ++pass) {
       const int32_t v = pass ? v1 : v0;
@@ -391,9 +404,9 @@ __global__ void collapse_kernel(Mesh m, const int32_t* edges, const uint32_t* so
       }
     }
     if (bad) {
-      Reject rr;
-      rr.key = ekey(v0, v1); rr.ver0 = vver[v0]; rr.ver1 = vver[v1];
-      rej[slot_of(rr.key, n_slots)] = rr;
+      const unsigned long long key = ekey(v0, v1);
+      atomicMax(&rej[slot_of(key, n_slots)],
+                ((unsigned long long)(round & 0xffffu) << 48) | reject_tag(key, vver[v0], vver[v1]));
       atomicAdd(&counters[1], 1);
       continue;
     }
@@ -568,7 +581,7 @@ int dsu_mesh_decimate_parallel(double* verts, int64_t n_verts, int32_t* faces, i
   DSU_HIP_TRY(hipMemsetAsync(vver, 0, (size_t)n_verts * sizeof(uint32_t), s));
   DSU_HIP_TRY(hipMemsetAsync(touched, 0xff, (size_t)n_verts * sizeof(uint32_t), s));
   DSU_HIP_TRY(hipMemsetAsync(touched2, 0xff, (size_t)n_verts * sizeof(uint32_t), s));
-  DSU_HIP_TRY(hipMemsetAsync(rej, 0xff, (size_t)L.n_slots * sizeof(Reject), s));
+  DSU_HIP_TRY(hipMemsetAsync(rej, 0, (size_t)L.n_slots * sizeof(Reject), s));
   iota_kernel<<<dsu_capped_blocks(3 * nf, T), T, 0, s>>>(iota, 3 * nf);
   if ((rc = build_csr())) return rc;
   Mesh m{verts, Q, F, voff, vfaces, n_verts, nf};
@@ -603,7 +616,7 @@ int dsu_mesh_decimate_parallel(double* verts, int64_t n_verts, int32_t* faces, i
       const uint32_t seed = (uint32_t)rounds * 16u + (uint32_t)pass;
       DSU_HIP_TRY(hipMemsetAsync(claim, 0xff, (size_t)n_verts * sizeof(unsigned long long), s));
       claim_kernel<<<dsu_capped_blocks(ncand, T), T, 0, s>>>(m, edges, idx2, cost2, ncand, (uint32_t)rounds, seed,
-                                                             touched, claim);
+                                                             touched, rej, L.n_slots, vver, claim);
       collapse_kernel<<<dsu_capped_blocks(ncand, T), T, 0, s>>>(m, edges, idx2, cost2, ncand, (uint32_t)rounds, seed,
                                                                 claim, link_test, flag, rej, L.n_slots, vver,
                                                                 touched2, touched, counters);

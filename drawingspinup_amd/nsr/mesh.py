@@ -650,6 +650,64 @@ def laplacian_smooth_implicit(verts, faces, lamb=2.0, iterations=5, volume_const
     return v
 
 
+def laplacian_smooth_implicit_device(verts, faces, lamb=2.0, iterations=5, volume_constraint=True,
+                                     sweeps=96):
+    """The same filter on DEVICE tensors (verts (N,3) float64, faces (M,3) int64): neighbour lists
+    by a sort of the directed edges, every implicit step by Jacobi sweeps of the library
+    (`dsu_umbrella_implicit_solve`: the matrix is diagonally dominant, 96 sweeps contract the error
+    by (2/3)^96 = 1e-17), volume rescaling with device reductions.  Returns (N,3) float64."""
+    from .. import _lib, ops
+    dev = verts.device
+    v = verts.to(torch.float64).contiguous().clone()
+    f = faces.to(torch.int64)
+    n = v.shape[0]
+    if n == 0 or f.shape[0] == 0:
+        return v
+    e = torch.cat([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]], 0)
+    e = torch.cat([e, e.flip(1)], 0)
+    key = torch.unique(e[:, 0] * n + e[:, 1])                          # sorted: row-major, columns ascending
+    rows = torch.div(key, n, rounding_mode="floor")
+    cols = (key - rows * n).to(torch.int32).contiguous()
+    off = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+    off[1:] = torch.cumsum(torch.bincount(rows, minlength=n), 0)
+    off = off.to(torch.int32).contiguous()
+    tmp = torch.empty_like(v)
+
+    def volume(p):
+        a, b, c = p[f[:, 0]], p[f[:, 1]], p[f[:, 2]]
+        return (a * torch.linalg.cross(b, c)).sum() / 6.0
+
+    vol0 = volume(v) if volume_constraint else None
+    lib = _lib.lib()
+    for _ in range(int(iterations)):
+        rhs = v.clone()
+        ops.check(lib.dsu_umbrella_implicit_solve(off.data_ptr(), cols.data_ptr(), n, float(lamb),
+                                                  rhs.data_ptr(), v.data_ptr(), tmp.data_ptr(), int(sweeps),
+                                                  torch.cuda.current_stream(dev).cuda_stream),
+                  "dsu_umbrella_implicit_solve")
+        if volume_constraint:
+            vol = volume(v)
+            ratio = vol0 / vol
+            # (vol0 / vol) ** (1/3) where the ratio is positive and finite, 1 otherwise: no host read
+            scale = torch.where(torch.isfinite(ratio) & (ratio > 0), ratio.abs() ** (1.0 / 3.0),
+                                torch.ones_like(ratio))
+            v = v * scale
+    return v
+
+
+def shear_transformation_device(v):
+    """shear_transformation on a device tensor (N,3) float64 (the 2x2 SVD on the host: four numbers)."""
+    d = v[:, 1:3]
+    nd = d - d.mean(0)
+    H = (nd.T @ nd).cpu().numpy()
+    vec, val, _ = np.linalg.svd(H)
+    vec = vec[:, val.argsort()[::-1]]
+    a = -vec[1, 0] / vec[0, 0]
+    out = v.clone()
+    out[:, 2] += a * v[:, 1]
+    return out
+
+
 def shear_transformation(v):
     """mesh_utils.py:76-93: principal axis of the (y, z) coordinates by SVD of their scatter matrix,
     then z += a * y with a = -v[1,0] / v[0,0] (the figure is sheared upright).  In place on a copy."""
@@ -685,6 +743,24 @@ def post_process_mesh(verts, faces, colors=None, ortho_scale=1.35, smoothing=Fal
     character mask, type='double' | 'front' | 'back') runs nsr/thinning.thinning_processing
     (mesh_utils.py:38-39) first; the nearest-vertex colour transfer then reads the thinned
     vertices, as the reference's does."""
+    if torch.is_tensor(verts) and verts.is_cuda and thinning is None and \
+            (colors is None or color_back_projection is not None):
+        # everything stays on the device (the export path: smoothing by Jacobi sweeps, colour
+        # back-projection, shear); host arrays only at the very end, for the OBJ writer
+        vd = verts.detach().to(torch.float64) * 0.5
+        out = torch.stack([vd[:, 0], vd[:, 2], -vd[:, 1]], -1)
+        fd = faces.detach().to(verts.device, torch.int64)
+        c = None
+        if smoothing and fd.shape[0]:
+            out = laplacian_smooth_implicit_device(out, fd, lamb=2.0, iterations=5)
+        if color_back_projection is not None and fd.shape[0]:
+            from .mesh_post import color_projection
+            cbp = color_back_projection
+            c = color_projection(out.contiguous(), fd, cbp["color_front"], cbp["mask_front"],
+                                 cbp["color_back"], res=cbp["color_front"].shape[0]).float().cpu().numpy()
+        if shearing and out.shape[0]:
+            out = shear_transformation_device(out)
+        return (out * ortho_scale).cpu().numpy(), fd.cpu().numpy(), c
     v = verts.detach().cpu().numpy().astype(np.float64) * 0.5
     old = np.zeros_like(v)
     old[:, 0], old[:, 1], old[:, 2] = v[:, 0], v[:, 2], -v[:, 1]

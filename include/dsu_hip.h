@@ -841,6 +841,15 @@ int dsu_mesh_decimate_parallel(double* verts, int64_t n_verts, int32_t* faces, i
                                int64_t* out_n_faces, int32_t* out_stats, void* workspace,
                                int64_t workspace_bytes, void* stream);
 
+/* One implicit step of trimesh.smoothing.filter_laplacian (save_mesh, mesh_utils.py:42-45):
+ * solves (I + lamb (I - L)) X = rhs for the umbrella operator L given as CSR neighbour lists
+ * (offsets (n_verts+1), neighbours: int32 device), rhs / x / tmp (n_verts,3) float64 device.
+ * x holds the starting guess on entry (rhs itself is a good one) and the solution on return;
+ * `sweeps` Jacobi sweeps (even; the error contracts by lamb / (1 + lamb) per sweep). */
+int dsu_umbrella_implicit_solve(const int32_t* offsets, const int32_t* neighbours, int64_t n_verts,
+                                double lamb, const double* rhs, double* x, double* tmp,
+                                int32_t sweeps, void* stream);
+
 /* Image-side host steps of thinning_processing (instant_nsr/utils/thinning_utils.py:205-218) on
  * HOST arrays (H,W) uint8, non-zero = character:
  *   cv2.distanceTransform(mask, cv2.DIST_L2, 5)            -> out (H,W) float32

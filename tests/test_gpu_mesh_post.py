@@ -105,3 +105,24 @@ def test_knn8_blend_matches_ckdtree(dev):
     w /= w.sum(1, keepdims=True)
     want = np.einsum("ijk,ij->ik", rgb[idx].astype(np.float64), w)
     np.testing.assert_allclose(got, want, rtol=0, atol=2e-6)
+
+
+def test_device_laplacian_smoothing_equals_the_sparse_lu_filter(dev):
+    """save_mesh's implicit Laplacian filter (mesh_utils.py:42-45) on device tensors — Jacobi sweeps
+    of dsu_umbrella_implicit_solve + device volume rescaling — against the host form (sparse LU of
+    the same matrix, pinned to the reference's save_mesh by tests/test_mesh_host.py): 1e-11, and the
+    whole post_process_mesh device path (smoothing + shear + scale) against the host path."""
+    import numpy as np
+    from drawingspinup_amd.nsr import mesh as M
+    from tests.test_export_host import _uv_sphere
+    v, f = _uv_sphere(96, 64)
+    g = np.random.default_rng(0)
+    v = v * (1 + 0.05 * g.standard_normal((v.shape[0], 1))) + 0.01 * g.standard_normal(v.shape)
+    want = M.laplacian_smooth_implicit(v, f, lamb=2.0, iterations=5)
+    got = M.laplacian_smooth_implicit_device(torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev),
+                                             lamb=2.0, iterations=5).cpu().numpy()
+    assert np.abs(got - want).max() < 1e-11
+    hv, hf, _ = M.post_process_mesh(torch.from_numpy(v), torch.from_numpy(f), None, smoothing=True, shearing=True)
+    dv, df, _ = M.post_process_mesh(torch.from_numpy(v).to(dev), torch.from_numpy(f).to(dev), None,
+                                    smoothing=True, shearing=True)
+    assert np.array_equal(hf, df) and np.abs(hv - dv).max() < 1e-10
