@@ -9,6 +9,9 @@ modes:  native         dsu_nsr_driver_step, own draws, prefetch
         fused          Python-sequenced step, torch draws
         native-inject  native step fed torch draws (no prefetch)   -> isolates the draw stream
         fused-philox   Python-sequenced step fed dsu_nsr_draws     -> isolates the sequencing
+        autograd       the op-by-op step through torch.autograd (the path the oracle / reference
+                       fixtures pin operator by operator), torch draws
+        fused-torch    Python-sequenced fused step fed the SAME torch draws as `autograd`
 usage: nsr_native_vs_fused.py [steps] [mode,mode,...] [seed]"""
 import ctypes as C
 import json, os, sys, time
@@ -79,7 +82,7 @@ for mode in ["warm-native", "warm-fused"] + order:
     ds = OrthoData.synthetic_sphere(512, device=dev)
     sysm = OrthoNeuSSystem(device=dev, seed=seed)
     sysm.dataset = ds
-    sysm.step_mode = "native" if name.startswith("native") else "fused"
+    sysm.step_mode = "native" if name.startswith("native") else ("autograd" if name == "autograd" else "fused")
     g = torch.Generator(device=dev).manual_seed(seed)
     torch.manual_seed(seed)
     n = 40 if warm else steps
@@ -90,6 +93,10 @@ for mode in ["warm-native", "warm-fused"] + order:
             r = sysm.training_step_native(torch_draws(ds, int(sysm.train_num_rays), g))
         elif name == "fused-philox":
             r = sysm.training_step_fused(philox_draws(ds, int(sysm.train_num_rays), s))
+        elif name == "autograd":
+            r = sysm.training_step_autograd(torch_draws(ds, int(sysm.train_num_rays), g))
+        elif name == "fused-torch":
+            r = sysm.training_step_fused(torch_draws(ds, int(sysm.train_num_rays), g))
         else:
             r = sysm.training_step()
         samples += r["n_samples"]
