@@ -265,21 +265,59 @@ def _timed_loop(args, ddist, dev, timer, body):
     return elapsed, last
 
 
+_PMC_CACHE = []
+
+
+def _pmc():
+    """profiles/round4_pmc.json (tools/pmc_round4.sh) or None."""
+    if not _PMC_CACHE:
+        path = os.path.join(ROOT, "profiles", "round4_pmc.json")
+        try:
+            with open(path) as f:
+                _PMC_CACHE.append(json.load(f))
+        except (OSError, ValueError):
+            _PMC_CACHE.append(None)
+    return _PMC_CACHE[0]
+
+
+def _sq_share(prefixes, field):
+    """dispatch-weighted mean of an SQ share (profiles/round4_pmc.json) over the kernels whose
+    name starts with one of `prefixes`, weighted by their wave cycles."""
+    pmc = _pmc()
+    if not pmc:
+        return None
+    num = den = 0.0
+    for k, v in pmc["kernels"].items():
+        if any(k.startswith(p) for p in prefixes) and v.get("SQ_WAVE_CYCLES") and v.get(field) is not None:
+            w = v["SQ_WAVE_CYCLES"] * v.get("dispatches", 1)
+            num += v[field] * w
+            den += w
+    return num / den if den else None
+
+
 def _roofline(timer, extra=None):
     rows = timer.summary()
     if not rows:
         return None
     top = dict(rows[0])
     top["kernels"] = rows[:3]
-    # HBM-side bytes per launch of the dominant family from the PMC passes (separate rocprofv3
-    # --pmc FETCH_SIZE / WRITE_SIZE runs, as MI355X_MICROARCH.md prescribes; not collectable
-    # inside this process): measured at N = 262 144 points, 5 active levels
-    # (profiles/round2_pmc_sdf_kernels.txt: backward pair 35.6 + 38.3 MB fetched — x2 for the
-    # guide's coalesced-read correction — + 77.6 + 43.6 MB written; forward 10.5 x 2 + 57.5 MB) and
-    # scaled to this run's mean algorithmic bytes per launch
-    pmc = {"sdf_fd_bwd": (2 * (35.6e6 + 38.3e6) + 77.6e6 + 43.6e6) / 315.6e6,
-           "sdf_fd_fwd": (2 * 10.5e6 + 57.5e6) / 315.6e6}
-    top["traffic"] = pmc[top["kernel"]] * top["alg_work_per_launch"] if top["kernel"] in pmc else None
+    # HBM-side bytes per launch of the dominant family: not collectable inside this process (PMC
+    # counters need their own rocprofv3 --pmc passes, FETCH_SIZE and WRITE_SIZE one pass each, as
+    # MI355X_MICROARCH.md prescribes).  profiles/round4_pmc.json holds this round's passes over
+    # tools/pmc_sdf_kernels.py (N = 262 144 Morton-ordered samples, 5 levels): per kernel
+    # (2 x FETCH_SIZE + WRITE_SIZE) — the guide's gfx950 correction for coalesced reads — and the
+    # workload's algorithmic bytes; the measured ratio is applied to this run's mean algorithmic
+    # bytes per launch.
+    pmc = _pmc()
+    fam = {"sdf_fd_bwd": ("sdf_fd_bwd_mfma_kernel", "sdf_fd_scatter_kernel", "reduce_partials_mfma_kernel"),
+           "sdf_fd_fwd": ("sdf_fd_fwd_kernel",)}
+    top["traffic"] = None
+    if pmc and top["kernel"] in fam:
+        side = sum(v.get("hbm_side_bytes", 0.0) for k, v in pmc["kernels"].items()
+                   if any(k.startswith(f) for f in fam[top["kernel"]]))
+        if side > 0:
+            top["traffic"] = side / pmc["sdf_algorithmic_bytes"] * top["alg_work_per_launch"]
+            top["traffic_source"] = "profiles/round4_pmc.json"
     if extra:
         top.update(extra)
     return top
@@ -349,13 +387,20 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
     }
     for st in stages.values():
         st["frac"] = st["achieved"] / st["peak"]
+    # matrix-pipe busy share of the wave cycles and the parked / issue-stalled shares of the stage's
+    # MFMA kernels, from this round's SQ pass (profiles/round4_pmc.json; one UNet forward / one frame)
+    for name, pre in (("mv", ("conv_f16_kernel", "mv_attention_kernel")), ("style", ("conv_igemm_kernel",))):
+        for field in ("mfma_busy_of_wave_cycles", "parked_frac", "issue_stall_frac"):
+            v = _sq_share(pre, field)
+            if v is not None:
+                stages[name][field] = v
     roof = _roofline(timer, {"stages": stages,
-                             "traffic_note": "HBM-side bytes per launch of the dominant "
-                                             "family: ratio to the algorithmic bytes measured in "
-                                             "separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes "
-                                             "(profiles/round2_pmc_sdf_kernels.txt, fetches x2 per "
-                                             "the guide's correction), applied to this run's mean "
-                                             "algorithmic bytes per launch"})
+                             "traffic_note": "HBM-side bytes per launch of the dominant family "
+                                             "(MLP part + scatter + partial reduce): (2 x FETCH_SIZE + "
+                                             "WRITE_SIZE) of this round's separate rocprofv3 --pmc passes "
+                                             "(profiles/round4_pmc.json, tools/pmc_round4.sh) relative to "
+                                             "that workload's algorithmic bytes, applied to this run's "
+                                             "mean algorithmic bytes per launch"})
     out = {
         "metric": "drawings/sec end-to-end (512x512, 6 views, 24 frames)",
         "value": world * args.steps / elapsed, "unit": "drawings/s", "n_gpus": world,
