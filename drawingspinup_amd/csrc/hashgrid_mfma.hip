@@ -478,6 +478,9 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
   float* q_v0 = sd + QCAP;
   float* q_v1 = sd + 2 * QCAP;
 
+  // the scatter kernel's work counter (behind the dIn buffer) starts every launch at zero
+  if (SPLIT && blockIdx.x == 0 && threadIdx.x == 0)
+    *reinterpret_cast<int*>(dinbuf + (size_t)7 * (size_t)n * NL) = 0;
   Frags<NL> fr;
   load_frags<NL>(mlp, fr, lane);
   // A operand of dIn^T = W0'^T . dPre^T : W0'[feat_of(T, r, h)][k = lane & 31]
@@ -945,7 +948,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
                 v[2 * c] = w * d0;
                 v[2 * c + 1] = w * d1;
               }
-              const int key = (int)(cp.c[0] | (cp.c[1] << 10) | (cp.c[2] << 20));
+              const int key = (int)((cp.c[0] & 1023u) | ((cp.c[1] & 1023u) << 10) | ((cp.c[2] & 1023u) << 20));
               const int l15 = lane & 15;
               // The neighbour keys are fetched with ALL lanes active: written as
               // `l15 == 15 || dpp(key) != key`, the short-circuit put the DPP move under a reduced
@@ -1076,6 +1079,12 @@ constexpr int SC_QCAP = DSU_SC_QCAP;                          // triples per wav
 constexpr int SC_LOG2 = DSU_SC_LOG2;
 constexpr int SC_SLOTS = 1 << SC_LOG2;
 constexpr int SC_LDS_F = SC_SLOTS + 4 * SC_SLOTS + (SC_THREADS / 64) * 3 * SC_QCAP;
+// Dense tile (see the kernel): the 512 Morton-ordered samples of one iteration touch a small box of
+// cells on every level; their gradients are accumulated over that box in LDS — [corner in box][2]
+// 64-bit fixed point in the cache's and the queues' bytes — and flushed once per iteration.
+constexpr int SC_TILE_CAP = (SC_LDS_F * 4) / 16;              // box corners x 16 B in the cache's + queues' bytes
+constexpr int SC_BBOX_OFF = SC_LDS_F;                         // 2 x 6 ints: min xyz, max xyz (two parities)
+constexpr int SC_LDS_TOTAL = SC_LDS_F + 16;
 static_assert(SC_QCAP % 4 == 0 && SC_QCAP >= 512, "queue: one full evaluation of a wave must fit");
 
 __device__ __forceinline__ uint32_t sc_slot(uint32_t entry) {
@@ -1098,11 +1107,18 @@ __device__ __forceinline__ void sc_commit_from(uint32_t* keys, unsigned long lon
   unsafeAtomicAdd(gtable + (size_t)entry * 2 + 1, v1);
 }
 
+#ifdef DSU_AB_SWITCHES
+// variant builds: per level, workgroups that took the dense tile / the cache, and the tile cells used
+__device__ unsigned long long dsu_sc_stat[3 * 16];
+// per workgroup: clocks of the last launch per level [block][16] (+ [15] = whole kernel)
+__device__ unsigned long long dsu_sc_clk[256 * 16];
+#endif
+
 template <int NL>
 __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
     GridMeta m, const float* __restrict__ pts, int64_t n, float radius, float eps, uint32_t active,
     const float2* __restrict__ dinbuf, float* __restrict__ gtable, int merge_levels,
-    int centre_acc) {
+    int centre_acc, int dense_levels, int* __restrict__ work_counter) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   uint32_t* c_keys = reinterpret_cast<uint32_t*>(lds);
   unsigned long long* c_acc = reinterpret_cast<unsigned long long*>(lds + SC_SLOTS);
@@ -1111,150 +1127,306 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
   uint32_t* q_ent = reinterpret_cast<uint32_t*>(qbase);
   float* q_v0 = qbase + SC_QCAP;
   float* q_v1 = qbase + 2 * SC_QCAP;
+  unsigned long long* tile = reinterpret_cast<unsigned long long*>(lds);   // tile mode: cache + queues' bytes
+  int* bbox = reinterpret_cast<int*>(lds + SC_BBOX_OFF);                   // 2 x (min xyz, max xyz)
   for (int t = threadIdx.x; t < SC_SLOTS; t += blockDim.x) {
     c_keys[t] = GC_EMPTY;
     c_acc[2 * t] = 0ull;
     c_acc[2 * t + 1] = 0ull;
   }
+  if (threadIdx.x < 12) bbox[threadIdx.x] = (threadIdx.x % 6) < 3 ? 0x7fffffff : -0x7fffffff;
+  int region = 0;                      // what the shared bytes are initialised for: 0 cache, 1 tile
   __syncthreads();
-  // Every workgroup owns ONE contiguous range of the (Morton-ordered) points and walks it once
-  // per level: the cache is flushed once per (workgroup, level) — a grid-stride walk flushed it
-  // after every 512 points, and with n = 2.03 x 256 x 512 its third round ran on 8 of 256 CUs —
-  // and neighbouring ranges of the sorted order keep hitting the same entries.
-  const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 63) / 64 * 64;
-  const int64_t r0 = blockIdx.x * per;
-  const int64_t r1 = r0 + per < n ? r0 + per : n;
+#ifdef DSU_AB_SWITCHES
+  const unsigned long long clk_start = wall_clock64();
+#endif
+  // Work items = (512-point chunk of the Morton-ordered samples, level), handed out dynamically:
+  // an item is self-contained (its tile is flushed at its end), items differ a lot in cost (how
+  // many offsets leave their cell, tile or cache), and n / 512 chunks do not divide by the 256
+  // resident workgroups — with one static range per workgroup the slowest ran 1.6x the mean
+  // (tools/scatter_stats.py) and a third, almost empty iteration cost every workgroup a full one.
+  // Item j = chunk j / active, level j % active.  Workgroup b starts with items b and b + G
+  // (G = grid size); further ones come from `work_counter` (zeroed by the MLP-part kernel, which
+  // precedes this one on the stream), fetched one item ahead so that the next item's loads can
+  // be issued a whole item before they are needed.
+  const int64_t n_chunks = (n + blockDim.x - 1) / blockDim.x;
+  const int64_t n_items = n_chunks * (int64_t)active;
+  int* next_slot = reinterpret_cast<int*>(lds + SC_BBOX_OFF) + 12;   // the item after next, via LDS
+  int64_t cur = blockIdx.x, nxt = (int64_t)blockIdx.x + gridDim.x;
+  float pn[3] = {0.f, 0.f, 0.f};       // position and the seven dIn pairs of the NEXT item to process
+  float2 dnx[7];
+#pragma unroll
+  for (int e = 0; e < 7; ++e) dnx[e] = make_float2(0.f, 0.f);
+  auto request = [&](int64_t item) {   // loads of an item: unconditional, from clamped addresses
+    const int64_t chunk = item / (int64_t)active;
+    const uint32_t lv = (uint32_t)(item - chunk * (int64_t)active);
+    int64_t idx = chunk * blockDim.x + threadIdx.x;
+    idx = idx < n ? idx : n - 1;
+    pn[0] = pts[idx * 3]; pn[1] = pts[idx * 3 + 1]; pn[2] = pts[idx * 3 + 2];
+#pragma unroll
+    for (int e = 0; e < 7; ++e) dnx[e] = dinbuf[((size_t)e * active + lv) * n + idx];
+  };
+  if (cur < n_items) request(cur);
+  int parity = 0;                      // bounding-box words in use (double-buffered over items)
+  int qn = 0;
+  auto drain = [&]() {
+    __builtin_amdgcn_wave_barrier();
+    for (int i0 = 0; i0 < qn; i0 += 64) {
+      const int qi = i0 + lane;
+      if (qi < qn) {
+        const uint32_t ent = q_ent[qi];
+        const float a0 = q_v0[qi], a1 = q_v1[qi];
+        const uint32_t slot = sc_slot(ent);
+        const uint32_t old = atomicCAS(&c_keys[slot], GC_EMPTY, ent);
+        if (old == GC_EMPTY || old == ent) {
+          atomicAdd(&c_acc[2 * slot], gc_fix(a0));
+          atomicAdd(&c_acc[2 * slot + 1], gc_fix(a1));
+        } else {
+          sc_commit_from(c_keys, c_acc, gtable, ent, slot, a0, a1);
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    qn = 0;
+  };
+  // cache -> table: one global atomic pair per touched entry, then reset (callers synchronise)
+  auto flush_cache = [&]() {
+    for (int t = threadIdx.x; t < SC_SLOTS; t += blockDim.x) {
+      const uint32_t key = c_keys[t];
+      if (key != GC_EMPTY) {
+        unsafeAtomicAdd(gtable + (size_t)key * 2, gc_unfix(c_acc[2 * t]));
+        unsafeAtomicAdd(gtable + (size_t)key * 2 + 1, gc_unfix(c_acc[2 * t + 1]));
+        c_keys[t] = GC_EMPTY;
+        c_acc[2 * t] = 0ull;
+        c_acc[2 * t + 1] = 0ull;
+      }
+    }
+  };
+
 #pragma unroll 1
-  for (int lev = 0; lev < NL; ++lev) {
-    if ((uint32_t)lev >= active) break;
-    const float l_scale = m.scale[lev];
-    const uint32_t l_off = m.off[lev], hsize = m.off[lev + 1] - m.off[lev];
-    const uint32_t l_res = m.res[lev], l_hashed = m.hashed[lev];
-    int qn = 0;
-    auto drain = [&]() {
-      __builtin_amdgcn_wave_barrier();
-      for (int i0 = 0; i0 < qn; i0 += 64) {
-        const int qi = i0 + lane;
-        if (qi < qn) {
-          const uint32_t ent = q_ent[qi];
-          const float a0 = q_v0[qi], a1 = q_v1[qi];
-          const uint32_t slot = sc_slot(ent);
-          const uint32_t old = atomicCAS(&c_keys[slot], GC_EMPTY, ent);
-          if (old == GC_EMPTY || old == ent) {
-            atomicAdd(&c_acc[2 * slot], gc_fix(a0));
-            atomicAdd(&c_acc[2 * slot + 1], gc_fix(a1));
-          } else {
-            sc_commit_from(c_keys, c_acc, gtable, ent, slot, a0, a1);
+  while (cur < n_items) {              // uniform over the workgroup
+    {
+      const int64_t chunk = cur / (int64_t)active;
+      const int lev = (int)(cur - chunk * (int64_t)active);
+      const float l_scale = m.scale[lev];
+      const uint32_t l_off = m.off[lev], hsize = m.off[lev + 1] - m.off[lev];
+      const uint32_t l_res = m.res[lev], l_hashed = m.hashed[lev];
+      const int64_t i = chunk * blockDim.x + threadIdx.x;
+      const bool valid = i < n;
+      const float p[3] = {pn[0], pn[1], pn[2]};
+      float2 dv[7];
+#pragma unroll
+      for (int e = 0; e < 7; ++e) {
+        dv[e].x = valid ? dnx[e].x : 0.0f;
+        dv[e].y = valid ? dnx[e].y : 0.0f;
+      }
+      if (nxt < n_items) request(nxt);   // uniform: the next item's loads, a whole item ahead
+      if (threadIdx.x == 0) *next_slot = (int)(2 * gridDim.x) + atomicAdd(work_counter, 1);
+      // ---- pass 1 (straight line): the centre's cell, which offsets stay in it, their sums.
+      // The interpolation weight of a corner is MULTILINEAR in the position inside the cell and an
+      // offset evaluation moves ONE coordinate: for an offset that stays in the centre's cell
+      //     w_c(f + D e_a) = w_c(f) + D * dw_c/df_a          (exactly, in real arithmetic)
+      // so the sum over the centre and those offsets of d_e * w_c(f_e) is
+      //     (sum_e d_e) * w_c(f)  +  sum_a (sum_{e on a} d_e * D_e) * dw_c/df_a :
+      // D0 = sum d_e and Da[a] = sum d_e * D_e are accumulated here (one contracted coordinate and
+      // one floor per offset instead of a full cell and eight weights); the eight corner sums are
+      // formed once, in the last emission below.  Offsets that leave the cell are emitted on their
+      // own.  (Different rounding than seven separate products: the table gradient's tolerance
+      // is 1e-2 relative; the tests hold it to 1e-4.)
+      const CellPos ccp = cell_of(l_scale, contract(p[0], radius), contract(p[1], radius),
+                                  contract(p[2], radius));
+      float2 D0 = dv[0], Da[3];
+      uint32_t left = 0u;
+      // fd_point clamps EVERY coordinate of an offset evaluation to the box (geometry.py:170) but
+      // not the centre: for a point outside the box (the perturbed random points can be) the
+      // offsets' other coordinates differ from the centre's — no shared cell, all six on their own
+      const bool inside = fabsf(p[0]) <= radius && fabsf(p[1]) <= radius && fabsf(p[2]) <= radius;
+      int lo[3], hi[3];                  // cells this lane touches (bounding box of the iteration)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        Da[a] = make_float2(0.f, 0.f);
+        lo[a] = valid ? (int)ccp.c[a] : 0x7fffffff;
+        hi[a] = valid ? (int)ccp.c[a] : -0x7fffffff;
+      }
+#pragma unroll
+      for (int e = 1; e < 7; ++e) {
+        const int ax = (e - 1) >> 1;
+        const float off = ((e - 1) & 1) ? -eps : eps;
+        const float qa = fminf(fmaxf(p[ax] + off, -radius), radius);      // fd_point's clamp
+        const float posa = fmaf(l_scale, contract(qa, radius), 0.5f);     // cell_of's position
+        const float fl = floorf(posa);
+        const bool same = ((uint32_t)(int)fl == ccp.c[ax]) & (centre_acc != 0) & inside;
+        const float delta = posa - ((float)(int)ccp.c[ax] + ccp.f[ax]);
+        D0.x += same ? dv[e].x : 0.0f;
+        D0.y += same ? dv[e].y : 0.0f;
+        Da[ax].x += same ? dv[e].x * delta : 0.0f;
+        Da[ax].y += same ? dv[e].y * delta : 0.0f;
+        left |= (valid & !same) ? (1u << e) : 0u;
+        if (valid & inside) {
+          lo[ax] = min(lo[ax], (int)fl);
+          hi[ax] = max(hi[ax], (int)fl);
+        }
+      }
+      if (valid & !inside) {             // rare, divergent: the general form of the six offsets
+#pragma unroll 1
+        for (int e = 1; e < 7; ++e) {
+          float q[3];
+          fd_point(p, e, eps, radius, q);
+          const CellPos cq = cell_of(l_scale, contract(q[0], radius), contract(q[1], radius),
+                                     contract(q[2], radius));
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            lo[a] = min(lo[a], (int)cq.c[a]);
+            hi[a] = max(hi[a], (int)cq.c[a]);
           }
         }
       }
-      __builtin_amdgcn_wave_barrier();
-      qn = 0;
-    };
-    // Software pipeline over the flattened (chunk, evaluation) iterations: the dIn pair of the
-    // NEXT iteration and the position of the NEXT chunk are requested before this iteration's
-    // arithmetic.  As written first, every iteration issued its 8-byte load and waited for it at
-    // once (`global_load_dwordx2` + `s_waitcnt vmcnt(0)`): 7 x levels x chunks round trips to
-    // memory per wave at two waves per SIMD — 47 % of the kernel's wave cycles were spent parked
-    // (SQ_WAIT_ANY, profiles/round3_sq_nsr_pass1_start.txt).  Loads are unconditional from clamped
-    // addresses (no exec-mask region around them); invalid lanes zero the value instead.
-    const int64_t w0 = r0 + wave * 64;
-    const int64_t last = r1 - 1;
-    float pn[3];
-    float2 dn;
-    {
-      const int64_t i0 = w0 + lane < r1 ? w0 + lane : last;
-      pn[0] = pts[i0 * 3]; pn[1] = pts[i0 * 3 + 1]; pn[2] = pts[i0 * 3 + 2];
-      dn = dinbuf[(size_t)lev * n + i0];
-    }
+      // ---- the iteration's box -> tile or cache.  The samples are in Morton order: the 512 points
+      // of one iteration touch a small box of cells on EVERY level (hashed levels too — the hash
+      // only decides where a corner's sum finally goes).  Their gradients are accumulated in a
+      // dense LDS tile over that box, [corner in box][2] 64-bit fixed point, with one ds_add_u64
+      // pair per corner and nothing else — no key compare-and-swap, no per-wave queue and drain —
+      // and the tile is flushed to the table (dense index or hash of the corner) at the end of
+      // the iteration.  An iteration whose box does not fit the tile (a jump of the Morton
+      // curve) goes through the hashed cache as before.
+      bool dense = false;
+      int x0 = 0, y0 = 0, z0 = 0, ddx = 1, ddxy = 1, vol = 0;
+      int64_t after_next;
+      {
+        int* bb = bbox + 6 * parity;
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+#pragma unroll
+          for (int off = 32; off > 0; off >>= 1) {
+            lo[a] = min(lo[a], __shfl_xor(lo[a], off));
+            hi[a] = max(hi[a], __shfl_xor(hi[a], off));
+          }
+        }
+        if (lane == 0) {
+#pragma unroll
+          for (int a = 0; a < 3; ++a) {
+            atomicMin(&bb[a], lo[a]);
+            atomicMax(&bb[3 + a], hi[a]);
+          }
+        }
+        __syncthreads();                 // (A) every wave's box is in (and the item after next)
+        after_next = *next_slot;
+        x0 = bb[0]; y0 = bb[1]; z0 = bb[2];
+        const long long ex = (long long)bb[3] - x0 + 2, ey = (long long)bb[4] - y0 + 2,
+                        ez = (long long)bb[5] - z0 + 2;                  // + the far corners
+        if (dense_levels && bb[3] >= bb[0] && ex * ey * ez <= (long long)SC_TILE_CAP && ex < 4096 && ey < 4096) {
+          dense = true;
+          ddx = (int)ex; ddxy = (int)(ex * ey); vol = (int)(ex * ey * ez);
+        }
+        // the OTHER parity's words are reset here for the next iteration: their readers (previous
+        // iteration) are past that iteration's barrier (B), and the next iteration's atomics on
+        // them come after this iteration's barrier (B), which follows this store in program order
+        if (threadIdx.x < 6) bbox[6 * (parity ^ 1) + threadIdx.x] = threadIdx.x < 3 ? 0x7fffffff : -0x7fffffff;
+        parity ^= 1;
+      }
+#ifdef DSU_AB_SWITCHES
+      if (threadIdx.x == 0) {
+        atomicAdd(&dsu_sc_stat[3 * lev + (dense ? 0 : 1)], 1ull);
+        atomicAdd(&dsu_sc_stat[3 * lev + 2], (unsigned long long)vol);
+      }
+#endif
+      if ((int)dense != region) {        // uniform: the shared bytes change hands
+        if (region == 0) {               // cache -> tile (the cache was flushed at the end of its item)
+          for (int t = threadIdx.x; t < SC_TILE_CAP * 2; t += blockDim.x) tile[t] = 0ull;
+        } else {                         // tile -> cache (the tile was flushed at the end of its item)
+          for (int t = threadIdx.x; t < SC_SLOTS; t += blockDim.x) {
+            c_keys[t] = GC_EMPTY;
+            c_acc[2 * t] = 0ull;
+            c_acc[2 * t + 1] = 0ull;
+          }
+        }
+        region = (int)dense;
+        __syncthreads();
+      }
+
+      // ---- pass 2: emissions — the offsets that left the centre's cell, then (e = 7) the centre cell
 #pragma unroll 1
-    for (int64_t wbase = w0; wbase < r1; wbase += blockDim.x) {   // wave-uniform trip count
-      const int64_t i = wbase + lane;
-      const bool valid = i < r1;
-      const int64_t ii = valid ? i : last;
-      const float p[3] = {pn[0], pn[1], pn[2]};
-      const int64_t inext = i + blockDim.x < r1 ? i + blockDim.x : last;   // clamped: harmless re-read
-      // The seven evaluations of a point are its centre and six offsets of one finite-difference
-      // step, which is the cell size of the FINEST active level: on every coarser level most of
-      // them fall into the centre's cell and hit the same eight entries.  Their contributions are
-      // summed in registers (`cv`) and emitted once, after the offsets that left the cell:
-      // 2.5-5.6 emissions per point and level instead of 7 (queue entries, LDS atomics and
-      // same-cell merges shrink by a quarter at 4 levels, by more than a third at 6).
-      float cv[16];
-      CellPos ccp;
-      int ckey = 0;
-#pragma unroll 1
-      for (int e = 0; e < 8; ++e) {          // e = 7: the centre cell's accumulated sum
-        CellPos cp;
+      for (int e = 1; e < 8; ++e) {
+        CellPos cp = ccp;
         float v[16];
         bool flush;
         if (e < 7) {
-          float2 d = dn;
-          if (e == 2) {   // wave-uniform: the next chunk's position, four iterations ahead of its use
-            pn[0] = pts[inext * 3]; pn[1] = pts[inext * 3 + 1]; pn[2] = pts[inext * 3 + 2];
+          flush = (left >> e) & 1u;
+          if (__ballot(flush) == 0ull) continue;   // uniform: this offset stayed in the centre cell everywhere
+          float2 d = dv[1];
+#pragma unroll
+          for (int k = 2; k < 7; ++k) {
+            d.x = e == k ? dv[k].x : d.x;
+            d.y = e == k ? dv[k].y : d.y;
           }
-          {
-            const bool wrap = e == 6;
-            const int64_t in_ = wrap ? inext : ii;
-            dn = dinbuf[((size_t)(wrap ? 0 : e + 1) * active + lev) * n + in_];
-          }
-          d.x = valid ? d.x : 0.0f;
-          d.y = valid ? d.y : 0.0f;
           float q[3];
-          fd_point(p, e, eps, radius, q);
-          const float cx = contract(q[0], radius), cy = contract(q[1], radius),
-                      cz = contract(q[2], radius);
-          cp = cell_of(l_scale, cx, cy, cz);
+          fd_point(p, e, eps, radius, q);          // the general form: every coordinate clamped
+          cp = cell_of(l_scale, contract(q[0], radius), contract(q[1], radius), contract(q[2], radius));
 #pragma unroll
           for (int c = 0; c < 8; ++c) {
             const float w = corner_weight(cp, c);
             v[2 * c] = w * d.x;
             v[2 * c + 1] = w * d.y;
           }
-          const int key = (int)(cp.c[0] | (cp.c[1] << 10) | (cp.c[2] << 20));
-          if (e == 0) {                      // wave-uniform
-            ccp = cp;
-            ckey = key;
-#pragma unroll
-            for (int k = 0; k < 16; ++k) cv[k] = v[k];
-            continue;
-          }
-          const bool same = (key == ckey) & (centre_acc != 0);
-#pragma unroll
-          for (int k = 0; k < 16; ++k) cv[k] += same ? v[k] : 0.0f;
-          flush = valid & !same;
-          if (__ballot(flush) == 0ull) continue;   // wave-uniform: every offset stayed in the centre cell
         } else {
-          cp = ccp;
+          const float X[2] = {1.0f - cp.f[0], cp.f[0]}, Y[2] = {1.0f - cp.f[1], cp.f[1]},
+                      Z[2] = {1.0f - cp.f[2], cp.f[2]};
 #pragma unroll
-          for (int k = 0; k < 16; ++k) v[k] = cv[k];
+          for (int c = 0; c < 8; ++c) {
+            const int cx_ = c & 1, cy_ = (c >> 1) & 1, cz_ = (c >> 2) & 1;
+            const float yz = Y[cy_] * Z[cz_], xz = X[cx_] * Z[cz_], xy = X[cx_] * Y[cy_];
+            const float w = X[cx_] * yz;
+            // dw/df_a = +- (product of the other two factors): + on the far side of axis a
+            const float gx = cx_ ? yz : -yz, gy = cy_ ? xz : -xz, gz = cz_ ? xy : -xy;
+            v[2 * c] = fmaf(D0.x, w, fmaf(Da[0].x, gx, fmaf(Da[1].x, gy, Da[2].x * gz)));
+            v[2 * c + 1] = fmaf(D0.y, w, fmaf(Da[0].y, gx, fmaf(Da[1].y, gy, Da[2].y * gz)));
+          }
           flush = valid;
         }
         // lanes with nothing to emit this round: a key no neighbour shares, zero contribution
-        const int key = flush ? (int)(cp.c[0] | (cp.c[1] << 10) | (cp.c[2] << 20))
+        const int key = flush ? (int)((cp.c[0] & 1023u) | ((cp.c[1] & 1023u) << 10) | ((cp.c[2] & 1023u) << 20))
                               : (0x40000000 | lane);
 #pragma unroll
         for (int k = 0; k < 16; ++k) v[k] = flush ? v[k] : 0.0f;
         bool lead = flush;
-        if (lev < merge_levels) {        // wave-uniform
-        const int l15 = lane & 15;
-        // neighbour keys with all lanes active (see the fused kernel: a DPP move under the EXEC
-        // mask of a short-circuit reads disabled source lanes as 0)
+        // Same-cell run merge (segmented sums over the 16-lane DPP rows): worth its ~200
+        // instructions only where neighbouring lanes of the Morton order DO share cells — the
+        // coarse levels.  Where most emitting lanes are alone in their cell (fine levels: more
+        // than three quarters of them start a run) every lane adds its own sum instead; the few
+        // shared cells then take two or three atomics.
         const int key_next = dpp_i<0x101>(key), key_prev = dpp_i<0x111>(key);
-        int ee = ((l15 == 15) | (key_next != key)) ? 1 : 0;   // run ends at this lane
+        const int l15 = lane & 15;
+        const bool starts = ((l15 == 0) | (key_prev != key)) & flush;
+        const int n_flush = __popcll(__ballot(flush)), n_start = __popcll(__ballot(starts));
+        if (lev < merge_levels && 4 * n_start <= 3 * n_flush) {      // uniform
+          // neighbour keys with all lanes active (a DPP move under the EXEC mask of a
+          // short-circuit reads disabled source lanes as 0)
+          int ee = ((l15 == 15) | (key_next != key)) ? 1 : 0;   // run ends at this lane
 #define DSU_SEG_STEP(CTRL)                                              \
-        {                                                               \
-          const int eo = dpp_i<CTRL>(ee);                               \
-          _Pragma("unroll") for (int k = 0; k < 16; ++k) {              \
-            const float vo = dpp_f<CTRL>(v[k]);                         \
-            v[k] += ee ? 0.0f : vo;                                     \
-          }                                                             \
-          ee |= eo;                                                     \
-        }
-        DSU_SEG_STEP(0x101) DSU_SEG_STEP(0x102) DSU_SEG_STEP(0x104) DSU_SEG_STEP(0x108)
+          {                                                             \
+            const int eo = dpp_i<CTRL>(ee);                             \
+            _Pragma("unroll") for (int k = 0; k < 16; ++k) {            \
+              const float vo = dpp_f<CTRL>(v[k]);                       \
+              v[k] += ee ? 0.0f : vo;                                   \
+            }                                                           \
+            ee |= eo;                                                   \
+          }
+          DSU_SEG_STEP(0x101) DSU_SEG_STEP(0x102) DSU_SEG_STEP(0x104) DSU_SEG_STEP(0x108)
 #undef DSU_SEG_STEP
-        // padding lanes (beyond the range) and lanes that emit nothing never lead a run
-        lead = ((l15 == 0) | (key_prev != key)) & flush;
+          // padding lanes (beyond the range) and lanes that emit nothing never lead a run
+          lead = starts;
+        }
+        if (dense) {                     // uniform: straight into the tile
+          if (lead) {
+            const int base = ((int)cp.c[0] - x0) + ((int)cp.c[1] - y0) * ddx + ((int)cp.c[2] - z0) * ddxy;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+              const int t = base + (c & 1) + ((c >> 1) & 1) * ddx + ((c >> 2) & 1) * ddxy;
+              atomicAdd(&tile[2 * t], gc_fix(v[2 * c]));
+              atomicAdd(&tile[2 * t + 1], gc_fix(v[2 * c + 1]));
+            }
+          }
+          continue;
         }
         const unsigned long long bal = __ballot(lead);
         if (lead) {
@@ -1277,22 +1449,34 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
         qn += 8 * __popcll(bal);
         if (qn + 512 > SC_QCAP) drain();
       }
-    }
-    drain();
-    // flush this level: one global atomic pair per touched entry, then reset
-    __syncthreads();
-    for (int t = threadIdx.x; t < SC_SLOTS; t += blockDim.x) {
-      const uint32_t key = c_keys[t];
-      if (key != GC_EMPTY) {
-        unsafeAtomicAdd(gtable + (size_t)key * 2, gc_unfix(c_acc[2 * t]));
-        unsafeAtomicAdd(gtable + (size_t)key * 2 + 1, gc_unfix(c_acc[2 * t + 1]));
-        c_keys[t] = GC_EMPTY;
-        c_acc[2 * t] = 0ull;
-        c_acc[2 * t + 1] = 0ull;
+      if (!dense) drain();               // cache mode: the item's queued contributions
+      __syncthreads();                   // (B) every wave's adds are in (and: see the box words above)
+      if (dense) {
+        // flush the box: one global atomic pair per touched corner, then reset
+        for (int t = threadIdx.x; t < vol; t += blockDim.x) {
+          const unsigned long long a0 = tile[2 * t], a1 = tile[2 * t + 1];
+          if (a0 | a1) {
+            const int z = t / ddxy, rr = t - z * ddxy;
+            const int y = rr / ddx, x = rr - y * ddx;
+            const uint32_t g = l_off + grid_index(l_hashed, hsize, l_res, (uint32_t)(x0 + x),
+                                                  (uint32_t)(y0 + y), (uint32_t)(z0 + z));
+            unsafeAtomicAdd(gtable + (size_t)g * 2, gc_unfix(a0));
+            unsafeAtomicAdd(gtable + (size_t)g * 2 + 1, gc_unfix(a1));
+            tile[2 * t] = 0ull;
+            tile[2 * t + 1] = 0ull;
+          }
+        }
+        // (the next item's adds come after its barrier (A): no barrier needed here)
+      } else {
+        flush_cache();                   // cache mode: this item's entries (the next item may be a tile)
       }
+      cur = nxt;
+      nxt = after_next;
     }
-    __syncthreads();
   }
+#ifdef DSU_AB_SWITCHES
+  if (threadIdx.x == 0 && blockIdx.x < 256) dsu_sc_clk[blockIdx.x * 16 + 15] = wall_clock64() - clk_start;
+#endif
 }
 
 template <int NL>
@@ -1369,6 +1553,22 @@ static bool use_valu(bool forward) {
 }
 
 extern "C" {
+
+#ifdef DSU_AB_SWITCHES
+int dsu_debug_sc_stats(unsigned long long* out48, int reset) {
+  if (hipMemcpyFromSymbol(out48, HIP_SYMBOL(dsu_sc_stat), 48 * sizeof(unsigned long long)) != hipSuccess)
+    return DSU_ELAUNCH;
+  if (reset) {
+    unsigned long long z[48] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(dsu_sc_stat), z, sizeof(z)) != hipSuccess) return DSU_ELAUNCH;
+  }
+  return DSU_OK;
+}
+int dsu_debug_sc_clocks(unsigned long long* out4096) {
+  return hipMemcpyFromSymbol(out4096, HIP_SYMBOL(dsu_sc_clk), 4096 * sizeof(unsigned long long)) == hipSuccess
+             ? DSU_OK : DSU_ELAUNCH;
+}
+#endif
 
 int dsu_sdf_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
                 const float* pts, int64_t n, float radius, uint32_t active_levels,
@@ -1452,7 +1652,8 @@ int64_t dsu_sdf_fd_bwd_workspace_bytes(const dsu_hashgrid_cfg* cfg, int64_t n) {
   const int blocks = dsu_capped_blocks(n, 256, BWD_MFMA_MAX_BLOCKS);
   int64_t bytes = (int64_t)blocks * PART_STRIDE * sizeof(float);
   // split form: + dIn of every (evaluation, point, level) as float2
-  if (bwd_split()) bytes += (int64_t)7 * n * cfg->n_levels * (int64_t)sizeof(float2);
+  // (+ the scatter kernel's work counter behind it)
+  if (bwd_split()) bytes += (int64_t)7 * n * cfg->n_levels * (int64_t)sizeof(float2) + 256;
   return bytes;
 }
 
@@ -1499,7 +1700,7 @@ int dsu_sdf_fd_bwd_sorted_mid(const dsu_hashgrid_cfg* cfg, const void* table_f16
   const int ablate = dsu_ab_int("DSU_BWD_ABLATE", 0);
   if (bwd_split()) {
     const size_t shm1 = (size_t)BWD_CACHE_OFF * sizeof(float);         // no gradient cache
-    const size_t shm2 = (size_t)SC_LDS_F * sizeof(float);
+    const size_t shm2 = (size_t)SC_LDS_TOTAL * sizeof(float);
     float2* dinbuf = reinterpret_cast<float2*>((char*)workspace +
                                                (size_t)blocks * PART_STRIDE * sizeof(float));
     const int sblocks = dsu_capped_blocks(n, SC_THREADS, SC_MAXBLOCKS);
@@ -1523,8 +1724,12 @@ int dsu_sdf_fd_bwd_sorted_mid(const dsu_hashgrid_cfg* cfg, const void* table_f16
       if (merge_lv < 0) merge_lv = dsu_ab_int("DSU_SC_MERGE_LEVELS", 64);
       static int centre_acc = -1;      // DSU_SC_CENTRE=0: every evaluation emitted on its own (A/B)
       if (centre_acc < 0) centre_acc = dsu_ab_int("DSU_SC_CENTRE", 1) != 0;
+      static int dense_lv = -1;        // DSU_SC_DENSE=0 (variant builds): every level through the cache
+      if (dense_lv < 0) dense_lv = dsu_ab_int("DSU_SC_DENSE", 1) != 0;
+      int* work_counter = reinterpret_cast<int*>(dinbuf + (size_t)7 * (size_t)n * cfg->n_levels);
       k2<<<dim3(sblocks), dim3(SC_THREADS), shm2, s>>>(m, pts, n, radius, eps, active_levels,
-                                                      dinbuf, grad_table, merge_lv, centre_acc);
+                                                      dinbuf, grad_table, merge_lv, centre_acc, dense_lv,
+                                                      work_counter);
       reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 63) / 64), dim3(1024), 0, s>>>(
           (const float*)workspace, blocks, g_w0, g_b0, g_w1, g_b1);
     });

@@ -153,6 +153,30 @@ def test_sdf_fd_bwd(dev):
                                    atol=1e-5 * max(np.abs(r).max(), 1.0))
 
 
+def test_sdf_fd_bwd_points_outside_the_box(dev):
+    """Points beyond [-radius, radius] (the perturbed random points of the sparsity / smoothness
+    terms can be): fd_point clamps every coordinate of the six offset evaluations but not the
+    centre (geometry.py:160-171), so the offsets do not share the centre's cell — the scatter's
+    same-cell shortcut must not apply to them."""
+    tab = _table(31, 0.5)
+    mlp = _mlp(32)
+    n = 500
+    pts = _pts(n, 33, -1.25, 1.25)
+    assert int((pts.abs() > 1).any(1).sum()) > 100
+    eps, active, radius = 0.02, 4, 1.0
+    g = torch.Generator().manual_seed(34)
+    d = [torch.randn(n, generator=g), torch.randn(n, 3, generator=g) * 0.1,
+         torch.randn(n, 13, generator=g), torch.randn(n, generator=g) * 1e-3]
+    tab64 = tab.double().requires_grad_(True)
+    mlp64 = [m.double().requires_grad_(True) for m in mlp]
+    _torch_fd_loss(tab64, mlp64, pts.numpy(), eps, active, radius, [x.double() for x in d]).backward()
+    gt, _ = ops.sdf_fd_bwd(CFG, tab.to(dev), [m.to(dev) for m in mlp], pts.to(dev), radius, eps,
+                           active, *[x.to(dev) for x in d])
+    gt = gt.cpu().numpy().reshape(-1, 2)
+    ref_t = tab64.grad.numpy()
+    np.testing.assert_allclose(gt, ref_t, rtol=1e-4, atol=1e-5 * np.abs(ref_t).max())
+
+
 def test_sdf_fd_feature_cache_round_trip(dev):
     """Forward with the feature cache == plain forward (bit for bit); the cache holds exactly
     the forward's f16 features; backward from the cache == backward that re-gathers, up to the
