@@ -47,6 +47,20 @@ __device__ unsigned long long dsu_bwd_prof[16];
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x = hi + mid + O(2^-16 |x|) with hi, mid in bf16 (round to nearest even both times): the operands
+// of the "bf16 x 3" products a b ~ a_hi b_hi + a_hi b_mid + a_mid b_hi (relative error ~2^-15 per
+// product, f32 accumulation) on v_mfma_f32_32x32x16_bf16 — 16x the rate of the f32 MFMA, used for the
+// backward GEMMs only (the forward recompute stays exact f32).
+__device__ __forceinline__ void bf16_split8(const float* x, bf16x8& hi, bf16x8& mid) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 h = (__bf16)x[i];
+    hi[i] = h;
+    mid[i] = (__bf16)(x[i] - (float)h);
+  }
+}
 
 template <int NL>
 struct MC {
@@ -490,6 +504,20 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r)
       w0t[T][r] = l31 < KIN ? w0p<NL>(mlp, feat_of(T, r, h), l31) : 0.0f;
+#ifndef DSU_DIN_F32
+  // dIn^T = W0'^T . dPre^T on the bf16 matrix pipe (bf16 x 3).  The contraction index of one
+  // v_mfma_f32_32x32x16_bf16 is 8 values per lane half: lane (l31, h) supplies k = 8 h + t.  The
+  // 32x32 accumulator layout of dPre already holds, in registers 8 g + t of a lane, hidden units
+  // feat_of(T, 8 g + t, h) of ITS point: they are the B operand as they are (no lane exchange), and
+  // the A operand is w0t[T][8 g + t] of the same lane — W0'[feat_of(T, 8 g + t, h)][k' = l31] —
+  // i.e. the SAME permutation of the contraction index on both sides.  2 tiles x 2 register groups
+  // x 3 products = 12 MFMAs of 32 clocks instead of 32 of 64.
+  bf16x8 w0t_hi[2][2], w0t_mid[2][2];
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int g = 0; g < 2; ++g) bf16_split8(&w0t[T][8 * g], w0t_hi[T][g], w0t_mid[T][g]);
+#endif
   load_w1perm(w1perm, b1s, mlp);
   if (!SPLIT) {
     for (int t = threadIdx.x; t < GC_SLOTS; t += blockDim.x) {
@@ -714,13 +742,28 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
             if (r & 1) din_b = __builtin_amdgcn_mfma_f32_32x32x2f32(w0t[T][r], dpre[r], din_b, 0, 0, 0);
             else din = __builtin_amdgcn_mfma_f32_32x32x2f32(w0t[T][r], dpre[r], din, 0, 0, 0);
           }
-#else
+#elif defined(DSU_DIN_F32)
           if (!DSU_ABL(64))
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             // softplus'(pre) = sigmoid(100 pre) = 1 - exp(-100 softplus(pre))
             dpre[r] *= 1.0f - __builtin_amdgcn_exp2f(Hh[T][r] * -144.26950408889634f);
             din = __builtin_amdgcn_mfma_f32_32x32x2f32(w0t[T][r], dpre[r], din, 0, 0, 0);
+          }
+#else
+          if (!DSU_ABL(64)) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+              // softplus'(pre) = sigmoid(100 pre) = 1 - exp(-100 softplus(pre))
+              dpre[r] *= 1.0f - __builtin_amdgcn_exp2f(Hh[T][r] * -144.26950408889634f);
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              bf16x8 bh, bm;
+              bf16_split8(&dpre[8 * g], bh, bm);
+              din = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_hi[T][g], bh, din, 0, 0, 0);
+              din = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_hi[T][g], bm, din, 0, 0, 0);
+              din = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_mid[T][g], bh, din, 0, 0, 0);
+            }
           }
 #endif
           // dPre of this half's points -> LDS rows [point][hidden] for the W0 gradient GEMM
