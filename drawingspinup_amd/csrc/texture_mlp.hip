@@ -18,6 +18,19 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// x = hi + mid + O(2^-16 |x|), hi and mid in bf16: operands of the "bf16 x 3" products
+// a b ~ a_hi b_hi + a_hi b_mid + a_mid b_hi on v_mfma_f32_32x32x16_bf16 (16x the f32 MFMA's rate),
+// used for the two backward GEMMs whose B operand is an accumulator as it stands (see the kernel)
+__device__ __forceinline__ void bf16_split8(const float* x, bf16x8& hi, bf16x8& mid) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const __bf16 hh = (__bf16)x[i];
+    hi[i] = hh;
+    mid[i] = (__bf16)(x[i] - (float)hh);
+  }
+}
 
 constexpr int TIN = 16, THID = 64, TOUT = 3;
 // LDS layout (floats)
@@ -34,7 +47,13 @@ constexpr int L_WEND = L_B2 + 8;                 // 5576
 constexpr int SD_ROW = 68, SIN_ROW = 20, SDO_ROW = 4;
 constexpr int S_P = 0, S_H = 32 * SD_ROW, S_IN = 2 * 32 * SD_ROW, S_DO = S_IN + 32 * SIN_ROW;
 constexpr int STAGE_F = S_DO + 32 * SDO_ROW;     // 5120
-constexpr int BWD_LDS_F = L_WEND + 4 * STAGE_F;  // 26056 floats = 104 KB
+// bf16 images of the backward GEMMs' weight operands, one 16-byte fragment per lane and MFMA:
+//   W1 image [hi|mid][To][Tin][g][lane] : 8 values t -> w1[feat_of(Tin, 8 g + t, h)][32 To + l31]
+//   W0 image [hi|mid][T][g][lane]       : 8 values t -> w0[feat_of(T, 8 g + t, h)][l31] (0 for l31 >= 16)
+constexpr int IMG1_F = 2 * 8 * 64 * 4, IMG0_F = 2 * 4 * 64 * 4;       // floats (16 B = 4 floats per fragment)
+constexpr int L_IMG1 = L_WEND + 4 * STAGE_F;
+constexpr int L_IMG0 = L_IMG1 + IMG1_F;
+constexpr int BWD_LDS_F = L_IMG0 + IMG0_F;       // 26056 + 6144 floats = 126 KB
 // per-workgroup partial vector
 constexpr int P_GW1 = 0, P_GW0 = 64 * 64, P_GW2 = P_GW0 + 64 * 32, P_GB1 = P_GW2 + 64 * 32,
               P_GB2 = P_GB1 + 64, PART_N = P_GB2 + 3, PART_STRIDE = 8320;
@@ -262,6 +281,27 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
   float* sDo = st + S_DO;
   load_weights(lds, m);
   __syncthreads();
+  {   // bf16 hi / mid fragments of W1 and W0 in the order the backward MFMAs consume them
+    bf16x8* img1 = reinterpret_cast<bf16x8*>(lds + L_IMG1);
+    bf16x8* img0 = reinterpret_cast<bf16x8*>(lds + L_IMG0);
+    for (int f = threadIdx.x; f < 8 * 64; f += blockDim.x) {
+      const int ln = f & 63, c = f >> 6, g = c & 1, Tin = (c >> 1) & 1, To = c >> 2;
+      float w[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        w[t] = lds[L_W1 + feat_of(Tin, 8 * g + t, ln >> 5) * W1_ROW + 32 * To + (ln & 31)];
+      bf16_split8(w, img1[f], img1[8 * 64 + f]);
+    }
+    for (int f = threadIdx.x; f < 4 * 64; f += blockDim.x) {
+      const int ln = f & 63, c = f >> 6, g = c & 1, T = c >> 1;
+      float w[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+        w[t] = (ln & 31) < TIN ? lds[L_W0 + feat_of(T, 8 * g + t, ln >> 5) * W0_ROW + (ln & 31)] : 0.0f;
+      bf16_split8(w, img0[f], img0[4 * 64 + f]);
+    }
+  }
+  __syncthreads();
 
   if (SHADE) {
     for (int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; t < so.tail * 13;
@@ -412,6 +452,7 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
       for (int T = 0; T < 2; ++T)
 #pragma unroll
         for (int r = 0; r < 16; ++r) D0[T][r] = 0.0f;
+#ifdef DSU_TEX_F32
       {   // weight operands one batch of four k-pairs ahead of their MFMAs (see forward_half)
         float a[2][8];
         auto load = [&](int s_, float* dst) {
@@ -435,6 +476,36 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
           }
         }
       }
+#else
+      {   // on the bf16 matrix pipe (bf16 x 3): registers 8 g + t of a lane's dPre1 accumulator hold
+          // units feat_of(Tin, 8 g + t, h) of ITS sample — the B operand of one
+          // v_mfma_f32_32x32x16_bf16 as they stand; the A fragment is W1 in the same order (image
+          // above).  2 x 2 x 2 x 3 = 24 MFMAs of 32 clocks instead of 64 of 64.
+        const bf16x8* img1 = reinterpret_cast<const bf16x8*>(lds + L_IMG1);
+        bf16x8 bh[2][2], bm[2][2];
+#pragma unroll
+        for (int Tin = 0; Tin < 2; ++Tin)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = D1[Tin][8 * g + t];
+            bf16_split8(v, bh[Tin][g], bm[Tin][g]);
+          }
+#pragma unroll
+        for (int To = 0; To < 2; ++To)
+#pragma unroll
+          for (int Tin = 0; Tin < 2; ++Tin)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+              const int f = ((To * 2 + Tin) * 2 + g) * 64 + lane;
+              const bf16x8 ah = img1[f], am = img1[8 * 64 + f];
+              D0[To] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[Tin][g], D0[To], 0, 0, 0);
+              D0[To] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm[Tin][g], D0[To], 0, 0, 0);
+              D0[To] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh[Tin][g], D0[To], 0, 0, 0);
+            }
+      }
+#endif
 #pragma unroll
       for (int T = 0; T < 2; ++T)
 #pragma unroll
@@ -484,6 +555,7 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
       f32x16 din;
 #pragma unroll
       for (int r = 0; r < 16; ++r) din[r] = 0.0f;
+#ifdef DSU_TEX_F32
       {   // same batching for the 32 weight operands of dIn
         float a[2][8];
         const int lc = l31 < TIN ? l31 : 0;
@@ -529,6 +601,26 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
         }
 #endif
       }
+#else
+      {   // bf16 x 3 as above: 2 x 2 x 3 = 12 MFMAs instead of 32
+        const bf16x8* img0 = reinterpret_cast<const bf16x8*>(lds + L_IMG0);
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = D0[T][8 * g + t];
+            bf16x8 bh, bm;
+            bf16_split8(v, bh, bm);
+            const int f = (T * 2 + g) * 64 + lane;
+            const bf16x8 ah = img0[f], am = img0[4 * 64 + f];
+            din = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, din, 0, 0, 0);
+            din = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, din, 0, 0, 0);
+            din = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, din, 0, 0, 0);
+          }
+      }
+#endif
       const int64_t si = wave_first + a * 32 + l31;              // the sample of column l31
       if (si < r1) {
         if (SHADE) {
