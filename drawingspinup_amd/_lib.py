@@ -90,7 +90,8 @@ class NsrStepArgs(C.Structure):                      # dsu_nsr_step_args
                 ("table_p", c_vp), ("table_m", c_vp), ("table_v", c_vp), ("table_n", c_i64),
                 ("table_lr", c_f32), ("table_bc1", c_f32), ("table_bc2_sqrt", c_f32),
                 ("table_eps", c_f32), ("table_wd", c_f32),
-                ("out_n_samples", c_i32), ("out_max_count", c_i32), ("out_next_n_rays", c_i32)]
+                ("out_n_samples", c_i32), ("out_max_count", c_i32), ("out_next_n_rays", c_i32),
+                ("terms_out", c_vp)]
 
 
 _PROTOS = {

@@ -98,6 +98,8 @@ struct SmallArgs {
   // outputs for the next step
   float *w0_eff, *w1_eff, *inv_s;
   float* zero_terms;   // the three sample-loss accumulators of the NEXT step
+  const float* terms;  // this step's eight loss terms ...
+  float* terms_out;    // ... and where the caller wants a copy of them (may be null)
   float lr_geo, lr_tex, lr_var, beta1, beta2, eps, wd, bc1, bc2_sqrt;
   int32_t update;   // 0: forward part only (first call)
 };
@@ -216,6 +218,7 @@ __global__ __launch_bounds__(1024) void small_update_kernel(SmallArgs a) {
       a.d_inv[0] = 0.0f;
     }
     if (t < 3) a.zero_terms[t] = 0.0f;
+    if (t >= 8 && t < 16 && a.terms_out) a.terms_out[t - 8] = a.terms[t - 8];
     __syncthreads();                                   // every read of s_gain / g_tex is done
     if (t < 64) s_gain[t] = new_gain;
     if (t < 13) s_gain[64 + t] = new_gain1;
@@ -460,6 +463,8 @@ int launch_small_update(dsu_nsr_driver* d, const dsu_nsr_step_args* a, int updat
   sa.m = d->L.adam_m; sa.v = d->L.adam_v;
   sa.w0_eff = d->L.w0_eff; sa.w1_eff = d->L.w1_eff; sa.inv_s = d->L.inv_s;
   sa.zero_terms = d->L.terms + 8 * (int)((a->step + 1) & 1) + 4;
+  sa.terms = d->L.terms + 8 * (int)(a->step & 1);
+  sa.terms_out = update ? a->terms_out : nullptr;
   sa.beta1 = c.beta1; sa.beta2 = c.beta2; sa.eps = c.adam_eps; sa.wd = c.weight_decay;
   sa.update = update;
   sa.lr_geo = sa.lr_tex = sa.lr_var = 0.0f;

@@ -702,6 +702,10 @@ class OrthoNeuSSystem:
         a.table_p, a.table_m, a.table_v = enc.params.data_ptr(), topt.m.data_ptr(), topt.v.data_ptr()
         a.table_n, a.table_lr, a.table_bc1, a.table_bc2_sqrt = int(n_tab), lr_tab, bc1, bc2s
         a.table_eps, a.table_wd = float(topt.eps), float(topt.wd)
+        # the step's loss terms come back as a copy in fresh memory (the driver's two sets are reused
+        # two steps later): a result kept across steps must not change under its holder
+        terms_copy = torch.empty(8, dtype=torch.float32, device=self.device)
+        a.terms_out = terms_copy.data_ptr()
         for attempt in range(6):
             rc = drv._lib.lib().dsu_nsr_driver_step(drv.handle, C.byref(a), ops.stream())
             if rc != -3 or a.out_n_samples <= _PACK_CAPACITY or a.n_rays <= 64:
@@ -720,9 +724,7 @@ class OrthoNeuSSystem:
             self.train_num_rays = int(a.out_next_n_rays)
         topt.commit_step(lr_tab)               # the update itself was launched by the driver
         self.global_step += 1
-        # a copy: the driver's two term sets are reused two steps later (and three of the eight
-        # floats are zeroed one step later), a result kept across steps must not change under it
-        t = drv.terms2[(self.global_step - 1) & 1].clone()
+        t = terms_copy
         L = self.config.loss
         terms = {"rgb_mse": t[0]}
         if L.lambda_rgb_l1:

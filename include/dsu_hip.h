@@ -707,6 +707,9 @@ typedef struct dsu_nsr_step_args {
   float table_lr, table_bc1, table_bc2_sqrt, table_eps, table_wd;
   /* outputs (host) */
   int32_t out_n_samples, out_max_count, out_next_n_rays;
+  /* optional: 8 floats of DEVICE memory that receive a copy of this step's loss terms (the
+   * driver's own two sets are reused two steps later); written by the step's last kernel */
+  float* terms_out;
 } dsu_nsr_step_args;
 
 /* The random draws of step `step` (neus_ortho.py:31-41: view / pixel triples of the ray batch;
