@@ -223,12 +223,19 @@ _PROTOS = {
     "dsu_upsample2_fwd": [P, P, c_i64, c_i32, c_i32, P],
     "dsu_upsample2_bwd": [P, P, c_i64, c_i32, c_i32, P],
     "dsu_pair_loss": [P, P, c_f32, c_i64, c_i32, c_f32, P, P, P],
+    "dsu_conv_x3_packed_elems": [c_i32, c_i32, c_i32],
+    "dsu_conv_x3_pack_weights": [P, c_i32, c_i32, c_i32, P, P, P],
+    "dsu_deform_conv3x3_fwd_x3": [P, P, c_i64, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                  P, P, c_i32, P, P, P],
+    "dsu_conv2d_fwd_x3": [P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                          c_i32, P, P, c_i32, P, P, P],
     "dsu_conv2d_fwd": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                        P, P, c_i32, P, P, P],
 }
 
 # return types that are neither an error code nor a byte count
-_RESTYPES = {"dsu_nsr_driver_destroy": None, "dsu_nsr_driver_terms": c_vp}
+_RESTYPES = {"dsu_nsr_driver_destroy": None, "dsu_nsr_driver_terms": c_vp,
+             "dsu_conv_x3_packed_elems": C.c_int64}
 
 _lib = None
 

@@ -625,6 +625,74 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, ep_scale=None, ep_shift=No
     return out
 
 
+class PackedConvWeight:
+    """A convolution weight split into bf16 hi/mid parts in the layout the bf16 x 3 evaluation
+    kernels read (dsu_conv_x3_pack_weights): built on the device, once per weight version."""
+
+    def __init__(self, weight):
+        weight = _f32c(weight.detach())
+        self.O, self.C, self.k, k2 = weight.shape
+        assert self.k == k2
+        self.C8 = (self.C + 7) & ~7      # the kernels read channels in groups of eight
+        n = int(lib().dsu_conv_x3_packed_elems(self.O, self.C, self.k))
+        if n <= 0:
+            raise DsuError("dsu_conv_x3_packed_elems: unsupported shape")
+        self.hi = torch.empty(n, dtype=torch.int16, device=weight.device)
+        self.mid = torch.empty(n, dtype=torch.int16, device=weight.device)
+        check(lib().dsu_conv_x3_pack_weights(ptr(weight), self.O, self.C, self.k, ptr(self.hi),
+                                             ptr(self.mid), stream()), "dsu_conv_x3_pack_weights")
+
+
+def cat_channels8(tensors):
+    """torch.cat(tensors, 1) with zero channels appended up to a multiple of eight (what the
+    bf16 x 3 kernels read; the packed weights of those channels are zero)."""
+    c = sum(t.shape[1] for t in tensors)
+    if c % 8:
+        t0 = tensors[0]
+        z = torch.zeros((t0.shape[0], 8 - c % 8) + tuple(t0.shape[2:]), dtype=t0.dtype,
+                        device=t0.device)
+        tensors = tuple(tensors) + (z,)
+    return torch.cat(tensors, 1)
+
+
+def _channels8(x, packed):
+    if x.shape[1] == packed.C8:
+        return x
+    assert x.shape[1] == packed.C, (x.shape, packed.C)
+    return cat_channels8((x,))
+
+
+def deform_conv3x3_x3(x, offset, packed, ep_scale=None, ep_shift=None, act=None, residual=None,
+                      in_relu=False):
+    """deform_conv3x3 with a PackedConvWeight (bf16 x 3 products, f32 accumulation)."""
+    x, offset = _channels8(_f32c(x), packed), _f32c(offset)
+    B, Cin, H, W = x.shape
+    assert packed.k == 3, "dsu deform conv: 3x3, groups=1 only"
+    bstride = 0 if offset.dim() == 3 or offset.shape[0] == 1 else 18 * H * W
+    out = torch.empty((B, packed.O, H, W), dtype=torch.float32, device=x.device)
+    check(lib().dsu_deform_conv3x3_fwd_x3(ptr(x), ptr(offset), bstride, ptr(packed.hi),
+                                          ptr(packed.mid), B, Cin, H, W, packed.O, int(in_relu),
+                                          ptr(ep_scale), ptr(ep_shift), ACT[act], ptr(residual),
+                                          ptr(out), stream()), "dsu_deform_conv3x3_fwd_x3")
+    return out
+
+
+def conv2d_x3(x, packed, bias=None, stride=1, padding=0, ep_scale=None, ep_shift=None, act=None,
+              residual=None, in_relu=False):
+    """conv2d with a PackedConvWeight (bf16 x 3 products, f32 accumulation)."""
+    x = _channels8(_f32c(x), packed)
+    B, Cin, H, W = x.shape
+    k = packed.k
+    OH = (H + 2 * padding - k) // stride + 1
+    OW = (W + 2 * padding - k) // stride + 1
+    out = torch.empty((B, packed.O, OH, OW), dtype=torch.float32, device=x.device)
+    check(lib().dsu_conv2d_fwd_x3(ptr(x), ptr(packed.hi), ptr(packed.mid), ptr(bias), B, Cin, H, W,
+                                  packed.O, k, stride, padding, int(in_relu), ptr(ep_scale),
+                                  ptr(ep_shift), ACT[act], ptr(residual), ptr(out), stream()),
+          "dsu_conv2d_fwd_x3")
+    return out
+
+
 # ------------------------------------------------------------------ style translator: training
 class DeformPlan:
     """Everything the fixed-offset deformable convolution needs besides the weights, for one

@@ -95,6 +95,35 @@ def _bn_fold(bn):
     return cache[1], cache[2]
 
 
+# Evaluation arithmetic of the generators' convolutions: True = bf16 x 3 products on the bf16 MFMA
+# (style_conv_x3.hip), False = exact f32 products on the f32 MFMA (style_conv.hip; what training
+# always uses).  A module attribute for the A/B tools and tests, not a deployment switch.
+EVAL_X3 = True
+
+
+def _packed(conv):
+    """The convolution's weight in the bf16 x 3 evaluation kernels' layout, cached on the module
+    (rebuilt when the parameter's version or storage changes; dropped by train())."""
+    w = conv.weight
+    ver = (w._version, w.data_ptr(), w.device)
+    cache = getattr(conv, "_dsu_pack", None)
+    if cache is None or cache[0] != ver:
+        conv._dsu_pack = (ver, ops.PackedConvWeight(w))
+        cache = conv._dsu_pack
+    return cache[1]
+
+
+def _cat_in(tensors):
+    """Channel concatenation feeding a convolution (zero channels up to a multiple of eight for
+    the bf16 x 3 kernels; their packed weights are zero there)."""
+    return ops.cat_channels8(tensors) if EVAL_X3 else torch.cat(tensors, 1)
+
+
+def _x3_ok(conv):
+    k, s = conv.kernel_size[0], conv.stride[0]
+    return (k, s) in ((1, 1), (3, 1), (3, 2), (7, 1))
+
+
 def _act_name(m):
     if m is None:
         return None
@@ -157,8 +186,9 @@ class _GeneratorBase(nn.Module):
         bump `Parameter._version`, so `_bn_fold`'s version check alone would keep serving the
         constants of the last evaluation (e.g. Trainer.test_on_full_image every log_interval)."""
         for m in self.modules():
-            if hasattr(m, "_dsu_fold"):
-                del m._dsu_fold
+            for attr in ("_dsu_fold", "_dsu_pack"):
+                if hasattr(m, attr):
+                    delattr(m, attr)
         return super().train(mode)
 
     # ---- constructors with the reference's sub-module names (state_dict keys)
@@ -201,12 +231,22 @@ class _GeneratorBase(nn.Module):
         scale = shift = None
         if bn is not None:
             scale, shift = _bn_fold(bn)
-        w = conv.weight
+        # evaluation: bf16 x 3 MFMA kernels on the packed weight (ops.PackedConvWeight)
+        if not EVAL_X3:
+            if coords is not None:
+                return ops.deform_conv3x3(x, coords, conv.weight, scale, shift, act, residual,
+                                          in_relu)
+            return ops.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], scale,
+                              shift, act, residual, in_relu)
         if coords is not None:
             assert conv.bias is None
-            return ops.deform_conv3x3(x, coords, w, scale, shift, act, residual, in_relu)
-        return ops.conv2d(x, w, conv.bias, conv.stride[0], conv.padding[0], scale, shift, act,
-                          residual, in_relu)
+            return ops.deform_conv3x3_x3(x, coords, _packed(conv), scale, shift, act, residual,
+                                         in_relu)
+        if not _x3_ok(conv):
+            return ops.conv2d(x, conv.weight, conv.bias, conv.stride[0], conv.padding[0], scale,
+                              shift, act, residual, in_relu)
+        return ops.conv2d_x3(x, _packed(conv), conv.bias, conv.stride[0], conv.padding[0], scale,
+                             shift, act, residual, in_relu)
 
     def _check(self, x):
         if not x.is_cuda:
@@ -252,7 +292,7 @@ class GeneratorJ(_GeneratorBase):
             output = self._conv(tmp, layer.conv_1, residual=output)
         output = self._up(self.upconv2, torch.cat((output, output_2), 1))
         output = self._up(self.upconv1, torch.cat((output, output_1), 1))
-        output = self._conv(torch.cat((output, output_0, x), 1), self.conv_11[0], act="relu")
+        output = self._conv(_cat_in((output, output_0, x)), self.conv_11[0], act="relu")
         if self.append_smoothers:
             a = self.conv_11_a
             # conv -> ReLU -> BN -> conv -> ReLU  (BN comes AFTER the ReLU here: models.py:98-104)
@@ -360,7 +400,7 @@ class GeneratorJ_RIC(_GeneratorBase):
         output = self._conv(tmp, self.upconv2[1], self.upconv2[2], "relu", coords=k1)
         tmp = ops.upsample2_fwd(torch.cat((output, output_1), 1))
         output = self._conv(tmp, self.upconv1[1], self.upconv1[2], "relu", coords=k0)
-        output = self._conv(torch.cat((output, output_0, x), 1), self.conv_11[0], act="relu",
+        output = self._conv(_cat_in((output, output_0, x)), self.conv_11[0], act="relu",
                             coords=k0)
         if self.append_smoothers:
             # models.py:347-352: the second smoother convolution takes `output` (the conv_11

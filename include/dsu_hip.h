@@ -415,6 +415,30 @@ int dsu_conv2d_fwd(const float* input, const float* weight, const float* bias, i
                    int32_t pad, int32_t in_relu, const float* ep_scale, const float* ep_shift,
                    int32_t act, const float* residual, float* out, void* stream);
 
+/* Evaluation-time variants of the two convolutions above on the bf16 MFMA with "bf16 x 3"
+ * operands (x = x_hi + x_mid + O(2^-16 |x|); products a_hi b_hi + a_hi b_mid + a_mid b_hi with
+ * f32 accumulation: relative error ~2^-15 per product — finer than the TF32 arithmetic
+ * torch.backends.cudnn.allow_tf32 = True gives the reference's nn.Conv2d by default).  Same
+ * tensors, epilogue and argument meaning; the weight comes packed:
+ *   dsu_conv_x3_packed_elems(O, C, k)   number of uint16 elements of EACH of w_hi / w_mid,
+ *   dsu_conv_x3_pack_weights            (O,C,k,k) f32 -> (roundup(O,32), ceil(C/16), k*k, 16) bf16
+ *                                       hi and mid parts, zero padded; 16-byte aligned buffers.
+ * k in {1,3,7} (stride 2 for k = 3 only); others DSU_EUNSUP.  Used by GeneratorJ / GeneratorJ_RIC
+ * in eval mode (models.py:41-129, :302-351); training keeps the exact-f32 kernels. */
+int64_t dsu_conv_x3_packed_elems(int32_t O, int32_t C, int32_t k);
+int dsu_conv_x3_pack_weights(const float* weight, int32_t O, int32_t C, int32_t k, uint16_t* w_hi,
+                             uint16_t* w_mid, void* stream);
+int dsu_deform_conv3x3_fwd_x3(const float* input, const float* offset, int64_t offset_batch_stride,
+                              const uint16_t* w_hi, const uint16_t* w_mid, int32_t B, int32_t C,
+                              int32_t H, int32_t W, int32_t O, int32_t in_relu,
+                              const float* ep_scale, const float* ep_shift, int32_t act,
+                              const float* residual, float* out, void* stream);
+int dsu_conv2d_fwd_x3(const float* input, const uint16_t* w_hi, const uint16_t* w_mid,
+                      const float* bias, int32_t B, int32_t C, int32_t H, int32_t W, int32_t O,
+                      int32_t k, int32_t stride, int32_t pad, int32_t in_relu,
+                      const float* ep_scale, const float* ep_shift, int32_t act,
+                      const float* residual, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Style translator, per-character TRAINING (3_style_translator/training/trainers.py:140-192:
  * autograd through GeneratorJ / GeneratorJ_RIC, DiscriminatorN_IN and PerceptualVGG19 on

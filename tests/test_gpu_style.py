@@ -89,6 +89,86 @@ def test_conv2d_vs_oracle(dev, k, s, p, C, O, H, W, bias, act):
     torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
 
 
+# ------------------------------------------------------------------ bf16 x 3 evaluation kernels
+# Stated tolerance: 2^-15 relative per product (operands split hi + mid in bf16, three MFMA
+# products, f32 accumulation) -> 1e-4 on these unit-scale outputs, the same bar as the f32 kernels.
+@pytest.mark.parametrize("C,O,H,W", [(6, 32, 32, 32), (32, 64, 24, 40), (128, 128, 16, 16),
+                                     (166, 64, 20, 20), (5, 3, 9, 7), (256, 128, 40, 40),
+                                     (24, 40, 13, 130)])
+def test_deform_conv_x3_vs_oracle(dev, C, O, H, W):
+    x = _rand((2, C, H, W), 1)
+    w = _rand((O, C, 3, 3), 2, 0.1)
+    off = _rand((1, 18, H, W), 3, 1.5)            # includes samples that leave the image
+    pk = ops.PackedConvWeight(w.to(dev))
+    ref = sr.deform_conv2d(x, off.expand(2, -1, -1, -1), w)
+    got = ops.deform_conv3x3_x3(x.to(dev), off[0].to(dev), pk).cpu().double()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    off2 = _rand((2, 18, H, W), 4, 1.0)           # per-image offsets, ReLU on the input
+    ref2 = sr.deform_conv2d(F.relu(x), off2, w)
+    got2 = ops.deform_conv3x3_x3(x.to(dev), off2.to(dev), pk, in_relu=True).cpu().double()
+    torch.testing.assert_close(got2, ref2, rtol=1e-4, atol=1e-4)
+    # against the exact-f32 kernel: the difference is the operand split alone
+    f32 = ops.deform_conv3x3(x.to(dev), off2.to(dev), w.to(dev), in_relu=True).cpu().double()
+    assert float((got2 - f32).abs().max()) <= 3e-5 * float(f32.abs().max())
+
+
+def test_deform_conv_x3_ric_epilogue(dev):
+    H = W = 64
+    x = _rand((1, 64, H, W), 7)
+    w = _rand((128, 64, 3, 3), 8, 0.05)
+    off = sr.generate_coordinates(H, W)
+    scale, shift = _rand((128,), 9).abs() + 0.5, _rand((128,), 10)
+    res = _rand((1, 128, H, W), 11)
+    ref = sr.deform_conv2d(x, off[None], w)
+    ref = F.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)) + res.double()
+    got = ops.deform_conv3x3_x3(x.to(dev), off.to(dev), ops.PackedConvWeight(w.to(dev)),
+                                scale.to(dev), shift.to(dev), "relu", res.to(dev)).cpu().double()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("k,s,p,C,O,H,W,bias,act", [
+    (7, 1, 3, 6, 32, 40, 40, False, "leaky_relu"),
+    (3, 2, 1, 32, 64, 40, 40, False, "leaky_relu"),
+    (3, 2, 1, 64, 128, 21, 19, False, "relu"),
+    (3, 1, 1, 128, 128, 16, 16, False, None),
+    (3, 1, 1, 192, 128, 24, 24, False, "relu"),
+    (3, 1, 1, 200, 72, 50, 50, False, "relu"),
+    (7, 1, 3, 166, 64, 24, 24, False, "relu"),
+    (1, 1, 0, 64, 3, 32, 32, True, "tanh"),
+    (1, 1, 0, 40, 200, 70, 70, True, None),
+])
+def test_conv2d_x3_vs_oracle(dev, k, s, p, C, O, H, W, bias, act):
+    x = _rand((2, C, H, W), 1)
+    w = _rand((O, C, k, k), 2, 1.0 / np.sqrt(C * k * k))
+    b = _rand((O,), 3) if bias else None
+    g, beta = _rand((O,), 4).abs() + 0.5, _rand((O,), 5)
+    mean, var = _rand((O,), 6, 0.1), _rand((O,), 7).abs() + 0.5
+    ref = sr.conv_bn_act(x, w, b, s, p, (g, beta, mean, var, 1e-5), act)
+    scale = g / torch.sqrt(var + 1e-5)
+    shift = beta - mean * scale
+    got = ops.conv2d_x3(x.to(dev), ops.PackedConvWeight(w.to(dev)),
+                        None if b is None else b.to(dev), s, p, scale.to(dev), shift.to(dev),
+                        act).cpu().double()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_conv2d_x3_in_relu_and_residual(dev):
+    x = _rand((3, 48, 37, 29), 1)
+    w = _rand((96, 48, 3, 3), 2, 0.05)
+    res = _rand((3, 96, 37, 29), 3)
+    ref = F.conv2d(F.relu(x).double(), w.double(), padding=1) + res.double()
+    got = ops.conv2d_x3(x.to(dev), ops.PackedConvWeight(w.to(dev)), None, 1, 1, residual=res.to(dev),
+                        in_relu=True).cpu().double()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+
+
+def test_x3_rejects_what_it_does_not_cover(dev):
+    from drawingspinup_amd._lib import DsuError
+    x = _rand((1, 16, 12, 12), 1).to(dev)
+    with pytest.raises(DsuError):          # 4x4 kernels (the discriminator) stay on the f32 path
+        ops.conv2d_x3(x, ops.PackedConvWeight(_rand((8, 16, 4, 4), 2).to(dev)), None, 1, 1)
+
+
 # ------------------------------------------------------------------ whole generators vs golden
 import os  # noqa: E402
 
