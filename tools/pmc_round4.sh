@@ -43,7 +43,7 @@ for path in sorted(glob.glob(os.path.join(out, "*.csv"))):
             tail = v[n // 4:] or v                      # steady state: drop the first quarter
             res[k][c] = sum(tail) / len(tail)
             res[k]["dispatches"] = n
-keep = ("sdf_fd", "reduce_partials", "conv_f16", "conv_igemm", "mv_attention", "gemm_f16", "gn_", "groupnorm",
+keep = ("sdf_fd", "reduce_partials", "conv_f16", "conv_igemm", "conv_x3", "mv_attention", "gemm_f16", "gn_", "groupnorm",
         "layernorm", "geglu", "deform", "style_conv", "texture_", "bin_")
 js = {}
 for k, cs in sorted(res.items()):
