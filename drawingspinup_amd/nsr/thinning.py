@@ -51,7 +51,13 @@ def get_end_points(skeleton):
     pad = np.pad(s, 1)
     cnt = sum(pad[1 + dr:pad.shape[0] - 1 + dr, 1 + dc:pad.shape[1] - 1 + dc]
               for dr in (-1, 0, 1) for dc in (-1, 0, 1))
-    rows, cols = np.nonzero((s > 0) & (cnt == 2))
+    ends = (s > 0) & (cnt == 2)
+    # the reference slices skeleton[row-1:row+2, col-1:col+2]: at row 0 or column 0 the start index
+    # -1 wraps and the slice is EMPTY (count 0), so pixels there are never end points; the last row
+    # / column only lose the neighbours outside the image
+    ends[0, :] = False
+    ends[:, 0] = False
+    rows, cols = np.nonzero(ends)
     return [(int(c), int(r)) for r, c in zip(rows, cols)]
 
 

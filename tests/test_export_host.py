@@ -446,3 +446,29 @@ def test_harmonic_reproduces_the_reference_run(ty):
     want = THIN["thinned_" + ty] - v
     assert np.abs(want).max() > 5e-3
     np.testing.assert_allclose(d, want, rtol=0, atol=1e-9)
+
+
+def test_end_points_at_the_image_border_follow_the_reference_slicing():
+    """thinning_utils.py:11-26 literally (negative start index -> empty neighbourhood at row 0 /
+    column 0; clipped neighbourhood at the last row / column)."""
+    def literal(skeleton):
+        out = []
+        for row, col in np.argwhere(skeleton > 0):
+            nb = skeleton[row - 1:row + 2, col - 1:col + 2]
+            if np.sum(nb) // 255 == 2:
+                out.append((int(col), int(row)))
+        return out
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        sk = np.zeros((12, 15), np.uint8)
+        # a few random strokes, some of them ending on each border
+        for _ in range(4):
+            r, c = int(rng.integers(0, 12)), int(rng.integers(0, 15))
+            if rng.random() < 0.5:
+                sk[r, min(c, 7):] = 255
+            else:
+                sk[:max(r, 3), c] = 255
+        assert T.get_end_points(sk) == literal(sk)
+    sk = np.zeros((6, 6), np.uint8)
+    sk[0, 0:3] = 255; sk[2:6, 5] = 255; sk[5, 0:2] = 255
+    assert T.get_end_points(sk) == literal(sk)
