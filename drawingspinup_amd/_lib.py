@@ -37,6 +37,11 @@ class TexMlp(C.Structure):
                 ("b2", c_vp)]
 
 
+class PartialReduce(C.Structure):                     # dsu_partial_reduce
+    _fields_ = [("partials", c_vp), ("map", c_vp), ("base", c_vp), ("nblocks", c_i32),
+                ("stride", c_i32), ("n", c_i32)]
+
+
 class NormCfg(C.Structure):
     _fields_ = [("batch", c_i32), ("channels", c_i32), ("hw", c_i32), ("instance", c_i32),
                 ("act", c_i32), ("stat_updates", c_i32), ("eps", c_f32), ("momentum", c_f32)]
@@ -117,6 +122,12 @@ _PROTOS = {
                               c_f32, c_u32, P, P, P, P, P, P, P, P, P, P, c_i64, P, P],
     "dsu_sdf_fd_bwd_sorted_mid": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, P, c_i64, c_f32,
                                   c_f32, c_u32, P, P, P, P, P, P, P, P, P, P, c_i64, P, P, P],
+    "dsu_sdf_fd_bwd_sorted_fold": [C.POINTER(HashGridCfg), P, C.POINTER(SdfMlp), P, P, c_i64, c_f32,
+                                   c_f32, c_u32, P, P, P, P, P, P, P, P, P, P, c_i64, P, P,
+                                   C.POINTER(PartialReduce), P],
+    "dsu_texture_partial_map": [P],
+    "dsu_texture_bwd_shaded_partials": [C.POINTER(TexMlp), P, P, P, P, P, c_i64, c_i64, P, P, P, c_i64,
+                                        C.POINTER(PartialReduce), P],
     "dsu_inpaint_telea_u8c3": [P, P, c_i32, c_i32, c_i32, P],
     "dsu_table_adamw": [P, P, P, P, P, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, P],
     "dsu_table_decay": [P, P, c_i64, c_f32, P],

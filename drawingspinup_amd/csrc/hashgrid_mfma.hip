@@ -17,6 +17,7 @@
 // permuting the weight rows instead of the data.  Only the parameter-gradient GEMMs
 // (contraction over points = lanes) go through LDS, 32 points at a time.
 #include "hashgrid_dev.h"
+#include "partial_reduce.h"
 
 #include <stdlib.h>
 #include <string.h>
@@ -1157,12 +1158,72 @@ __device__ unsigned long long dsu_sc_stat[3 * 16];
 __device__ unsigned long long dsu_sc_clk[256 * 16];
 #endif
 
+// Sum of the MLP-part kernel's per-workgroup partial vectors into the reference-layout gradients:
+// 64 elements per workgroup, 16 interleaved slices of the workgroup range, then the slices in order
+// (the same order whatever the block size; `red`: 16 * 64 floats of LDS).
+struct OwnReduce {
+  const float* partials;
+  int nblocks;
+  float *g_w0, *g_b0, *g_w1, *g_b1;
+};
+constexpr int OWN_RED_BLOCKS = (PART_GB1 + NOUT + 63) / 64;
+
+template <int NL>
+__device__ __forceinline__ void reduce_own_block(const OwnReduce& o, int blk, float* red) {
+  const int e = threadIdx.x & 63, g = threadIdx.x >> 6, ng = blockDim.x >> 6;
+  const int v = blk * 64 + e;
+  const bool in_range = v < PART_GB1 + NOUT;
+  for (int sl = g; sl < 16; sl += ng) {
+    float acc = 0.0f;
+    if (in_range)
+      for (int b = sl; b < o.nblocks; b += 16) acc += o.partials[(size_t)b * PART_STRIDE + v];
+    red[sl * 64 + e] = acc;
+  }
+  __syncthreads();
+  if (g != 0 || !in_range) return;
+  float s = 0.0f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) s += red[k * 64 + e];
+  if (v < PART_GW1) {
+    const int feat = v >> 5, k = v & 31;
+    if (k < MC<NL>::KIN) {
+      const int c = ref_col<NL>(k);
+      if (c >= 0) o.g_w0[feat * MC<NL>::DIN + c] += s;
+      else o.g_b0[feat] += s;
+    }
+  } else if (v < PART_GB1) {
+    const int feat = (v - PART_GW1) >> 5, oo = (v - PART_GW1) & 31;
+    if (oo < NOUT) o.g_w1[oo * HID + feat] += s;
+  } else {
+    o.g_b1[v - PART_GB1] += s;
+  }
+}
+
+template <int NL>
+__global__ void reduce_partials_mfma_kernel(OwnReduce o) {
+  __shared__ float red[16 * 64];
+  reduce_own_block<NL>(o, blockIdx.x, red);
+}
+
 template <int NL>
 __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
     GridMeta m, const float* __restrict__ pts, int64_t n, float radius, float eps, uint32_t active,
     const float2* __restrict__ dinbuf, float* __restrict__ gtable, int merge_levels,
-    int centre_acc, int dense_levels, int* __restrict__ work_counter) {
+    int centre_acc, int dense_levels, int* __restrict__ work_counter, OwnReduce own,
+    dsu_partial_reduce extra) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  // The first workgroups of the launch sum partial gradient vectors (the MLP part's own and, when
+  // the caller passes one, another kernel's: partial_reduce.h) and leave; they are dispatched
+  // first, take a few microseconds, and the scatter workgroups that inherit their slots lose
+  // nothing because the scatter's work items are handed out dynamically.
+  const int n_red_own = own.partials ? OWN_RED_BLOCKS : 0;
+  const int n_red = n_red_own + (extra.partials ? dsu_red::blocks_of(extra) : 0);
+  if ((int)blockIdx.x < n_red) {
+    if ((int)blockIdx.x < n_red_own) reduce_own_block<NL>(own, blockIdx.x, lds);
+    else dsu_red::reduce_block(extra, blockIdx.x - n_red_own, lds);
+    return;
+  }
+  const int sc_block = (int)blockIdx.x - n_red, sc_grid = (int)gridDim.x - n_red;
   uint32_t* c_keys = reinterpret_cast<uint32_t*>(lds);
   unsigned long long* c_acc = reinterpret_cast<unsigned long long*>(lds + SC_SLOTS);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1195,7 +1256,7 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
   const int64_t n_chunks = (n + blockDim.x - 1) / blockDim.x;
   const int64_t n_items = n_chunks * (int64_t)active;
   int* next_slot = reinterpret_cast<int*>(lds + SC_BBOX_OFF) + 12;   // the item after next, via LDS
-  int64_t cur = blockIdx.x, nxt = (int64_t)blockIdx.x + gridDim.x;
+  int64_t cur = sc_block, nxt = (int64_t)sc_block + sc_grid;
   float pn[3] = {0.f, 0.f, 0.f};       // position and the seven dIn pairs of the NEXT item to process
   float2 dnx[7];
 #pragma unroll
@@ -1264,7 +1325,7 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
         dv[e].y = valid ? dnx[e].y : 0.0f;
       }
       if (nxt < n_items) request(nxt);   // uniform: the next item's loads, a whole item ahead
-      if (threadIdx.x == 0) *next_slot = (int)(2 * gridDim.x) + atomicAdd(work_counter, 1);
+      if (threadIdx.x == 0) *next_slot = 2 * sc_grid + atomicAdd(work_counter, 1);
       // ---- pass 1 (straight line): the centre's cell, which offsets stay in it, their sums.
       // The interpolation weight of a corner is MULTILINEAR in the position inside the cell and an
       // offset evaluation moves ONE coordinate: for an offset that stays in the centre's cell
@@ -1518,41 +1579,8 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
     }
   }
 #ifdef DSU_AB_SWITCHES
-  if (threadIdx.x == 0 && blockIdx.x < 256) dsu_sc_clk[blockIdx.x * 16 + 15] = wall_clock64() - clk_start;
+  if (threadIdx.x == 0 && sc_block < 256) dsu_sc_clk[sc_block * 16 + 15] = wall_clock64() - clk_start;
 #endif
-}
-
-template <int NL>
-__global__ void reduce_partials_mfma_kernel(const float* __restrict__ partials, int nblocks,
-                                            float* __restrict__ g_w0, float* __restrict__ g_b0,
-                                            float* __restrict__ g_w1, float* __restrict__ g_b1) {
-  // 64 elements x 16 slices of the workgroup range per 1024-thread workgroup
-  __shared__ float red[16][64];
-  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-  const int v = blockIdx.x * 64 + e;
-  const bool in_range = v < PART_GB1 + NOUT;
-  float acc = 0.0f;
-  if (in_range)
-    for (int b = sl; b < nblocks; b += 16) acc += partials[(size_t)b * PART_STRIDE + v];
-  red[sl][e] = acc;
-  __syncthreads();
-  if (sl != 0 || !in_range) return;
-  float s = 0.0f;
-#pragma unroll
-  for (int k = 0; k < 16; ++k) s += red[k][e];
-  if (v < PART_GW1) {
-    const int feat = v >> 5, k = v & 31;
-    if (k < MC<NL>::KIN) {
-      const int c = ref_col<NL>(k);
-      if (c >= 0) g_w0[feat * MC<NL>::DIN + c] += s;
-      else g_b0[feat] += s;
-    }
-  } else if (v < PART_GB1) {
-    const int feat = (v - PART_GW1) >> 5, o = (v - PART_GW1) & 31;
-    if (o < NOUT) g_w1[o * HID + feat] += s;
-  } else {
-    g_b1[v - PART_GB1] += s;
-  }
 }
 
 constexpr int BWD_MFMA_MAX_BLOCKS = 256;   // one workgroup per CU (458 registers: one wave per SIMD)
@@ -1718,6 +1746,24 @@ int dsu_sdf_fd_bwd_sorted_mid(const dsu_hashgrid_cfg* cfg, const void* table_f16
                               const float* d_laplace, float* grad_table, float* g_w0, float* g_b0,
                               float* g_w1, float* g_b1, void* workspace, int64_t workspace_bytes,
                               const void* enc_cache, void* mid_event, void* stream) {
+  return dsu_sdf_fd_bwd_sorted_fold(cfg, table_f16, mlp, pts, perm, n, radius, eps, active_levels,
+                                    d_sdf, d_grad, d_feature, d_laplace, grad_table, g_w0, g_b0, g_w1,
+                                    g_b1, workspace, workspace_bytes, enc_cache, mid_event, nullptr,
+                                    stream);
+}
+
+int dsu_sdf_fd_bwd_sorted_fold(const dsu_hashgrid_cfg* cfg, const void* table_f16,
+                               const dsu_sdf_mlp* mlp, const float* pts, const int32_t* perm,
+                               int64_t n, float radius, float eps, uint32_t active_levels,
+                               const float* d_sdf, const float* d_grad, const float* d_feature,
+                               const float* d_laplace, float* grad_table, float* g_w0, float* g_b0,
+                               float* g_w1, float* g_b1, void* workspace, int64_t workspace_bytes,
+                               const void* enc_cache, void* mid_event,
+                               const dsu_partial_reduce* extra, void* stream) {
+  if (extra && (!extra->partials || !extra->map || !extra->base || extra->nblocks < 0 ||
+                extra->n <= 0 || extra->stride < extra->n))
+    return DSU_EINVAL;
+  if (extra && (use_valu(false) || !bwd_split() || n == 0)) return DSU_EUNSUP;
   if (use_valu(false) && perm) return DSU_EUNSUP;
   if (use_valu(false))
     return dsu_sdf_fd_bwd_valu(cfg, table_f16, mlp, pts, n, radius, eps, active_levels, d_sdf,
@@ -1770,11 +1816,14 @@ int dsu_sdf_fd_bwd_sorted_mid(const dsu_hashgrid_cfg* cfg, const void* table_f16
       static int dense_lv = -1;        // DSU_SC_DENSE=0 (variant builds): every level through the cache
       if (dense_lv < 0) dense_lv = dsu_ab_int("DSU_SC_DENSE", 1) != 0;
       int* work_counter = reinterpret_cast<int*>(dinbuf + (size_t)7 * (size_t)n * cfg->n_levels);
-      k2<<<dim3(sblocks), dim3(SC_THREADS), shm2, s>>>(m, pts, n, radius, eps, active_levels,
-                                                      dinbuf, grad_table, merge_lv, centre_acc, dense_lv,
-                                                      work_counter);
-      reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 63) / 64), dim3(1024), 0, s>>>(
-          (const float*)workspace, blocks, g_w0, g_b0, g_w1, g_b1);
+      // the partial sums ride in the scatter launch (its first workgroups): no launches of their own
+      const OwnReduce own{(const float*)workspace, blocks, g_w0, g_b0, g_w1, g_b1};
+      dsu_partial_reduce ext{};
+      if (extra) ext = *extra;
+      const int n_red = OWN_RED_BLOCKS + (extra ? dsu_red::blocks_of(ext) : 0);
+      k2<<<dim3(n_red + sblocks), dim3(SC_THREADS), shm2, s>>>(m, pts, n, radius, eps, active_levels,
+                                                              dinbuf, grad_table, merge_lv, centre_acc,
+                                                              dense_lv, work_counter, own, ext);
     });
     DSU_CHECK_LAUNCH();
     return DSU_OK;
@@ -1790,8 +1839,8 @@ int dsu_sdf_fd_bwd_sorted_mid(const dsu_hashgrid_cfg* cfg, const void* table_f16
         (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
         d_grad, d_feature, d_laplace, grad_table, (float*)workspace, (const __half2*)enc_cache,
         nullptr, perm, ablate);
-    reduce_partials_mfma_kernel<NL><<<dim3((PART_GB1 + NOUT + 63) / 64), dim3(1024), 0, s>>>(
-        (const float*)workspace, blocks, g_w0, g_b0, g_w1, g_b1);
+    reduce_partials_mfma_kernel<NL><<<dim3(OWN_RED_BLOCKS), dim3(1024), 0, s>>>(
+        OwnReduce{(const float*)workspace, blocks, g_w0, g_b0, g_w1, g_b1});
   });
   DSU_CHECK_LAUNCH();
   return DSU_OK;

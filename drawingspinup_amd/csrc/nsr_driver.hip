@@ -19,6 +19,7 @@
 // occupancy grid and the RNG, not on the parameters), and hand the sample total to the host
 // through pinned memory.  All device memory is the caller's: one workspace carved here.
 #include "common.h"
+#include "adamw_dev.h"
 
 #include <math.h>
 #include <string.h>
@@ -114,7 +115,15 @@ __device__ __forceinline__ void adamw_elem(float& x, float g, float& m, float& v
   x -= (lr / a.bc1) * m / denom;
 }
 
-__global__ __launch_bounds__(1024) void small_update_kernel(SmallArgs a) {
+// Workgroup 0: the small tensors (below).  Workgroups 1..: AdamW of the hash table's active levels
+// (adamw_dev.h) — the two used to be consecutive launches (9 + 18 us); side by side the table update
+// disappears behind the single-workgroup chain.
+__global__ __launch_bounds__(1024) void small_update_kernel(SmallArgs a, dsu_table_adamw_args ta) {
+  if (blockIdx.x > 0) {
+    dsu_table_adamw_range(ta, (int64_t)(blockIdx.x - 1) * 1024 + threadIdx.x,
+                          (int64_t)(gridDim.x - 1) * 1024);
+    return;
+  }
   // Everything the kernel touches more than once sits in LDS: the first version walked the rows of
   // the weight-norm reductions with dependent global loads from 77 threads (36 us per step for
   // 8 k elements of work).
@@ -277,6 +286,7 @@ struct Layout {
   float *normal, *rgb, *alpha, *w, *comp, *d_comp, *terms;
   float *d_sdf_all, *d_grad_all, *d_feat_all, *d_normal, *d_rgb;
   void *tex_ws, *sdf_ws;
+  int32_t* tex_map;                   // dsu_texture_partial_map, uploaded at creation
   float *g_geo, *g_tex, *d_inv;      // contiguous: zeroed as one block
   float *w0_eff, *w1_eff, *inv_s, *adam_m, *adam_v;
   int64_t tex_ws_bytes, sdf_ws_bytes, sort_ws_bytes, enc_cache_bytes, total;
@@ -322,6 +332,7 @@ int carve(const dsu_nsr_driver_cfg& c, char* base, Layout& L) {
   L.d_normal = k.take<float>(N * 3); L.d_rgb = k.take<float>(N * 3);
   L.tex_ws = k.take<char>(L.tex_ws_bytes > 4 ? L.tex_ws_bytes : 4);
   L.sdf_ws = k.take<char>(L.sdf_ws_bytes > 4 ? L.sdf_ws_bytes : 4);
+  L.tex_map = k.take<int32_t>(dsu_texture_partial_map(nullptr));
   L.g_geo = k.take<float>(N_GEO + N_TEX + 1);
   L.g_tex = L.g_geo ? L.g_geo + N_GEO : nullptr;
   L.d_inv = L.g_geo ? L.g_geo + N_GEO + N_TEX : nullptr;
@@ -349,6 +360,7 @@ struct dsu_nsr_driver {
   hipEvent_t ready[3] = {nullptr, nullptr, nullptr};   // side: set packed, stats copied to the host
   hipEvent_t gate = nullptr;                           // main: MLP part of the latest backward done
   hipEvent_t fwd_done = nullptr;                       // main: this step's geometry forward done
+  bool fold = true;                 // DSU_NSR_FOLD (variant builds)
   bool side_high_priority = true;   // DSU_NSR_SIDE_PRIO
   int pack_gate = 1;                // DSU_NSR_PACK_GATE: 0 with the march, 1 behind this step's geometry
                                     // forward (own event), 2 behind the MLP part of this step's backward
@@ -474,7 +486,24 @@ int launch_small_update(dsu_nsr_driver* d, const dsu_nsr_step_args* a, int updat
     sa.bc1 = (float)(1.0 - pow((double)c.beta1, (double)a->adam_step));
     sa.bc2_sqrt = (float)sqrt(1.0 - pow((double)c.beta2, (double)a->adam_step));
   }
-  small_update_kernel<<<dim3(1), dim3(1024), 0, s>>>(sa);
+  // ... and the hash table (active levels; level / decay bookkeeping is the caller's)
+  dsu_table_adamw_args ta{};
+  int table_blocks = 0;
+  if (update && a->table_p && !d->fold) {
+    DSU_TRY(dsu_table_adamw(a->table_p, a->table_grad, a->table_m, a->table_v,
+                            const_cast<void*>(a->table_img), a->table_n, a->table_lr, c.beta1, c.beta2,
+                            a->table_eps, a->table_wd, a->table_bc1, a->table_bc2_sqrt, s));
+  } else if (update && a->table_p) {
+    if (a->table_n < 0 || (a->table_n & 3) || !a->table_grad || !a->table_m || !a->table_v ||
+        !a->table_img || !(a->table_bc1 > 0.0f) || !(a->table_bc2_sqrt > 0.0f))
+      return DSU_EINVAL;
+    ta = dsu_table_adamw_args{(float4*)a->table_p, (float4*)a->table_grad, (float4*)a->table_m,
+                              (float4*)a->table_v, (__half2*)const_cast<void*>(a->table_img),
+                              a->table_n / 4, a->table_lr, c.beta1, c.beta2, a->table_eps,
+                              a->table_wd, a->table_bc1, a->table_bc2_sqrt};
+    table_blocks = (int)((ta.n4 + 1023) / 1024 < 512 ? (ta.n4 + 1023) / 1024 : 512);
+  }
+  small_update_kernel<<<dim3(1 + table_blocks), dim3(1024), 0, s>>>(sa, ta);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }
@@ -523,9 +552,19 @@ int dsu_nsr_driver_create(const dsu_nsr_driver_cfg* cfg, dsu_nsr_driver** out) {
     d->aabb[3 + k] = cfg->radius;
   }
   d->rowcap = march_row_capacity(cfg->radius, cfg->render_step_size);
+  {
+    std::vector<int32_t> map((size_t)dsu_texture_partial_map(nullptr));
+    dsu_texture_partial_map(map.data());
+    if (hipMemcpy(d->L.tex_map, map.data(), map.size() * sizeof(int32_t), hipMemcpyHostToDevice) !=
+        hipSuccess) {
+      delete d;
+      return DSU_ELAUNCH;
+    }
+  }
   int lo = 0, hi = 0;
   d->side_high_priority = dsu_ab_int("DSU_NSR_SIDE_PRIO", 1) != 0;
   d->pack_gate = dsu_ab_int("DSU_NSR_PACK_GATE", 1);
+  d->fold = dsu_ab_int("DSU_NSR_FOLD", 1) != 0;
   bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
             hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking,
                                         d->side_high_priority ? hi : lo) == hipSuccess;
@@ -692,16 +731,30 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
   DSU_TRY(dsu_ray_losses(L.comp, f.rgb, f.normal, f.mask, f.cosines, f.vw, a->n_rays, &c.ray_loss,
                          terms, L.d_comp, s));
   // ---- backward
+  dsu_partial_reduce tex_red{};
+  bool have_tex_red = false;
   if (n_s > 0) {
     DSU_TRY(dsu_neus_composite_bwd(L.a_sdf, L.normal, L.rgb, f.rays_d, f.t_starts, f.t_ends,
                                    f.offsets, f.counts, a->n_rays, L.inv_s, a->cos_anneal_ratio,
                                    L.alpha, L.w, L.d_comp, nullptr, L.d_sdf_all, L.d_normal, L.d_rgb,
                                    L.d_inv, s));
     dsu_tex_mlp tex{c.tex[0], c.tex[1], c.tex[2], c.tex[3], c.tex[4], c.tex[5]};
-    float* gt = L.g_tex;
-    DSU_TRY(dsu_texture_bwd_shaded(&tex, L.a_feat, L.a_grad, L.rgb, L.d_rgb, L.d_normal, n_s, 2 * n_r,
-                                   L.d_grad_all, L.d_feat_all, gt, gt + 1024, gt + 1088, gt + 5184,
-                                   gt + 5248, gt + 5440, L.tex_ws, L.tex_ws_bytes, s));
+    // parameter gradients of the texture MLP: per-workgroup partials now, summed into g_tex by
+    // extra workgroups of the geometry backward's scatter launch (no launch of their own;
+    // DSU_NSR_FOLD=0 in variant builds: the separate reduction and table-AdamW launches, for A/B)
+    if (!d->fold) {
+      float* gt = L.g_tex;
+      DSU_TRY(dsu_texture_bwd_shaded(&tex, L.a_feat, L.a_grad, L.rgb, L.d_rgb, L.d_normal, n_s, 2 * n_r,
+                                     L.d_grad_all, L.d_feat_all, gt, gt + 1024, gt + 1088, gt + 5184,
+                                     gt + 5248, gt + 5440, L.tex_ws, L.tex_ws_bytes, s));
+    } else {
+    DSU_TRY(dsu_texture_bwd_shaded_partials(&tex, L.a_feat, L.a_grad, L.rgb, L.d_rgb, L.d_normal, n_s,
+                                            2 * n_r, L.d_grad_all, L.d_feat_all, L.tex_ws,
+                                            L.tex_ws_bytes, &tex_red, s));
+    tex_red.map = L.tex_map;
+    tex_red.base = L.g_tex;
+    have_tex_red = true;
+    }
   } else {
     DSU_HIP(hipMemsetAsync(L.d_feat_all, 0, (size_t)(2 * n_r) * 13 * sizeof(float), s));
   }
@@ -710,11 +763,11 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
                             terms + 4, s));
   float* gg = L.g_geo;
   DSU_TRY(mark(d, 1, s));
-  DSU_TRY(dsu_sdf_fd_bwd_sorted_mid(&c.grid, a->table_img, &mlp, pts, perm, n_all, c.radius, a->eps,
-                                a->active_levels, L.d_sdf_all, L.d_grad_all, L.d_feat_all, nullptr,
-                                a->table_grad, gg, gg + 64 * 23, gg + 64 * 23 + 64,
-                                gg + 64 * 23 + 64 + 13 * 64, L.sdf_ws, L.sdf_ws_bytes, L.enc_cache,
-                                    d->gate, s));
+  DSU_TRY(dsu_sdf_fd_bwd_sorted_fold(&c.grid, a->table_img, &mlp, pts, perm, n_all, c.radius, a->eps,
+                                     a->active_levels, L.d_sdf_all, L.d_grad_all, L.d_feat_all, nullptr,
+                                     a->table_grad, gg, gg + 64 * 23, gg + 64 * 23 + 64,
+                                     gg + 64 * 23 + 64 + 13 * 64, L.sdf_ws, L.sdf_ws_bytes,
+                                     L.enc_cache, d->gate, have_tex_red ? &tex_red : nullptr, s));
   DSU_TRY(mark(d, 1, s));
   if (d->timing) d->work[1] += alg_bytes;
   if (a->prefetch_next && d->pack_gate == 2) {
@@ -727,12 +780,7 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
     DSU_HIP(hipEventRecord(d->ready[q], d->side));
     d->pf_valid[q] = true;
   }
-  // ---- optimizer: the hash table (active levels; level / decay bookkeeping is the caller's) ...
-  if (a->table_p)
-    DSU_TRY(dsu_table_adamw(a->table_p, a->table_grad, a->table_m, a->table_v,
-                            const_cast<void*>(a->table_img), a->table_n, a->table_lr, c.beta1, c.beta2,
-                            a->table_eps, a->table_wd, a->table_bc1, a->table_bc2_sqrt, s));
-  // ... and the small tensors
+  // ---- optimizer: the hash table and the small tensors in one launch
   DSU_TRY(launch_small_update(d, a, 1, s));
   d->last_step = a->step;
   guard.ok = true;

@@ -10,6 +10,7 @@
 //   sample_losses_kernel  eikonal / sparsity / 3-D normal smoothness and their gradients
 //   ray_offsets_kernel    exclusive scan of the per-ray sample counts + (total, max)
 #include "common.h"
+#include "adamw_dev.h"
 #include <math.h>
 
 namespace {
@@ -448,32 +449,9 @@ __global__ __launch_bounds__(256) void ortho_ray_batch_kernel(
 // over all 3.8 M entries, 80 % of which belong to levels the progressive schedule has not
 // switched on yet and only see `p *= 1 - lr * wd`: that factor is applied lazily by
 // table_decay_kernel when a level is switched on / at the end).
-__global__ __launch_bounds__(256) void table_adamw_kernel(
-    float4* __restrict__ p, float4* __restrict__ g, float4* __restrict__ m, float4* __restrict__ v,
-    __half2* __restrict__ img, int64_t n4, float lr, float beta1, float beta2, float eps, float wd,
-    float bc1, float bc2_sqrt) {
-  const float step_size = lr / bc1;
-  // 1 - beta from the double values torch uses (1 - 0.99f is 9.5e-7 off 0.01)
-  const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    float4 P = p[i], G = g[i], M = m[i], V = v[i];
-    float* pp = &P.x; float* gg = &G.x; float* mm = &M.x; float* vv = &V.x;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      float x = pp[k];
-      x -= lr * wd * x;
-      const float mk = mm[k] + (gg[k] - mm[k]) * omb1;                  // lerp, as torch
-      const float vk = beta2 * vv[k] + omb2 * gg[k] * gg[k];
-      const float denom = sqrtf(vk) / bc2_sqrt + eps;
-      x -= step_size * mk / denom;
-      pp[k] = x; mm[k] = mk; vv[k] = vk;
-    }
-    p[i] = P; m[i] = M; v[i] = V;
-    g[i] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    img[2 * i] = __floats2half2_rn(P.x, P.y);
-    img[2 * i + 1] = __floats2half2_rn(P.z, P.w);
-  }
+__global__ __launch_bounds__(256) void table_adamw_kernel(dsu_table_adamw_args a) {
+  dsu_table_adamw_range(a, blockIdx.x * (int64_t)blockDim.x + threadIdx.x,
+                        (int64_t)gridDim.x * blockDim.x);
 }
 
 // torch.optim.AdamW for the model's small tensors (SDF MLP, texture MLP, variance: 13 tensors of
@@ -524,8 +502,9 @@ int dsu_table_adamw(float* p, float* g, float* m, float* v, void* img_f16, int64
   if (!(bias_correction1 > 0.0f) || !(bias_correction2_sqrt > 0.0f)) return DSU_EINVAL;
   if (n == 0) return DSU_OK;
   table_adamw_kernel<<<dsu_capped_blocks(n / 4, 256, 2048), 256, 0, (hipStream_t)stream>>>(
-      (float4*)p, (float4*)g, (float4*)m, (float4*)v, (__half2*)img_f16, n / 4, lr, beta1, beta2,
-      eps, weight_decay, bias_correction1, bias_correction2_sqrt);
+      dsu_table_adamw_args{(float4*)p, (float4*)g, (float4*)m, (float4*)v, (__half2*)img_f16, n / 4,
+                           lr, beta1, beta2, eps, weight_decay, bias_correction1,
+                           bias_correction2_sqrt});
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }

@@ -805,4 +805,57 @@ int dsu_texture_bwd_shaded(const dsu_tex_mlp* mlp, const float* feature, const f
   return DSU_OK;
 }
 
+int32_t dsu_texture_partial_map(int32_t* map_host) {
+  if (map_host) {
+    // offsets into one contiguous gradient block [w0 (64,16) | b0 | w1 (64,64) | b1 | w2 (3,64) | b2]
+    constexpr int O_W0 = 0, O_B0 = THID * TIN, O_W1 = O_B0 + THID, O_B1 = O_W1 + THID * THID,
+                  O_W2 = O_B1 + THID, O_B2 = O_W2 + TOUT * THID;
+    for (int v = 0; v < PART_N; ++v) {
+      int d = -1;
+      if (v < P_GW0) {
+        d = O_W1 + v;
+      } else if (v < P_GW2) {
+        const int i = (v - P_GW0) >> 5, k = (v - P_GW0) & 31;
+        if (k < TIN) d = O_W0 + i * TIN + k;
+        else if (k == TIN) d = O_B0 + i;
+      } else if (v < P_GB1) {
+        const int i = (v - P_GW2) >> 5, o = (v - P_GW2) & 31;
+        if (o < TOUT) d = O_W2 + o * THID + i;
+      } else if (v < P_GB2) {
+        d = O_B1 + (v - P_GB1);
+      } else {
+        d = O_B2 + (v - P_GB2);
+      }
+      map_host[v] = d;
+    }
+  }
+  return PART_N;
+}
+
+int dsu_texture_bwd_shaded_partials(const dsu_tex_mlp* mlp, const float* feature, const float* grad,
+                                    const float* rgb, const float* d_rgb, const float* d_normal,
+                                    int64_t n, int64_t tail_rows, float* d_grad, float* d_feature,
+                                    void* workspace, int64_t workspace_bytes,
+                                    dsu_partial_reduce* red, void* stream) {
+  if (!mlp_ok(mlp) || n < 0 || !red) return DSU_EINVAL;
+  if (tail_rows < 0 || (n && (!feature || !grad || !rgb || !d_rgb || !d_grad || !d_feature)))
+    return DSU_EINVAL;
+  if (n == 0) return DSU_EUNSUP;                    // the caller zeroes the tail itself
+  const int64_t need = dsu_texture_bwd_workspace_bytes(n);
+  if (!workspace || workspace_bytes < need) return DSU_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = dsu_capped_blocks(n, 256, TEX_MAX_BLOCKS);
+  const size_t shm = (size_t)BWD_LDS_F * sizeof(float);
+  DSU_ENSURE_DYN_LDS(texture_bwd_kernel<true>, shm);
+  texture_bwd_kernel<true><<<blocks, 256, shm, s>>>(*mlp, nullptr, ShadeIn{feature, grad},
+                                                   ShadeOut{d_normal, d_grad, d_feature, tail_rows}, rgb, d_rgb,
+                                                   n, nullptr, (float*)workspace);
+  DSU_CHECK_LAUNCH();
+  red->partials = (const float*)workspace;
+  red->nblocks = blocks;
+  red->stride = PART_STRIDE;
+  red->n = PART_N;
+  return DSU_OK;
+}
+
 }  // extern "C"

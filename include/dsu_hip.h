@@ -173,6 +173,17 @@ int dsu_sdf_fd_bwd_sorted(const dsu_hashgrid_cfg* cfg, const void* table_f16,
                           float* g_w1, float* g_b1, void* workspace, int64_t workspace_bytes,
                           const void* enc_cache, void* stream);
 
+/* A deferred sum of per-workgroup partial vectors: element v of the result is
+ * sum_b partials[b * stride + v] (b < nblocks, v < n), added to base[map[v]] (map[v] < 0: a padding
+ * element, dropped).  The partial reductions of the backward kernels are carried out by extra
+ * workgroups of the scatter launch of dsu_sdf_fd_bwd_sorted_fold instead of launches of their own. */
+typedef struct dsu_partial_reduce {
+  const float* partials;
+  const int32_t* map;   /* device, n entries */
+  float* base;
+  int32_t nblocks, stride, n;
+} dsu_partial_reduce;
+
 /* dsu_sdf_fd_bwd_sorted with a hipEvent_t (as void*, may be NULL) recorded on `stream` between the
  * two kernels of the backward: behind the MLP part, which occupies every SIMD with one
  * 458-register wave, and in front of the table-gradient scatter, which leaves room.  Work a caller
@@ -184,6 +195,19 @@ int dsu_sdf_fd_bwd_sorted_mid(const dsu_hashgrid_cfg* cfg, const void* table_f16
                               const float* d_laplace, float* grad_table, float* g_w0, float* g_b0,
                               float* g_w1, float* g_b1, void* workspace, int64_t workspace_bytes,
                               const void* enc_cache, void* mid_event, void* stream);
+
+/* dsu_sdf_fd_bwd_sorted_mid whose scatter launch also carries out `extra` (may be NULL), a deferred
+ * partial sum of ANOTHER kernel that precedes this call on `stream` (the native NSR step passes the
+ * texture backward's: dsu_texture_bwd_shaded_partials).  The backward's own partial sums always
+ * ride in that launch.  DSU_EUNSUP with `extra` on the fused / VALU variants. */
+int dsu_sdf_fd_bwd_sorted_fold(const dsu_hashgrid_cfg* cfg, const void* table_f16,
+                               const dsu_sdf_mlp* mlp, const float* pts_sorted, const int32_t* perm,
+                               int64_t n, float radius, float eps, uint32_t active_levels,
+                               const float* d_sdf, const float* d_grad, const float* d_feature,
+                               const float* d_laplace, float* grad_table, float* g_w0, float* g_b0,
+                               float* g_w1, float* g_b1, void* workspace, int64_t workspace_bytes,
+                               const void* enc_cache, void* mid_event,
+                               const dsu_partial_reduce* extra, void* stream);
 
 /* Bytes of device scratch dsu_sdf_fd_bwd needs for n points (per-workgroup partial MLP
  * gradients, summed by a second kernel: deterministic, no same-address atomics).  <0 = error. */
@@ -332,6 +356,19 @@ int dsu_texture_bwd_shaded(const dsu_tex_mlp* mlp, const float* feature, const f
                            int64_t tail_rows, float* d_grad, float* d_feature, float* g_w0,
                            float* g_b0, float* g_w1, float* g_b1, float* g_w2, float* g_b2,
                            void* workspace, int64_t workspace_bytes, void* stream);
+
+/* dsu_texture_bwd_shaded without its final launch: the per-workgroup partial parameter gradients
+ * stay in `workspace` and `red` receives partials / nblocks / stride / n of the deferred sum; the
+ * caller sets red->map (device copy of dsu_texture_partial_map) and red->base (a contiguous
+ * [w0 | b0 | w1 | b1 | w2 | b2] gradient block, accumulated +=) and hands the record to a launch that
+ * carries it out (dsu_sdf_fd_bwd_sorted_fold).  dsu_texture_partial_map fills map_host (may be NULL)
+ * and returns the number of entries. */
+int32_t dsu_texture_partial_map(int32_t* map_host);
+int dsu_texture_bwd_shaded_partials(const dsu_tex_mlp* mlp, const float* feature, const float* grad,
+                                    const float* rgb, const float* d_rgb, const float* d_normal,
+                                    int64_t n, int64_t tail_rows, float* d_grad, float* d_feature,
+                                    void* workspace, int64_t workspace_bytes,
+                                    dsu_partial_reduce* red, void* stream);
 
 /* OrthoNeuSSystem.preprocess_data (systems/neus_ortho.py:26-82) for n sampled (view, y, x)
  * triples (int64, drawn by the caller): c2w gather, get_ortho_rays (models/ray_utils.py:36-58),
