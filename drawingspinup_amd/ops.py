@@ -134,8 +134,9 @@ def sdf_fd_fwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, with_grad=T
 
 
 def sdf_fd_bwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, d_sdf, d_grad, d_feature,
-               d_laplace, grad_table=None, enc_cache=None, perm=None):
-    """perm: as in sdf_fd_fwd (`pts` sorted, the upstream gradients in the original row order)."""
+               d_laplace, grad_table=None, enc_cache=None, perm=None, extra=None):
+    """perm: as in sdf_fd_fwd (`pts` sorted, the upstream gradients in the original row order).
+    extra: a DeferredSum (texture_bwd_shaded_partials) carried out by the scatter launch."""
     pts = _f32c(pts)
     n = pts.shape[0]
     dev = pts.device
@@ -155,6 +156,17 @@ def sdf_fd_bwd(cfg, table_f16, mlp, pts, radius, eps, active_levels, d_sdf, d_gr
         need = int(lib().dsu_sdf_fd_enc_cache_bytes(n, int(active_levels)))
         if enc_cache.numel() * enc_cache.element_size() < need:
             raise DsuError("feature cache smaller than dsu_sdf_fd_enc_cache_bytes")
+    if extra is not None:
+        # the scatter launch also carries out a deferred partial sum of another kernel
+        check(lib().dsu_sdf_fd_bwd_sorted_fold(C.byref(c), ptr(table_f16, torch.float16), C.byref(m),
+                                               ptr(pts), ptr(perm, torch.int32), n, float(radius),
+                                               float(eps), int(active_levels),
+                                               ptr(d[0]), ptr(d[1]), ptr(d[2]), ptr(d[3]),
+                                               ptr(grad_table), ptr(g[0]), ptr(g[1]), ptr(g[2]),
+                                               ptr(g[3]), ptr(ws), int(wbytes), ptr(enc_cache), None,
+                                               C.byref(extra.record), stream()),
+              "dsu_sdf_fd_bwd_sorted_fold")
+        return grad_table, g
     check(lib().dsu_sdf_fd_bwd_sorted(C.byref(c), ptr(table_f16, torch.float16), C.byref(m),
                                       ptr(pts), ptr(perm, torch.int32), n, float(radius),
                                       float(eps), int(active_levels),
@@ -475,6 +487,48 @@ def texture_bwd_shaded(params, feature, grad, rgb, d_rgb, d_normal, tail_rows=0)
                                        *[ptr(t) for t in g], ptr(ws), wbytes, stream()),
           "dsu_texture_bwd_shaded")
     return d_grad, d_feat, g
+
+
+def texture_partial_map():
+    """Destination of every element of the texture backward's partial vectors inside a contiguous
+    [w0 | b0 | w1 | b1 | w2 | b2] gradient block (-1: padding), host int32 array."""
+    import numpy as np
+    n = int(lib().dsu_texture_partial_map(None))
+    m = np.empty(n, dtype=np.int32)
+    lib().dsu_texture_partial_map(m.ctypes.data_as(C.c_void_p))
+    return m
+
+
+class DeferredSum:
+    """A dsu_partial_reduce record plus the tensors it points into (kept alive with it)."""
+
+    def __init__(self, record, keep):
+        self.record, self.keep = record, keep
+
+
+def texture_bwd_shaded_partials(params, feature, grad, rgb, d_rgb, d_normal, tail_rows=0):
+    """texture_bwd_shaded WITHOUT the final sum: returns (d_grad, d_feature, g_flat, deferred) where
+    g_flat (zeros now) is the contiguous gradient block the deferred sum will be added to by the
+    launch it is handed to (sdf_fd_bwd(..., extra=deferred))."""
+    from ._lib import PartialReduce
+    feature, grad, rgb, d_rgb = _f32c(feature), _f32c(grad), _f32c(rgb), _f32c(d_rgb)
+    n = rgb.shape[0]
+    dev = rgb.device
+    d_grad = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    d_feat = torch.empty((n + tail_rows, 13), dtype=torch.float32, device=dev)
+    flat = torch.zeros(sum(t.numel() for t in params), dtype=torch.float32, device=dev)
+    wbytes = int(lib().dsu_texture_bwd_workspace_bytes(n))
+    ws = torch.empty(max(wbytes, 4) // 4, dtype=torch.float32, device=dev)
+    m = _tex_struct(params)
+    dn = None if d_normal is None else _f32c(d_normal)
+    rec = PartialReduce()
+    check(lib().dsu_texture_bwd_shaded_partials(C.byref(m), ptr(feature), ptr(grad), ptr(rgb),
+                                                ptr(d_rgb), ptr(dn), n, int(tail_rows), ptr(d_grad),
+                                                ptr(d_feat), ptr(ws), wbytes, C.byref(rec), stream()),
+          "dsu_texture_bwd_shaded_partials")
+    tmap = torch.from_numpy(texture_partial_map()).to(dev)
+    rec.map, rec.base = tmap.data_ptr(), flat.data_ptr()
+    return d_grad, d_feat, flat, DeferredSum(rec, (ws, tmap, flat))
 
 
 def ortho_ray_batch(index, x, y, c2w, origins, directions, images, normals, masks, view_weights):

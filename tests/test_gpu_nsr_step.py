@@ -418,3 +418,39 @@ def test_shaded_texture_kernels_equal_the_separate_launches(dev, n):
     assert torch.equal(d_feat2[:n], d_feat) and float(d_feat2[n:].abs().max()) == 0.0
     for a, b in zip(gp, gp2):          # sums over the samples: the two instantiations agree to rounding
         torch.testing.assert_close(a, b, rtol=1e-5, atol=1e-5 * float(a.abs().max()))
+
+
+@pytest.mark.parametrize("n", [63, 5000, 100003])
+def test_deferred_partial_sums_in_the_scatter_launch_equal_the_separate_reductions(dev, n):
+    """The native step's tail: the texture backward leaves its per-workgroup partial gradients and
+    the geometry backward's scatter launch sums them (and its own) in its first workgroups
+    (dsu_texture_bwd_shaded_partials + dsu_sdf_fd_bwd_sorted_fold).  Same partials, same summation
+    order as the stand-alone reduction launches: the geometry gradients are bit-identical."""
+    g = torch.Generator().manual_seed(n)
+    mk = lambda *s: (torch.randn(*s, generator=g)).to(dev)
+    params = [mk(64, 16) * 0.3, mk(64) * 0.1, mk(64, 64) * 0.15, mk(64) * 0.1, mk(3, 64) * 0.2,
+              mk(3) * 0.1]
+    feat, grad = mk(n, 13), mk(n, 3)
+    d_rgb, d_normal = mk(n, 3), mk(n, 3)
+    _, rgb = ops.texture_fwd_shaded(params, feat, grad)
+    d_grad, d_feat, gp = ops.texture_bwd_shaded(params, feat, grad, rgb, d_rgb, d_normal, tail_rows=3)
+    d_grad2, d_feat2, flat, deferred = ops.texture_bwd_shaded_partials(params, feat, grad, rgb, d_rgb,
+                                                                      d_normal, tail_rows=3)
+    assert torch.equal(d_grad2, d_grad) and torch.equal(d_feat2, d_feat)
+    assert float(flat.abs().max()) == 0.0                      # nothing summed yet
+    # a geometry backward on the same stream, with and without the deferred record
+    cfg = ops.HashGridConfig()
+    tab = ((torch.rand(cfg.n_entries, 2, generator=g) * 2 - 1) * 0.1).half().to(dev)
+    mlp = [mk(64, 23) * 0.3, mk(64) * 0.05, mk(13, 64) * 0.2, mk(13) * 0.1]
+    pts = (torch.rand(n, 3, generator=g) * 1.6 - 0.8).to(dev)
+    d = [mk(n), mk(n, 3), mk(n, 13), None]
+    gt_a, g_a = ops.sdf_fd_bwd(cfg, tab, mlp, pts, 1.0, 0.01, 5, *d)
+    gt_b, g_b = ops.sdf_fd_bwd(cfg, tab, mlp, pts, 1.0, 0.01, 5, *d, extra=deferred)
+    for a, b in zip(g_a, g_b):
+        assert torch.equal(a, b)
+    torch.testing.assert_close(gt_b, gt_a, rtol=1e-4, atol=1e-5 * float(gt_a.abs().max()))   # atomics
+    sizes = [t.numel() for t in params]
+    # (two runs of the texture backward: its waves add into the workgroup's partial vector with LDS
+    # float atomics, so the partials themselves differ in the last bits from run to run)
+    for a, b in zip(gp, torch.split(flat, sizes)):
+        torch.testing.assert_close(b, a.reshape(-1), rtol=1e-5, atol=1e-5 * float(a.abs().max()))

@@ -163,3 +163,15 @@ def test_round2_entry_points_validate_before_launching():
     out[2, 3] = 9
     assert (out == 9).all()
     assert lib.dsu_inpaint_telea_u8c3(P(img.ctypes.data), P(m.ctypes.data), 2, 6, 3, P(out.ctypes.data)) == -3
+
+
+def test_texture_partial_map_is_a_bijection_onto_the_gradient_block():
+    """Host-only: every parameter of the texture MLP receives exactly one element of the partial
+    vector, the padding elements none."""
+    import numpy as np
+    from drawingspinup_amd import ops
+    m = ops.texture_partial_map()
+    n_tex = 64 * 16 + 64 + 64 * 64 + 64 + 3 * 64 + 3
+    dst = m[m >= 0]
+    assert dst.size == n_tex and np.array_equal(np.sort(dst), np.arange(n_tex))
+    assert (m < 0).sum() == m.size - n_tex
