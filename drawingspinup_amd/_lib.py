@@ -42,6 +42,16 @@ class PartialReduce(C.Structure):                     # dsu_partial_reduce
                 ("stride", c_i32), ("n", c_i32)]
 
 
+class OccRefreshArgs(C.Structure):                    # dsu_occgrid_refresh_args
+    _fields_ = [("occs", c_vp), ("binary", c_vp), ("res", c_i32), ("all_cells", c_i32),
+                ("aabb", C.POINTER(c_f32)), ("seed", C.c_uint64), ("step", c_i64),
+                ("grid", C.POINTER(HashGridCfg)), ("table_img", c_vp), ("mlp", C.POINTER(SdfMlp)),
+                ("inv_s", c_vp), ("radius", c_f32), ("render_step_size", c_f32),
+                ("ema_decay", c_f32), ("occ_thre", c_f32), ("active_levels", c_u32),
+                ("inj_count", c_i32), ("inj_cells", c_vp), ("inj_rand", c_vp), ("thre_out", c_vp),
+                ("workspace", c_vp), ("workspace_bytes", c_i64)]
+
+
 class NormCfg(C.Structure):
     _fields_ = [("batch", c_i32), ("channels", c_i32), ("hw", c_i32), ("instance", c_i32),
                 ("act", c_i32), ("stat_updates", c_i32), ("eps", c_f32), ("momentum", c_f32)]
@@ -128,6 +138,9 @@ _PROTOS = {
     "dsu_texture_partial_map": [P],
     "dsu_texture_bwd_shaded_partials": [C.POINTER(TexMlp), P, P, P, P, P, c_i64, c_i64, P, P, P, c_i64,
                                         C.POINTER(PartialReduce), P],
+    "dsu_occgrid_refresh_workspace_bytes": [c_i32],
+    "dsu_occgrid_refresh": [C.POINTER(OccRefreshArgs), P],
+    "dsu_nsr_driver_occ_refresh": [P, C.POINTER(OccRefreshArgs), P],
     "dsu_inpaint_telea_u8c3": [P, P, c_i32, c_i32, c_i32, P],
     "dsu_table_adamw": [P, P, P, P, P, c_i64, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, c_f32, P],
     "dsu_table_decay": [P, P, c_i64, c_f32, P],

@@ -787,6 +787,26 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
   return DSU_OK;
 }
 
+int dsu_nsr_driver_occ_refresh(dsu_nsr_driver* d, const dsu_occgrid_refresh_args* args,
+                               void* main_stream) {
+  if (!d || !args) return DSU_EINVAL;
+  if (!d->initialised) return DSU_EUNSUP;             // effective weights exist after the first step
+  const dsu_nsr_driver_cfg& c = d->cfg;
+  // nothing of the side stream may still read the grid that is about to be rewritten
+  DSU_HIP(hipStreamSynchronize(d->side));
+  for (int k = 0; k < 3; ++k) d->pf_valid[k] = false;
+  dsu_occgrid_refresh_args a = *args;
+  const dsu_sdf_mlp mlp{d->L.w0_eff, c.b0, d->L.w1_eff, c.b1};
+  a.grid = &c.grid;
+  a.mlp = &mlp;
+  a.inv_s = d->L.inv_s;
+  a.aabb = d->aabb;
+  a.seed = c.seed;
+  a.radius = c.radius;
+  a.render_step_size = c.render_step_size;
+  return dsu_occgrid_refresh(&a, main_stream);
+}
+
 int dsu_nsr_driver_timing(dsu_nsr_driver* d, int32_t enable) {
   if (!d) return DSU_EINVAL;
   for (int f = 0; f < 2; ++f) {

@@ -38,6 +38,9 @@ class OccupancyGrid(nn.Module):
         self.register_buffer("_binary", torch.zeros(resolution, dtype=torch.bool))
         self._binary_u8 = None
         self._aabb_host = [float(v) for v in torch.as_tensor(roi_aabb).tolist()]
+        # set by the native step driver: refresh(grid, step, all_cells, occ_thre, ema_decay) -> bool,
+        # the whole of _update as one stream-ordered library call (dsu_nsr_driver_occ_refresh)
+        self.native_refresh = None
 
     @property
     def roi_aabb(self):
@@ -71,6 +74,9 @@ class OccupancyGrid(nn.Module):
     @torch.no_grad()
     def _update(self, step, occ_eval_fn, occ_thre=0.01, ema_decay=0.95, warmup_steps=256,
                 rand=None, indices=None):
+        if (self.native_refresh is not None and rand is None and indices is None
+                and self.native_refresh(self, step, step < warmup_steps, occ_thre, ema_decay)):
+            return
         if indices is None and step >= warmup_steps:
             n = self.num_cells // 4
             uniform = torch.randint(self.num_cells, (n,), device=self.occs.device)

@@ -424,6 +424,11 @@ class NativeStepDriver:
         self.terms2 = self.workspace[off:off + 64].view(torch.float32).view(2, 8)
         self.timing_on = False
         self.dataset = ds
+        self.system = system
+        self.stepped = False                                  # effective weights exist after a step
+        self._occ_ws = None
+        if getattr(mc, "grid_prune", False):
+            m.occupancy_grid.native_refresh = self.occ_refresh
 
     def set_timing(self, on):
         if on != self.timing_on:
@@ -446,7 +451,46 @@ class NativeStepDriver:
             t[0] += n.value; t[1] += ms.value; t[2] += work.value
         ops.check(self._lib.lib().dsu_nsr_driver_timing(self.handle, 1), "dsu_nsr_driver_timing")
 
+    def occ_refresh(self, grid, step, all_cells, occ_thre, ema_decay, inj_cells=None, inj_rand=None):
+        """OccupancyGrid._update through dsu_nsr_driver_occ_refresh: selection of the cells, points,
+        SDF with the driver's effective weights, alpha, EMA, mean, binarisation — on the current
+        stream, no host round trip.  Returns False (the caller's torch path runs) before the
+        driver's first step, when its effective weights do not exist yet."""
+        C, _lib = self.C, self._lib
+        if self.handle is None or not self.stepped:
+            return False
+        if [p._version for p in self.params] != self.param_versions:
+            return False          # parameters written from outside: the driver's weights are stale
+        geo = self.system.model.geometry
+        dev = grid.occs.device
+        need = int(_lib.lib().dsu_occgrid_refresh_workspace_bytes(grid.res))
+        if self._occ_ws is None or self._occ_ws.numel() < need:
+            self._occ_ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        binary = grid.binary_u8()
+        a = _lib.OccRefreshArgs()
+        a.occs, a.binary = grid.occs.data_ptr(), binary.data_ptr()
+        a.res, a.all_cells = int(grid.res), int(bool(all_cells))
+        a.step = int(step)
+        a.table_img = geo.hashgrid.table_f16().data_ptr()
+        a.active_levels = int(geo.active_levels)
+        a.ema_decay, a.occ_thre = float(ema_decay), float(occ_thre)
+        keep = []
+        if inj_cells is not None:
+            ic = inj_cells.to(dev, torch.int32).contiguous()
+            ir = inj_rand.to(dev, torch.float32).contiguous()
+            keep += [ic, ir]
+            a.inj_count, a.inj_cells, a.inj_rand = int(ic.numel()), ic.data_ptr(), ir.data_ptr()
+        a.workspace, a.workspace_bytes = self._occ_ws.data_ptr(), need
+        ops.check(_lib.lib().dsu_nsr_driver_occ_refresh(self.handle, C.byref(a), ops.stream()),
+                  "dsu_nsr_driver_occ_refresh")
+        grid._binary_u8 = binary
+        grid._binary = binary.view(grid.res, grid.res, grid.res).bool()
+        return True
+
     def close(self):
+        grid = getattr(self.system.model, "occupancy_grid", None) if self.system is not None else None
+        if grid is not None and getattr(grid, "native_refresh", None) == self.occ_refresh:
+            grid.native_refresh = None
         if self.handle is not None:
             self.flush_timing()
             self._lib.lib().dsu_nsr_driver_destroy(self.handle)
@@ -719,6 +763,7 @@ class OrthoNeuSSystem:
             raise ops.DsuError(f"dsu_nsr_driver_step failed ({rc}): {a.out_n_samples} samples, "
                                f"longest ray {a.out_max_count} (capacity {_PACK_CAPACITY})")
         drv.adam_step += 1
+        drv.stepped = True
         n_rays = int(self.train_num_rays)
         if m.config.dynamic_ray_sampling:
             self.train_num_rays = int(a.out_next_n_rays)

@@ -291,6 +291,39 @@ int dsu_occgrid_ema(float* occs, const int64_t* idx, const float* occ, int64_t n
 int dsu_occgrid_binarize(const float* occs, int64_t n_cells, float thre, uint8_t* binary,
                          void* stream);
 
+/* The whole refresh (nerfacc 0.3.3 OccupancyGrid._update with NeuSModel's occ_eval_fn,
+ * instant_nsr/models/neus.py:61-88) as one stream-ordered sequence without host round trips:
+ * cells (all of them while all_cells = 1, i.e. step < warm-up; otherwise res^3/4 uniform draws + the
+ * occupied cells, subsampled to res^3/4 with replacement when there are more) -> points
+ * (cell + U[0,1)^3) / res in the aabb -> dsu_sdf_fwd -> occ = clip((sigmoid(prev inv_s) -
+ * sigmoid(next inv_s) + 1e-5) / (sigmoid(prev inv_s) + 1e-5)), prev / next = sdf +- render_step_size/2
+ * -> occs[c] = max(occs[c] ema_decay, occ) -> binary = occs > min(mean(occs), occ_thre).
+ * Draws: Philox4x32-10 keyed (seed, step), streams 8-10.  inj_cells / inj_rand (device, inj_count
+ * cells and inj_count x 3 uniforms; tests) replace the draws.  thre_out (device, may be NULL)
+ * receives the threshold.  workspace: dsu_occgrid_refresh_workspace_bytes(res) (< 0: invalid). */
+typedef struct dsu_occgrid_refresh_args {
+  float* occs;               /* (res^3) f32, updated in place */
+  uint8_t* binary;           /* (res^3) u8: read (occupied cells), then rewritten */
+  int32_t res, all_cells;
+  const float* aabb;         /* HOST: min xyz, max xyz */
+  uint64_t seed;
+  int64_t step;
+  const dsu_hashgrid_cfg* grid;
+  const void* table_img;
+  const dsu_sdf_mlp* mlp;    /* effective (weight-normed) weights */
+  const float* inv_s;        /* device scalar exp(10 variance) */
+  float radius, render_step_size, ema_decay, occ_thre;
+  uint32_t active_levels;
+  int32_t inj_count;
+  const int32_t* inj_cells;
+  const float* inj_rand;
+  float* thre_out;
+  void* workspace;
+  int64_t workspace_bytes;
+} dsu_occgrid_refresh_args;
+int64_t dsu_occgrid_refresh_workspace_bytes(int32_t res);
+int dsu_occgrid_refresh(const dsu_occgrid_refresh_args* args, void* stream);
+
 /* Fused NeuS shading + compositing of one ray batch (neus.py:90-112 get_alpha, :143-153
  * render_weight_from_alpha + the four accumulate_along_rays): per sample
  *   alpha = clip((sigmoid(prev*inv_s) - sigmoid(next*inv_s) + 1e-5) / (sigmoid(prev*inv_s) + 1e-5))
@@ -704,8 +737,8 @@ int dsu_adamw_multi(const dsu_adamw_tensor* tensors, int32_t count, float beta1,
  * variance groups (configs/neuralangelo-ortho-wmask.yaml:96-127) sequenced by the library
  * itself: the host-side cost of a step is ~20 kernel launches issued from C instead of ~1.4 ms
  * of interpreter work (as long as the step's device time).  The hash table's own update stays the
- * caller's bookkeeping (levels, lazy decay) with the launch itself inside the step, the occupancy-grid refresh of every 16th step
- * the caller's too (dsu_sdf_fwd + dsu_occgrid_*).
+ * caller's bookkeeping (levels, lazy decay) with the launch itself inside the step; the occupancy-grid
+ * refresh of every 16th step is dsu_nsr_driver_occ_refresh, called by the caller before that step.
  *
  * All device memory is the caller's: parameters, dataset tensors and ONE workspace of
  * dsu_nsr_driver_workspace_bytes(cfg) bytes.  The driver object owns a side stream, three
@@ -798,6 +831,11 @@ const float* dsu_nsr_driver_terms(const dsu_nsr_driver* d);
 int dsu_nsr_driver_timing(dsu_nsr_driver* d, int32_t enable);
 int dsu_nsr_driver_timing_read(dsu_nsr_driver* d, int32_t family, int64_t* launches,
                                double* total_ms, double* alg_bytes);
+/* dsu_occgrid_refresh with the driver's own effective weights, inv_s, grid, radius, step size, aabb
+ * and seed filled in (args->grid / mlp / inv_s / aabb / seed / radius / render_step_size are
+ * ignored): the refresh of every 16th step without leaving the native path. */
+int dsu_nsr_driver_occ_refresh(dsu_nsr_driver* d, const dsu_occgrid_refresh_args* args,
+                               void* main_stream);
 /* Wait for the side stream and drop a pending prefetch (before the caller changes the ray count,
  * the dataset or the occupancy grid behind the driver's back). */
 int dsu_nsr_driver_sync(dsu_nsr_driver* d);

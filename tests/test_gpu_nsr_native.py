@@ -181,3 +181,66 @@ def test_native_step_results_are_snapshots_and_survive_a_step_jump(dev):
     for k in ("eikonal", "sparsity", "normal_smooth", "rgb_mse"):
         va, vb = float(ra[k]), float(rb[k])
         assert abs(va - vb) <= 2e-3 * max(abs(va), 1e-3), (k, va, vb)
+
+
+def test_native_occupancy_refresh_matches_the_torch_update(dev):
+    """dsu_nsr_driver_occ_refresh (cells -> points -> SDF -> alpha -> EMA -> mean -> binary on the
+    stream, no host round trip) against OccupancyGrid._update with the SAME cells and uniforms
+    (nerfacc's rule restated in nsr/render.py, pinned to oracle/nerfacc_ref by test_gpu_render.py)."""
+    sysm, ds = _system(dev, 11, "native")
+    for _ in range(3):
+        sysm.training_step()
+    drv, m = sysm._native, sysm.model
+    grid = m.occupancy_grid
+    assert grid.native_refresh is not None and drv.stepped
+    n = grid.num_cells
+    g = torch.Generator().manual_seed(5)
+    cells = torch.randperm(n, generator=g)[: n // 3].to(dev)          # distinct cells: no EMA races
+    rand = torch.rand(cells.numel(), 3, generator=g).to(dev)
+    occs0, bin0 = grid.occs.clone(), grid.binary_u8().clone()
+    # torch path (injected cells switch the native hook off)
+    grid._update(512, m.occ_eval_fn, occ_thre=0.01, ema_decay=0.95, rand=rand, indices=cells)
+    occs_py, bin_py = grid.occs.clone(), grid.binary_u8().clone()
+    thre_py = float(torch.clamp(occs_py.mean(), max=0.01))
+    # native path from the same state
+    grid.occs.copy_(occs0)
+    grid._binary_u8 = bin0.clone()
+    assert drv.occ_refresh(grid, 512, False, 0.01, 0.95, inj_cells=cells, inj_rand=rand)
+    occs_nat, bin_nat = grid.occs, grid.binary_u8()
+    # (the SDF differs in the last bits: torch's weight_norm vs the driver's effective weights)
+    torch.testing.assert_close(occs_nat, occs_py, rtol=1e-5, atol=1e-6)
+    assert float((occs_nat != occs0).float().mean()) > 0.2                # it did update
+    border = (occs_py - thre_py).abs() < 3e-6
+    assert torch.equal(bin_nat[~border], bin_py[~border])
+    assert grid.binary.dtype == torch.bool and torch.equal(grid.binary.reshape(-1), bin_nat.bool())
+
+
+def test_native_occupancy_refresh_own_draws(dev):
+    """The library's own selection: warm-up form (every cell once) and the regular form (N/4 uniform
+    cells + the occupied cells); the binary grid is occs > min(mean, threshold) of the result."""
+    sysm, ds = _system(dev, 12, "native")
+    for _ in range(2):
+        sysm.training_step()
+    drv, grid = sysm._native, sysm.model.occupancy_grid
+    for all_cells in (True, False):
+        occs0 = grid.occs.clone()
+        was_on = grid.binary_u8().bool().clone()
+        assert drv.occ_refresh(grid, 640 + int(all_cells), all_cells, 0.01, 0.95)
+        occs = grid.occs
+        assert torch.isfinite(occs).all() and float(occs.min()) >= 0.0 and float(occs.max()) <= 1.0
+        changed = occs != occs0
+        if all_cells:
+            assert bool((occs >= occs0 * 0.95 - 1e-12).all())            # max(old * decay, new)
+        else:
+            # every previously occupied cell was visited (fewer than N/4 of them on this scene) ...
+            assert int(was_on.sum()) <= grid.num_cells // 4
+            visited = changed | (occs0 == 0)
+            assert bool(visited[was_on].all())
+            # ... plus about a fifth of all cells by the uniform draws (1 - exp(-1/4) = 22 %)
+            frac = float((changed & ~was_on).float().mean())
+            assert 0.1 < frac < 0.3 or float((occs0 > 0).float().mean()) < 0.05
+        thre = min(float(occs.double().mean()), 0.01)
+        border = (occs - thre).abs() < 1e-7
+        assert torch.equal(grid.binary_u8().bool()[~border], (occs > thre)[~border])
+    # the step after a refresh runs (the driver re-marches with the new grid)
+    sysm.training_step()

@@ -43,6 +43,20 @@ print("one step:")
 for s, e, q, n in one:
     print(f"  +{(s - b) / 1e3:8.1f} us  {(e - s) / 1e3:7.1f} us  q{q}  {n}")
 
+# the longest step of the window (the occupancy refresh of every 16th step: its samples cannot be
+# prefetched), all queues
+base = len(starts) // 2
+longest = max(range(base, base + 30), key=lambda i: rows[starts[i + 1]][0] - rows[starts[i]][0])
+# the refresh follows the step's optimizer launch: print from there to the next forward
+seg = rows[starts[longest]:starts[longest + 1] + 1]
+cut = max((i for i, r in enumerate(seg) if "small_update" in r[3]), default=0)
+seg = seg[cut:]
+b = seg[0][0]
+print(f"longest step of the window: {(rows[starts[longest + 1]][0] - rows[starts[longest]][0]) / 1e3:.1f} us; "
+      f"kernels between the previous optimizer launch and the next forward:")
+for s_, e_, q, n in seg:
+    print(f"  +{(s_ - b) / 1e3:8.1f} us  {(e_ - s_) / 1e3:7.1f} us  q{q}  {n}")
+
 # where the main queue idles: gaps > 4 us between consecutive kernels of the busiest queue, by
 # (kernel before -> kernel after), summed over the window
 mainq = max(byq, key=lambda q: sum(e - s for s, e, _, _ in byq[q]))
