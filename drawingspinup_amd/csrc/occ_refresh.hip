@@ -159,10 +159,9 @@ struct Ws {
 int carve(int32_t res, char* base, Ws& w) {
   const int64_t n = (int64_t)res * res * res;
   if (res < 1 || n >= (1ll << 31)) return DSU_EINVAL;
-  size_t b = 0;
-  if (hipcub::DeviceSelect::Flagged(nullptr, b, (int32_t*)nullptr, (uint8_t*)nullptr, (int32_t*)nullptr,
-                                    (int32_t*)nullptr, (int)n) != hipSuccess)
-    return DSU_ELAUNCH;
+  // scratch of the ordered selection: per-tile descriptors only (a few KB for 128^3); reserved by a
+  // bound so that the size can be planned without a device, checked against the real need at run time
+  const size_t b = (size_t)(n / 64 > (1 << 20) ? n / 64 : (1 << 20));
   Carve k{base};
   w.iota = k.take<int32_t>(n);
   w.occupied = k.take<int32_t>(n);
@@ -207,8 +206,14 @@ int dsu_occgrid_refresh(const dsu_occgrid_refresh_args* a, void* stream) {
   if (m == 0) return DSU_OK;
   if (!a->all_cells && !a->inj_cells) {
     // occupied cells in ascending order (= torch.nonzero), their number stays on the device
+    size_t cub_need = 0;
+    if (hipcub::DeviceSelect::Flagged(nullptr, cub_need, w.iota, a->binary, w.occupied, w.n_occupied,
+                                      (int)n, s) != hipSuccess)
+      return DSU_ELAUNCH;
+    if (cub_need > w.cub_bytes) return DSU_EUNSUP;
     iota_kernel<<<dsu_blocks_for(n, 256), 256, 0, s>>>(w.iota, n);
-    if (hipcub::DeviceSelect::Flagged(w.cub, w.cub_bytes, w.iota, a->binary, w.occupied, w.n_occupied,
+    cub_need = w.cub_bytes;
+    if (hipcub::DeviceSelect::Flagged(w.cub, cub_need, w.iota, a->binary, w.occupied, w.n_occupied,
                                       (int)n, s) != hipSuccess)
       return DSU_ELAUNCH;
   }

@@ -175,3 +175,20 @@ def test_texture_partial_map_is_a_bijection_onto_the_gradient_block():
     dst = m[m >= 0]
     assert dst.size == n_tex and np.array_equal(np.sort(dst), np.arange(n_tex))
     assert (m < 0).sum() == m.size - n_tex
+
+
+def test_occgrid_refresh_host_side():
+    """Workspace planning and argument checks of the native occupancy refresh (no launch)."""
+    import ctypes as C
+    from drawingspinup_amd import _lib
+    lib = _lib.lib()
+    n = 128 ** 3
+    need = lib.dsu_occgrid_refresh_workspace_bytes(128)
+    # iota + occupied + cells (int32), points (3 f32) + sdf (f32): 7 words per cell at least
+    assert 7 * 4 * n <= need < 9 * 4 * n
+    assert lib.dsu_occgrid_refresh_workspace_bytes(0) == -1
+    assert lib.dsu_occgrid_refresh_workspace_bytes(2048) == -1          # 2^33 cells
+    a = _lib.OccRefreshArgs()
+    assert lib.dsu_occgrid_refresh(C.byref(a), None) == -1              # NULL pointers
+    assert lib.dsu_occgrid_refresh(None, None) == -1
+    assert lib.dsu_nsr_driver_occ_refresh(None, C.byref(a), None) == -1
