@@ -190,6 +190,8 @@ _PROTOS = {
     "dsu_ray_offsets": [P, c_i64, P, P, P],
     "dsu_ortho_ray_batch": [P, P, P, c_i64, P, P, P, P, c_i32, P, P, P, c_i32, c_i32, P, P, P, P, P,
                             P, P],
+    "dsu_ortho_ray_batch_split": [P, P, P, c_i64, P, P, P, P, c_i32, P, P, P, c_i32, c_i32, P, P, P, P, P,
+                            P, P, P, P],
     "dsu_ray_losses": [P, P, P, P, P, P, c_i32, C.POINTER(RayLossCfg), P, P, P],
     "dsu_sample_losses": [P, P, c_i64, c_i64, c_f32, c_f32, c_f32, c_f32, c_i32, P, P, P, P],
     "dsu_texture_fwd": [C.POINTER(TexMlp), P, c_i64, P, P],

@@ -412,12 +412,12 @@ int enqueue_march(dsu_nsr_driver* d, int p, int64_t step, int32_t n_rays,
     if (a.inj_y) py = a.inj_y;
     if (a.inj_jitter) jitter = a.inj_jitter;
   }
-  DSU_TRY(dsu_ortho_ray_batch(index, px, py, n_rays, c.c2w, c.origins, c.directions, c.images,
-                              c.image_channels, c.normals, c.masks, c.view_weights, c.H, c.W,
-                              f.rays, f.rgb, f.normal, f.mask, f.cosines, f.vw, s));
-  // rays (n,6) -> contiguous origins / directions for the marcher and the compositing kernels
-  DSU_HIP(hipMemcpy2DAsync(f.rays_o, 12, f.rays, 24, 12, n_rays, hipMemcpyDeviceToDevice, s));
-  DSU_HIP(hipMemcpy2DAsync(f.rays_d, 12, f.rays + 3, 24, 12, n_rays, hipMemcpyDeviceToDevice, s));
+  // rays (n,6) and, from the same launch, contiguous origins / directions for the marcher and the
+  // compositing kernels (they used to be two strided copies per step)
+  DSU_TRY(dsu_ortho_ray_batch_split(index, px, py, n_rays, c.c2w, c.origins, c.directions, c.images,
+                                    c.image_channels, c.normals, c.masks, c.view_weights, c.H, c.W,
+                                    f.rays, f.rgb, f.normal, f.mask, f.cosines, f.vw, f.rays_o,
+                                    f.rays_d, s));
   DSU_TRY(dsu_ray_aabb(f.rays_o, f.rays_d, n_rays, d->aabb, a.randomized ? jitter : nullptr,
                        c.render_step_size, f.tmin, f.tmax, s));
   DSU_TRY(dsu_ray_march_scratch(f.rays_o, f.rays_d, f.tmin, f.tmax, n_rays, d->aabb, a.occ_binary,

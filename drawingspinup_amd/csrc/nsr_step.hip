@@ -412,7 +412,8 @@ __global__ __launch_bounds__(256) void ortho_ray_batch_kernel(
     const float* __restrict__ normals, const float* __restrict__ masks,
     const float* __restrict__ vweights, int H, int W, float* __restrict__ rays /*(n,6)*/,
     float* __restrict__ rgb, float* __restrict__ normal, float* __restrict__ mask,
-    float* __restrict__ cosines, float* __restrict__ vw) {
+    float* __restrict__ cosines, float* __restrict__ vw, float* __restrict__ rays_o /*(n,3) or null*/,
+    float* __restrict__ rays_d) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int64_t v = index[i];
@@ -435,6 +436,12 @@ __global__ __launch_bounds__(256) void ortho_ray_batch_kernel(
   const float dz = fmaxf(dn, 1e-12f);                    // F.normalize(rays_d, p=2, eps=1e-12)
   rays[i * 6 + 0] = ro[0]; rays[i * 6 + 1] = ro[1]; rays[i * 6 + 2] = ro[2];
   rays[i * 6 + 3] = rd[0] / dz; rays[i * 6 + 4] = rd[1] / dz; rays[i * 6 + 5] = rd[2] / dz;
+  if (rays_o) {
+    // the same values as two contiguous (n,3) arrays (what the marcher and the compositing kernels
+    // read): the native step used to copy them out of `rays` with two strided copies per step
+    rays_o[i * 3] = ro[0]; rays_o[i * 3 + 1] = ro[1]; rays_o[i * 3 + 2] = ro[2];
+    rays_d[i * 3] = rd[0] / dz; rays_d[i * 3 + 1] = rd[1] / dz; rays_d[i * 3 + 2] = rd[2] / dz;
+  }
   for (int c = 0; c < img_c; ++c) rgb[i * img_c + c] = images[pix * img_c + c];
   normal[i * 3] = nx; normal[i * 3 + 1] = ny; normal[i * 3 + 2] = nz;
   mask[i] = masks[pix];
@@ -544,14 +551,26 @@ int dsu_ortho_ray_batch(const int64_t* index, const int64_t* x, const int64_t* y
                         const float* masks, const float* view_weights, int32_t H, int32_t W,
                         float* rays, float* rgb, float* normal, float* mask, float* cosines,
                         float* vw, void* stream) {
+  return dsu_ortho_ray_batch_split(index, x, y, n, c2w, origins, directions, images, image_channels,
+                                   normals, masks, view_weights, H, W, rays, rgb, normal, mask,
+                                   cosines, vw, nullptr, nullptr, stream);
+}
+
+int dsu_ortho_ray_batch_split(const int64_t* index, const int64_t* x, const int64_t* y, int64_t n,
+                              const float* c2w, const float* origins, const float* directions,
+                              const float* images, int32_t image_channels, const float* normals,
+                              const float* masks, const float* view_weights, int32_t H, int32_t W,
+                              float* rays, float* rgb, float* normal, float* mask, float* cosines,
+                              float* vw, float* rays_o, float* rays_d, void* stream) {
   if (n < 0 || H <= 0 || W <= 0 || image_channels <= 0) return DSU_EINVAL;
+  if ((rays_o == nullptr) != (rays_d == nullptr)) return DSU_EINVAL;
   if (n == 0) return DSU_OK;
   if (!index || !x || !y || !c2w || !origins || !directions || !images || !normals || !masks ||
       !view_weights || !rays || !rgb || !normal || !mask || !cosines || !vw)
     return DSU_EINVAL;
   ortho_ray_batch_kernel<<<dsu_blocks_for(n, 256), 256, 0, (hipStream_t)stream>>>(
       index, x, y, n, c2w, origins, directions, images, image_channels, normals, masks, view_weights,
-      H, W, rays, rgb, normal, mask, cosines, vw);
+      H, W, rays, rgb, normal, mask, cosines, vw, rays_o, rays_d);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }

@@ -415,6 +415,15 @@ int dsu_ortho_ray_batch(const int64_t* index, const int64_t* x, const int64_t* y
                         float* rays, float* rgb, float* normal, float* mask, float* cosines,
                         float* vw, void* stream);
 
+/* The same launch also writing rays[:, :3] and rays[:, 3:] as two contiguous (n,3) arrays (both or
+ * neither may be NULL). */
+int dsu_ortho_ray_batch_split(const int64_t* index, const int64_t* x, const int64_t* y, int64_t n,
+                              const float* c2w, const float* origins, const float* directions,
+                              const float* images, int32_t image_channels, const float* normals,
+                              const float* masks, const float* view_weights, int32_t H, int32_t W,
+                              float* rays, float* rgb, float* normal, float* mask, float* cosines,
+                              float* vw, float* rays_o, float* rays_d, void* stream);
+
 /* Ray-level loss terms of OrthoNeuSSystem.training_step
  * (2_charactor_reconstructor/instant_nsr/systems/neus_ortho.py:94-133 with
  * systems/criterions.py:4-27) and their gradient w.r.t. the raw composite
