@@ -424,7 +424,8 @@ class NativeStepDriver:
         self.terms2 = self.workspace[off:off + 64].view(torch.float32).view(2, 8)
         self.timing_on = False
         self.dataset = ds
-        self.system = system
+        import weakref
+        self._system = weakref.ref(system)                    # no cycle: the system owns the driver
         self.stepped = False                                  # effective weights exist after a step
         self._occ_ws = None
         if getattr(mc, "grid_prune", False):
@@ -451,13 +452,17 @@ class NativeStepDriver:
             t[0] += n.value; t[1] += ms.value; t[2] += work.value
         ops.check(self._lib.lib().dsu_nsr_driver_timing(self.handle, 1), "dsu_nsr_driver_timing")
 
+    @property
+    def system(self):
+        return self._system()
+
     def occ_refresh(self, grid, step, all_cells, occ_thre, ema_decay, inj_cells=None, inj_rand=None):
         """OccupancyGrid._update through dsu_nsr_driver_occ_refresh: selection of the cells, points,
         SDF with the driver's effective weights, alpha, EMA, mean, binarisation — on the current
         stream, no host round trip.  Returns False (the caller's torch path runs) before the
         driver's first step, when its effective weights do not exist yet."""
         C, _lib = self.C, self._lib
-        if self.handle is None or not self.stepped:
+        if self.handle is None or not self.stepped or self.system is None:
             return False
         if [p._version for p in self.params] != self.param_versions:
             return False          # parameters written from outside: the driver's weights are stale
