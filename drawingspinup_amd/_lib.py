@@ -49,7 +49,8 @@ class OccRefreshArgs(C.Structure):                    # dsu_occgrid_refresh_args
                 ("inv_s", c_vp), ("radius", c_f32), ("render_step_size", c_f32),
                 ("ema_decay", c_f32), ("occ_thre", c_f32), ("active_levels", c_u32),
                 ("inj_count", c_i32), ("inj_cells", c_vp), ("inj_rand", c_vp), ("thre_out", c_vp),
-                ("workspace", c_vp), ("workspace_bytes", c_i64)]
+                ("workspace", c_vp), ("workspace_bytes", c_i64), ("cells_out", c_vp),
+                ("rand_out", c_vp)]
 
 
 class NormCfg(C.Structure):
@@ -209,7 +210,7 @@ _PROTOS = {
     "dsu_shade_prep_fwd": [P, P, c_i64, P, P, P],
     "dsu_shade_prep_bwd": [P, P, P, c_i64, P, P, P],
     "dsu_shade_prep_bwd_tail": [P, P, P, c_i64, c_i64, P, P, P],
-    "dsu_occgrid_ema": [P, P, P, c_i64, c_f32, P],
+    "dsu_occgrid_ema": [P, P, P, c_i64, c_f32, P, P],
     "dsu_occgrid_binarize": [P, c_i64, c_f32, P, P],
     "dsu_ric_offsets": [c_i32, c_i32, P, P],
     "dsu_deform_conv3x3_fwd": [P, P, c_i64, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, P, P,

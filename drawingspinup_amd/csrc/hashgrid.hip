@@ -269,6 +269,11 @@ __device__ __forceinline__ void mlp_stream_sgpr(const dsu_sdf_mlp& mlp, const fl
 #define DSU_FWD_THREADS 256
 #endif
 
+// hidden units per group of the level-outer forward (scalar weight registers: JB x (DIN + 14))
+#ifndef DSU_FWD_JB
+#define DSU_FWD_JB 2
+#endif
+
 template <int NL, int NO>
 __global__ __launch_bounds__(256) void sdf_fwd_kernel(const __half2* __restrict__ table,
                                                       GridMeta m, dsu_sdf_mlp mlp,
@@ -361,6 +366,185 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
     if (laplace != nullptr) {
       // (sdf(+)+sdf(-)-2 sdf).sum(-1) / eps^2   (geometry.py:176)
       float t0 = s[1] + s[2] - 2.0f * s[0];
+      float t1 = s[3] + s[4] - 2.0f * s[0];
+      float t2 = s[5] + s[6] - 2.0f * s[0];
+      laplace[oi] = ((t0 + t1) + t2) / eps2;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The same 7 evaluations, level-outer: per active level the 8 corners of the centre's cell are
+// gathered ONCE per point; an offset evaluation (+-eps along one axis: less than one cell on
+// every active level, geometry.py:196-215 ties eps to the finest active level) stays in the
+// centre's cell or moves to the neighbour that shares a face with it, so it reuses 8 or 4 of the
+// centre's corners and gathers 0 or 4 new entries instead of 8.  Same table entries, same weights,
+// same f16 FMA chain over corners 0..7 -> the features are bit-identical to lookup_level's.
+// (Anything else — a clamped point outside the box, an eps of more than a cell — takes the full
+// 8-corner lookup.)  Gathers per point and level: 8 + 4 x (crossings) ~ 17-25 instead of 56.
+// Then the MLP with the hidden units outer and the 7 evaluations inner: one set of scalar weight
+// loads serves 7 evaluations; the interpolated features stay packed f16 in registers and enter
+// the f32 FMAs through the mixed-precision form (widening is exact), the FMA chains (k ascending
+// for the pre-activations, j ascending for the outputs) are those of mlp_stream.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ __half2 interp8(const CellPos& p, const __half2* v) {
+  __half2 acc = __float2half2_rn(0.0f);
+#pragma unroll
+  for (int c = 0; c < 8; ++c) {
+    float wf = corner_weight(p, c);
+    asm volatile("" : "+v"(wf));     // f32 product rounded before the f16 conversion (see lookup_level)
+    const __half w = __float2half_rn(wf);
+    acc = __hfma2(__half2(w, w), v[c], acc);
+  }
+  return acc;
+}
+
+template <int NL, int ACT, bool FEAT>
+__global__ __launch_bounds__(256) void sdf_fd_fwd_shared_kernel(
+    const __half2* __restrict__ table, GridMeta m, dsu_sdf_mlp mlp,
+    const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
+    float* __restrict__ sdf, float* __restrict__ grad, float* __restrict__ feature,
+    float* __restrict__ laplace, __half2* __restrict__ enc, const int32_t* __restrict__ perm) {
+  constexpr int DIN = 3 + 2 * NL;
+  const cfloat_t* w0 = as_const(mlp.w0);
+  const cfloat_t* b0 = as_const(mlp.b0);
+  const cfloat_t* w1 = as_const(mlp.w1);
+  const cfloat_t* b1 = as_const(mlp.b1);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const float p[3] = {pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2]};
+    const int64_t oi = perm ? (int64_t)perm[i] : i;
+    // contracted coordinates: q[0] the centre; evaluation e > 0 moves axis (e-1)/2 by +-eps and
+    // clamps ALL axes to the box ((points_ + offsets).clamp(-radius, radius), geometry.py:170)
+    float q[7][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) q[0][a] = contract(p[a], radius);
+#pragma unroll
+    for (int e = 1; e < 7; ++e) {
+      const int ax = (e - 1) >> 1;
+      const float d = ((e - 1) & 1) ? -eps : eps;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        const float v = p[a] + (a == ax ? d : 0.0f);
+        q[e][a] = contract(fminf(fmaxf(v, -radius), radius), radius);
+      }
+    }
+    __half2 f[7][ACT];
+#pragma unroll
+    for (int l = 0; l < ACT; ++l) {
+      const uint32_t hsize = m.off[l + 1] - m.off[l];
+      const __half2* lvl = table + m.off[l];
+      const CellPos pc = cell_of(m.scale[l], q[0][0], q[0][1], q[0][2]);
+      __half2 v[8];
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        v[c] = lvl[grid_index(m.hashed[l], hsize, m.res[l], pc.c[0] + (c & 1),
+                              pc.c[1] + ((c >> 1) & 1), pc.c[2] + ((c >> 2) & 1))];
+      // the six offset evaluations: cell, relation to the centre's cell, new corners requested
+      CellPos pe[6];
+      int dcell[6];
+      bool odd[6];
+      __half2 g[6][4];
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const int ax = t >> 1, a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+        pe[t] = cell_of(m.scale[l], q[t + 1][0], q[t + 1][1], q[t + 1][2]);
+        dcell[t] = (int)(pe[t].c[ax] - pc.c[ax]);
+        odd[t] = pe[t].c[a1] != pc.c[a1] || pe[t].c[a2] != pc.c[a2] || dcell[t] < -1 || dcell[t] > 1;
+        if (!odd[t] && dcell[t] != 0) {
+          // the face of the new cell that the centre's cell does not have
+          const uint32_t ca = pe[t].c[ax] + (dcell[t] > 0 ? 1u : 0u);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            uint32_t cc[3];
+            cc[ax] = ca;
+            cc[a1] = pc.c[a1] + (k & 1);
+            cc[a2] = pc.c[a2] + (k >> 1);
+            g[t][k] = lvl[grid_index(m.hashed[l], hsize, m.res[l], cc[0], cc[1], cc[2])];
+          }
+        }
+      }
+      f[0][l] = interp8(pc, v);
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const int ax = t >> 1, a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+        if (odd[t]) {
+          f[t + 1][l] = lookup_level(table, m, l, q[t + 1][0], q[t + 1][1], q[t + 1][2]);
+        } else {
+          __half2 w[8];
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            const int lo = ((k & 1) << a1) | ((k >> 1) << a2), hi = lo | (1 << ax);
+            const __half2 gk = dcell[t] != 0 ? g[t][k] : v[lo];
+            w[lo] = dcell[t] == 0 ? v[lo] : (dcell[t] > 0 ? v[hi] : gk);
+            w[hi] = dcell[t] == 0 ? v[hi] : (dcell[t] > 0 ? gk : v[lo]);
+          }
+          f[t + 1][l] = interp8(pe[t], w);
+        }
+      }
+    }
+    if (enc != nullptr) {
+      // interpolated f16 features kept for the backward pass, layout [eval][point][active level]
+#pragma unroll
+      for (int e = 0; e < 7; ++e) {
+        __half2* row = enc + ((size_t)e * n + i) * ACT;
+#pragma unroll
+        for (int l = 0; l < ACT; ++l) row[l] = f[e][l];
+      }
+    }
+    // ---- MLP: groups of hidden units outer, evaluations inner
+    float xin[7][3];
+#pragma unroll
+    for (int e = 0; e < 7; ++e)
+#pragma unroll
+      for (int a = 0; a < 3; ++a) xin[e][a] = q[e][a] * 2.0f + -1.0f;
+    constexpr int NO0 = FEAT ? NOUT : 1;
+    float o0[NO0], s[7];
+#pragma unroll
+    for (int o = 0; o < NO0; ++o) o0[o] = b1[o];
+#pragma unroll
+    for (int e = 1; e < 7; ++e) s[e] = b1[0];
+#pragma unroll 1
+    for (int j = 0; j < HID; j += DSU_FWD_JB) {
+#pragma unroll
+      for (int e = 0; e < 7; ++e) {
+        float h[DSU_FWD_JB];
+#pragma unroll
+        for (int r = 0; r < DSU_FWD_JB; ++r) {
+          float acc = b0[j + r];
+#pragma unroll
+          for (int a = 0; a < 3; ++a) acc = fmaf(w0[(j + r) * DIN + a], xin[e][a], acc);
+#pragma unroll
+          for (int l = 0; l < ACT; ++l) {
+            acc = fmaf(w0[(j + r) * DIN + 3 + 2 * l], __low2float(f[e][l]), acc);
+            acc = fmaf(w0[(j + r) * DIN + 4 + 2 * l], __high2float(f[e][l]), acc);
+          }
+          h[r] = softplus100(acc);
+        }
+        if (e == 0) {
+#pragma unroll
+          for (int o = 0; o < NO0; ++o)
+#pragma unroll
+            for (int r = 0; r < DSU_FWD_JB; ++r) o0[o] = fmaf(w1[o * HID + j + r], h[r], o0[o]);
+        } else {
+#pragma unroll
+          for (int r = 0; r < DSU_FWD_JB; ++r) s[e] = fmaf(w1[j + r], h[r], s[e]);
+        }
+      }
+    }
+    s[0] = o0[0];
+    if (FEAT) {
+#pragma unroll
+      for (int o = 0; o < NO0; ++o) feature[oi * NOUT + o] = o0[o];
+    }
+    sdf[oi] = s[0];
+    if (grad != nullptr) {
+      grad[oi * 3 + 0] = 0.5f * (s[1] - s[2]) / eps;     // geometry.py:173
+      grad[oi * 3 + 1] = 0.5f * (s[3] - s[4]) / eps;
+      grad[oi * 3 + 2] = 0.5f * (s[5] - s[6]) / eps;
+    }
+    if (laplace != nullptr) {
+      float t0 = s[1] + s[2] - 2.0f * s[0];               // geometry.py:176
       float t1 = s[3] + s[4] - 2.0f * s[0];
       float t2 = s[5] + s[6] - 2.0f * s[0];
       laplace[oi] = ((t0 + t1) + t2) / eps2;
@@ -806,6 +990,42 @@ int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, cons
   hipStream_t s = (hipStream_t)stream;
   const float eps2 = (float)((double)eps * (double)eps);
   const int blocks = dsu_capped_blocks(n, DSU_FWD_THREADS, 8192 * (256 / DSU_FWD_THREADS));
+#if !defined(DSU_FWD_PER_EVAL) && !defined(DSU_FWD_LDS_W)
+  // level-outer kernel with shared corners, one instance per number of active levels
+  if (active_levels >= 1 && !dsu_ab_is("DSU_FWD_KERNEL", "per_eval")) {
+#define DSU_FWD_SHARED_CASE(NLv, ACTv)                                                            \
+  case ACTv:                                                                                      \
+    if (feature)                                                                                  \
+      sdf_fd_fwd_shared_kernel<NLv, ACTv, true><<<dim3(blocks), dim3(DSU_FWD_THREADS), 0, s>>>(   \
+          (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, sdf, grad, feature,      \
+          laplace, (__half2*)enc_cache, perm);                                                    \
+    else                                                                                          \
+      sdf_fd_fwd_shared_kernel<NLv, ACTv, false><<<dim3(blocks), dim3(DSU_FWD_THREADS), 0, s>>>(  \
+          (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, sdf, grad, feature,      \
+          laplace, (__half2*)enc_cache, perm);                                                    \
+    break;
+    DSU_DISPATCH_NL(cfg->n_levels, {
+      switch (active_levels) {
+        DSU_FWD_SHARED_CASE(NL, 1) DSU_FWD_SHARED_CASE(NL, 2) DSU_FWD_SHARED_CASE(NL, 3)
+        DSU_FWD_SHARED_CASE(NL, 4) DSU_FWD_SHARED_CASE(NL, 5) DSU_FWD_SHARED_CASE(NL, 6)
+        DSU_FWD_SHARED_CASE(NL, 7) DSU_FWD_SHARED_CASE(NL, 8) DSU_FWD_SHARED_CASE(NL, 9)
+        DSU_FWD_SHARED_CASE(NL, 10)
+        default:
+          if constexpr (NL >= 12) {
+            switch (active_levels) {
+              DSU_FWD_SHARED_CASE(NL, 11) DSU_FWD_SHARED_CASE(NL, 12)
+              default: return DSU_EUNSUP;
+            }
+          } else {
+            return DSU_EUNSUP;
+          }
+      }
+    });
+#undef DSU_FWD_SHARED_CASE
+    DSU_CHECK_LAUNCH();
+    return DSU_OK;
+  }
+#endif
   DSU_DISPATCH_NL(cfg->n_levels, {
     const size_t shm = DSU_FWD_LDS_BYTES(NL);
     if (active_levels <= 6)

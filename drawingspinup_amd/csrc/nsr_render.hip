@@ -342,13 +342,37 @@ __global__ void accumulate_fwd_kernel(const float* __restrict__ w, const float* 
   out[t] = acc;
 }
 
-__global__ void occ_ema_kernel(float* __restrict__ occs, const int64_t* __restrict__ idx,
-                               const float* __restrict__ occ, int64_t n, float decay) {
+__global__ void occ_ema_kernel(float* __restrict__ occs, const float* __restrict__ occ, int64_t n,
+                               float decay) {
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t c = idx ? idx[i] : i;
-    occs[c] = fmaxf(occs[c] * decay, occ[i]);
-  }
+       i += (int64_t)gridDim.x * blockDim.x)
+    occs[i] = fmaxf(occs[i] * decay, occ[i]);
+}
+
+// Indexed form in three passes, so that a cell listed twice is decayed once: candidates from the
+// untouched grid, the listed cells to zero, atomic max of the candidates (values >= 0: the bit
+// pattern orders like the value).
+__global__ void occ_ema_candidates_kernel(const float* __restrict__ occs,
+                                          const int64_t* __restrict__ idx,
+                                          const float* __restrict__ occ, int64_t n, float decay,
+                                          float* __restrict__ cand) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    cand[i] = fmaxf(fmaxf(occs[idx[i]] * decay, occ[i]), 0.0f);
+}
+
+__global__ void occ_ema_clear_kernel(float* __restrict__ occs, const int64_t* __restrict__ idx,
+                                     int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    occs[idx[i]] = 0.0f;
+}
+
+__global__ void occ_ema_max_kernel(float* __restrict__ occs, const int64_t* __restrict__ idx,
+                                   const float* __restrict__ cand, int64_t n) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x)
+    atomicMax(reinterpret_cast<int*>(&occs[idx[i]]), __float_as_int(cand[i]));
 }
 
 __global__ void occ_bin_kernel(const float* __restrict__ occs, int64_t n, float thre,
@@ -797,11 +821,18 @@ int dsu_accumulate_fwd(const float* weights, const float* values, int32_t channe
 }
 
 int dsu_occgrid_ema(float* occs, const int64_t* idx, const float* occ, int64_t n, float decay,
-                    void* stream) {
-  if (n < 0 || (n && (!occs || !occ))) return DSU_EINVAL;
+                    float* scratch, void* stream) {
+  if (n < 0 || (n && (!occs || !occ)) || (n && idx && !scratch)) return DSU_EINVAL;
   if (n == 0) return DSU_OK;
-  occ_ema_kernel<<<dsu_capped_blocks(n, 256), 256, 0, (hipStream_t)stream>>>(occs, idx, occ, n,
-                                                                            decay);
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = dsu_capped_blocks(n, 256);
+  if (!idx) {
+    occ_ema_kernel<<<blocks, 256, 0, s>>>(occs, occ, n, decay);
+  } else {
+    occ_ema_candidates_kernel<<<blocks, 256, 0, s>>>(occs, idx, occ, n, decay, scratch);
+    occ_ema_clear_kernel<<<blocks, 256, 0, s>>>(occs, idx, n);
+    occ_ema_max_kernel<<<blocks, 256, 0, s>>>(occs, idx, scratch, n);
+  }
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }

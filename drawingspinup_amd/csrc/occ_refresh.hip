@@ -10,11 +10,16 @@
 //   occ     = clip((sigmoid(prev inv_s) - sigmoid(next inv_s) + 1e-5) / (sigmoid(prev inv_s) + 1e-5), 0, 1),
 //             prev / next = sdf(x) +- render_step_size / 2
 //   occs[c] = max(occs[c] * decay, occ);   binary = occs > min(mean(occs), occ_thre)
+// A cell drawn more than once (a uniform draw that hits an occupied cell: about a fifth of them)
+// is decayed ONCE and receives the largest of its alphas: nerfacc's indexed assignment gathers
+// every old value before it scatters, and which duplicate it keeps is unspecified; the largest is
+// one of its outcomes and makes the result independent of the run order.
 // The torch form costs ~50 launches and two host synchronisations (nonzero's size, float(mean)) —
 // 0.7 ms of the 1.26 ms a refresh step adds (profiles/round4_nsr_refresh_step_timeline.txt).  Here:
 // ordered selection of the occupied cells (hipCUB, the size stays on the device), one kernel for
 // cells + points (launched for the 2 x N/4 capacity; unused slots carry cell -1 and a dummy point),
-// dsu_sdf_fwd, one kernel for alpha + EMA, partial sums, mean + threshold + binarisation.
+// dsu_sdf_fwd, one kernel for alpha (atomic max per cell into a scratch grid preset to -1), the EMA
+// of the visited cells riding in the partial-sum pass, mean + threshold + binarisation.
 // Draws: Philox4x32-10 keyed (seed, step), streams 8-10 (the step's own draws use 0-2).
 #include "common.h"
 
@@ -51,7 +56,8 @@ __global__ __launch_bounds__(256) void occ_points_kernel(
     uint64_t seed, int64_t step, int32_t res, int32_t n_cells, int32_t n_uni, int32_t all,
     const int32_t* __restrict__ occupied, const int32_t* __restrict__ n_occupied,
     const int32_t* __restrict__ cell_inj, const float* __restrict__ rand_inj, float lo0, float lo1, float lo2, float hi0, float hi1,
-    float hi2, int32_t m, int32_t* __restrict__ cell, float* __restrict__ pts) {
+    float hi2, int32_t m, int32_t* __restrict__ cell, float* __restrict__ pts,
+    int32_t* __restrict__ cells_out, float* __restrict__ rand_out) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const uint2 key = make_uint2((uint32_t)seed, (uint32_t)(seed >> 32));
@@ -76,6 +82,10 @@ __global__ __launch_bounds__(256) void occ_points_kernel(
     const uint4 r = philox(make_uint4((uint32_t)i, 10u, s0, s1), key);
     r0 = u01(r.x); r1 = u01(r.y); r2 = u01(r.z);
   }
+  if (cells_out) cells_out[i] = c;
+  if (rand_out) {
+    rand_out[3 * (size_t)i] = r0; rand_out[3 * (size_t)i + 1] = r1; rand_out[3 * (size_t)i + 2] = r2;
+  }
   const int32_t cc = c < 0 ? 0 : c;
   const int32_t ix = cc / (res * res), iy = (cc / res) % res, iz = cc % res;
   // (coords + rand) / res * (hi - lo) + lo   (grid.py _update; render.py _cell_points)
@@ -85,10 +95,9 @@ __global__ __launch_bounds__(256) void occ_points_kernel(
   pts[3 * (size_t)i + 2] = ((float)iz + r2) / fr * (hi2 - lo2) + lo2;
 }
 
-__global__ __launch_bounds__(256) void occ_alpha_ema_kernel(
+__global__ __launch_bounds__(256) void occ_alpha_kernel(
     const float* __restrict__ sdf, const int32_t* __restrict__ cell, int32_t m,
-    const float* __restrict__ inv_s_p, float half_step, float decay, float* __restrict__ occs,
-    float* __restrict__ occ_out) {
+    const float* __restrict__ inv_s_p, float half_step, int32_t* __restrict__ amax) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const float inv_s = fminf(fmaxf(*inv_s_p, 1e-6f), 1e6f);
@@ -96,19 +105,29 @@ __global__ __launch_bounds__(256) void occ_alpha_ema_kernel(
   const float next = s - half_step, prev = s + half_step;
   const float pc = sigmoidf_(prev * inv_s), nc = sigmoidf_(next * inv_s);
   const float a = fminf(fmaxf(((pc - nc) + 1e-5f) / (pc + 1e-5f), 0.0f), 1.0f);
-  if (occ_out) occ_out[i] = a;
   const int32_t c = cell[i];
-  if (c >= 0) occs[c] = fmaxf(occs[c] * decay, a);   // duplicates race like the indexed torch form
+  // alpha >= 0: its bit pattern orders like the value and beats the preset -1.0f (negative as int)
+  if (c >= 0) atomicMax(&amax[c], __float_as_int(a));
 }
 
 constexpr int SUM_BLOCKS = 256;
 
-__global__ __launch_bounds__(256) void occ_sum_kernel(const float* __restrict__ occs, int32_t n,
-                                                      double* __restrict__ partial) {
+// EMA of the visited cells (amax >= 0) and the partial sums of the updated grid in one pass
+__global__ __launch_bounds__(256) void occ_ema_sum_kernel(float* __restrict__ occs,
+                                                          const int32_t* __restrict__ amax,
+                                                          float decay, int32_t n,
+                                                          double* __restrict__ partial) {
   __shared__ double red[256];
   double acc = 0.0;
-  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
-    acc += (double)occs[i];
+  for (int32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    float v = occs[i];
+    const int32_t ab = amax[i];
+    if (ab >= 0) {
+      v = fmaxf(v * decay, __int_as_float(ab));
+      occs[i] = v;
+    }
+    acc += (double)v;
+  }
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int o = 128; o > 0; o >>= 1) {
@@ -148,7 +167,7 @@ struct Carve {
 };
 
 struct Ws {
-  int32_t *iota, *occupied, *n_occupied, *cell;
+  int32_t *iota, *occupied, *n_occupied, *cell, *amax;
   float *pts, *sdf;
   double* partial;
   void* cub;
@@ -169,6 +188,7 @@ int carve(int32_t res, char* base, Ws& w) {
   w.cell = k.take<int32_t>(n);            // capacity: every cell (warm-up); 2 x n/4 afterwards
   w.pts = k.take<float>(3 * n);
   w.sdf = k.take<float>(n);
+  w.amax = k.take<int32_t>(n);            // per cell: bits of the largest alpha drawn, -1.0f = not visited
   w.partial = k.take<double>(SUM_BLOCKS);
   w.cub = k.take<char>((int64_t)b);
   w.cub_bytes = b;
@@ -220,14 +240,16 @@ int dsu_occgrid_refresh(const dsu_occgrid_refresh_args* a, void* stream) {
   occ_points_kernel<<<dsu_blocks_for(m, 256), 256, 0, s>>>(
       a->seed, a->step, a->res, n, n_uni, a->all_cells ? 1 : 0, w.occupied, w.n_occupied, a->inj_cells,
       a->inj_rand, a->aabb[0], a->aabb[1], a->aabb[2], a->aabb[3], a->aabb[4], a->aabb[5], m, w.cell,
-      w.pts);
+      w.pts, a->cells_out, a->rand_out);
   DSU_CHECK_LAUNCH();
   rc = dsu_sdf_fwd(a->grid, a->table_img, a->mlp, w.pts, m, a->radius, a->active_levels, 1, w.sdf, s);
   if (rc) return rc;
   const float half_step = (float)((double)a->render_step_size * 0.5);
-  occ_alpha_ema_kernel<<<dsu_blocks_for(m, 256), 256, 0, s>>>(w.sdf, w.cell, m, a->inv_s, half_step,
-                                                             a->ema_decay, a->occs, nullptr);
-  occ_sum_kernel<<<SUM_BLOCKS, 256, 0, s>>>(a->occs, n, w.partial);
+  if (hipMemsetD32Async((hipDeviceptr_t)w.amax, (int)0xBF800000u, (size_t)n, s) != hipSuccess)   // -1.0f
+    return DSU_ELAUNCH;
+  occ_alpha_kernel<<<dsu_blocks_for(m, 256), 256, 0, s>>>(w.sdf, w.cell, m, a->inv_s, half_step,
+                                                         w.amax);
+  occ_ema_sum_kernel<<<SUM_BLOCKS, 256, 0, s>>>(a->occs, w.amax, a->ema_decay, n, w.partial);
   occ_binarize_kernel<<<dsu_blocks_for(n, 256), 256, 0, s>>>(a->occs, n, w.partial, a->occ_thre,
                                                             a->binary, a->thre_out);
   DSU_CHECK_LAUNCH();

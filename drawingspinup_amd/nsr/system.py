@@ -456,11 +456,13 @@ class NativeStepDriver:
     def system(self):
         return self._system()
 
-    def occ_refresh(self, grid, step, all_cells, occ_thre, ema_decay, inj_cells=None, inj_rand=None):
+    def occ_refresh(self, grid, step, all_cells, occ_thre, ema_decay, inj_cells=None, inj_rand=None,
+                    export=None):
         """OccupancyGrid._update through dsu_nsr_driver_occ_refresh: selection of the cells, points,
         SDF with the driver's effective weights, alpha, EMA, mean, binarisation — on the current
         stream, no host round trip.  Returns False (the caller's torch path runs) before the
-        driver's first step, when its effective weights do not exist yet."""
+        driver's first step, when its effective weights do not exist yet.  export: a dict that
+        receives "cells" (int32, -1 = unused slot) and "rand" (x 3 uniforms) of the call (tests)."""
         C, _lib = self.C, self._lib
         if self.handle is None or not self.stepped or self.system is None:
             return False
@@ -485,6 +487,12 @@ class NativeStepDriver:
             ir = inj_rand.to(dev, torch.float32).contiguous()
             keep += [ic, ir]
             a.inj_count, a.inj_cells, a.inj_rand = int(ic.numel()), ic.data_ptr(), ir.data_ptr()
+        if export is not None:
+            m = int(ic.numel()) if inj_cells is not None else \
+                (grid.num_cells if all_cells else 2 * (grid.num_cells // 4))
+            export["cells"] = torch.empty(m, dtype=torch.int32, device=dev)
+            export["rand"] = torch.empty(m, 3, dtype=torch.float32, device=dev)
+            a.cells_out, a.rand_out = export["cells"].data_ptr(), export["rand"].data_ptr()
         a.workspace, a.workspace_bytes = self._occ_ws.data_ptr(), need
         ops.check(_lib.lib().dsu_nsr_driver_occ_refresh(self.handle, C.byref(a), ops.stream()),
                   "dsu_nsr_driver_occ_refresh")

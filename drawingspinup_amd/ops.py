@@ -625,8 +625,13 @@ def accumulate_fwd(weights, values, offsets, counts):
 
 
 def occgrid_ema(occs, idx, occ, decay):
+    """occs[idx] = max(occs[idx] * decay, occ): old values gathered first; a cell listed several
+    times is decayed once and keeps its largest candidate."""
+    scratch = torch.empty(occ.shape[0], dtype=torch.float32, device=occs.device) \
+        if idx is not None else None
     check(lib().dsu_occgrid_ema(ptr(occs, torch.float32), ptr(idx, torch.int64) if idx is not None
-                                else None, ptr(_f32c(occ)), occ.shape[0], float(decay), stream()),
+                                else None, ptr(_f32c(occ)), occ.shape[0], float(decay),
+                                ptr(scratch) if scratch is not None else None, stream()),
           "dsu_occgrid_ema")
 
 

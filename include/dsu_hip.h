@@ -284,9 +284,11 @@ int dsu_accumulate_fwd(const float* weights, const float* values, int32_t channe
                        float* out, void* stream);
 
 /* OccupancyGrid._update tail (nerfacc 0.3.3 grid.py): occs[idx] = max(occs[idx]*decay, occ).
- * idx may be NULL (= all cells, warm-up). */
+ * idx may be NULL (= all cells, warm-up; scratch unused).  With idx, every old value is read
+ * before any is written (the indexed assignment gathers first) and a cell listed several times
+ * keeps the largest of its candidates: scratch = n floats of the caller. */
 int dsu_occgrid_ema(float* occs, const int64_t* idx, const float* occ, int64_t n, float decay,
-                    void* stream);
+                    float* scratch, void* stream);
 /* binary = occs > thre  (thre = min(mean(occs), occ_thre) computed by the caller). */
 int dsu_occgrid_binarize(const float* occs, int64_t n_cells, float thre, uint8_t* binary,
                          void* stream);
@@ -298,9 +300,15 @@ int dsu_occgrid_binarize(const float* occs, int64_t n_cells, float thre, uint8_t
  * (cell + U[0,1)^3) / res in the aabb -> dsu_sdf_fwd -> occ = clip((sigmoid(prev inv_s) -
  * sigmoid(next inv_s) + 1e-5) / (sigmoid(prev inv_s) + 1e-5)), prev / next = sdf +- render_step_size/2
  * -> occs[c] = max(occs[c] ema_decay, occ) -> binary = occs > min(mean(occs), occ_thre).
+ * A cell drawn several times is decayed once and keeps the largest of its occ values (one of the
+ * outcomes of nerfacc's indexed assignment, whose winner among duplicates is unspecified; the old
+ * values are all gathered before any is written, as there).
  * Draws: Philox4x32-10 keyed (seed, step), streams 8-10.  inj_cells / inj_rand (device, inj_count
  * cells and inj_count x 3 uniforms; tests) replace the draws.  thre_out (device, may be NULL)
- * receives the threshold.  workspace: dsu_occgrid_refresh_workspace_bytes(res) (< 0: invalid). */
+ * receives the threshold.  cells_out / rand_out (device, may be NULL; capacity res^3 cells while
+ * all_cells, else 2 (res^3 / 4), x 3 uniforms): the cells (-1 = unused slot) and uniforms the call
+ * evaluated, so that a caller can replay the update.  workspace:
+ * dsu_occgrid_refresh_workspace_bytes(res) (< 0: invalid). */
 typedef struct dsu_occgrid_refresh_args {
   float* occs;               /* (res^3) f32, updated in place */
   uint8_t* binary;           /* (res^3) u8: read (occupied cells), then rewritten */
@@ -320,6 +328,8 @@ typedef struct dsu_occgrid_refresh_args {
   float* thre_out;
   void* workspace;
   int64_t workspace_bytes;
+  int32_t* cells_out;
+  float* rand_out;
 } dsu_occgrid_refresh_args;
 int64_t dsu_occgrid_refresh_workspace_bytes(int32_t res);
 int dsu_occgrid_refresh(const dsu_occgrid_refresh_args* args, void* stream);

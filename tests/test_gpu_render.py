@@ -132,6 +132,15 @@ def test_occgrid(dev):
     exp = before.clone()
     exp[idx] = torch.maximum(before[idx] * 0.95, occ2)
     assert torch.equal(t, exp)
+    # cells listed several times: every old value is gathered before any is written (nerfacc's
+    # `occs[idx] = max(occs[idx] * decay, occ)`), i.e. ONE decay, and the largest candidate stays
+    dup = torch.from_numpy(g.integers(0, 64, 5000).astype(np.int64)).to(dev)
+    occ3 = torch.from_numpy((g.random(5000) * 0.004).astype(np.float32)).to(dev)
+    before = t.clone()
+    ops.occgrid_ema(t, dup, occ3, 0.95)
+    best = torch.full_like(before, -1.0).scatter_reduce(0, dup, occ3, "amax", include_self=True)
+    exp = torch.where(best >= 0, torch.maximum(before * 0.95, best), before)
+    assert torch.equal(t, exp)
 
 
 def test_single_pass_march_equals_two_pass(dev):
