@@ -155,7 +155,7 @@ def cpu_baseline(nsr_steps, frames, mv_steps):
     path for its CUDA-only ops, so the baseline runs (a) this repository's restatements that are
     pinned to the reference's own classes by fixtures and execute the SAME torch CPU operators
     the reference's modules would (FFC-ResNet generator, GeneratorJ: nn.Conv2d / BatchNorm /
-    activations), (b) the float64 UNet oracle, (c) the torch-CPU form of the hash-grid oracle
+    activations), (b) the UNet oracle run in float32, (c) the torch-CPU form of the hash-grid oracle
     (all `cores` threads).  Each leg is a bounded sample, extrapolated by the stated factor."""
     from oracle import mv_ref as mr, style_net_ref as snr
     # at most 32 threads: on the GPU box's 256 hardware threads torch's CPU convolutions ran 10-90x
@@ -180,21 +180,21 @@ def cpu_baseline(nsr_steps, frames, mv_steps):
     with torch.no_grad():
         t = time.time(); snr.generator_j_forward(g2, xf); t_g2 = time.time() - t
     legs["style_s"] = frames * t_g2 * (271.9 + 148.8) / 271.9
-    # (b) diffusion: ONE UNet forward of the full-width architecture at B=12 on 16x16 latents in
-    # the float64 oracle, scaled to the BASELINE 32x32 shape by algorithmic work (SURVEY.md 8d:
-    # convolutions / linears 1088.9 GMAC scale x4, attention 367.5 GMAC x16 -> 1456.3 / 295.2 =
-    # x4.93), x75 steps (VAE / CLIP not charged)
+    # (b) diffusion: ONE UNet forward of the full-width architecture at the BASELINE shape
+    # (12, 8, 32, 32) in float32 through the oracle's functional UNet
+    # (torch CPU convolutions / linears / attention), x75 steps (VAE / CLIP not charged)
     from drawingspinup_amd.mv.unet import UNetMV2DConditionModel
     torch.manual_seed(0)
     un = UNetMV2DConditionModel().half()
     ref = mr.UNetRef(un.state_dict(), (320, 640, 1280, 1280),
                      ("CrossAttnDownBlockMV2D",) * 3 + ("DownBlock2D",),
-                     ("UpBlock2D",) + ("CrossAttnUpBlockMV2D",) * 3, layers_per_block=2)
+                     ("UpBlock2D",) + ("CrossAttnUpBlockMV2D",) * 3, layers_per_block=2,
+                     dtype=torch.float32)
     g = torch.Generator().manual_seed(1)
-    sample = torch.randn(12, 8, 16, 16, generator=g)
+    sample = torch.randn(12, 8, 32, 32, generator=g)
     t = time.time()
     ref(sample, torch.tensor([500]), torch.randn(12, 1, 768, generator=g), torch.randn(12, 10, generator=g))
-    t_unet = (time.time() - t) * 4.93
+    t_unet = time.time() - t
     legs["mv_s"] = mv_steps * t_unet
     del un, ref
     # (c) NSR: the geometry network's share of one optimisation step (7 finite-difference
@@ -211,8 +211,8 @@ def cpu_baseline(nsr_steps, frames, mv_steps):
     return {"value": 1.0 / total, "unit": "drawings/s", "cores": cores, "kind": "port",
             "seconds_per_drawing": total, "legs_seconds": legs,
             "sample": ("host cores, torch CPU / numpy: one 512^2 FFC-ResNet forward (%.2f s); one 512^2 "
-                       "GeneratorJ frame (%.2f s) x %d frames x (272+149)/272 GMAC; one float64 oracle "
-                       "UNet forward at B=12 (16x16 latents, x4.93 by work to 32x32: %.1f s) x %d steps; "
+                       "GeneratorJ frame (%.2f s) x %d frames x (272+149)/272 GMAC; one float32 UNet "
+                       "forward at (12,8,32,32) through the oracle's functional UNet (%.1f s) x %d steps; "
                        "geometry forward+backward (7 evaluations per point, torch CPU autograd, %d threads) "
                        "of %d points (%.2f s) x 266 240 / %d x %d steps + 2 x 512^3 export evaluations "
                        "at the forward rate"
@@ -240,7 +240,7 @@ def run(args):
         out = bench_drawing(args, ddist, rank, world, dev, timer)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_initialized():        # world > 1, or the forced one-rank group
         torch.distributed.destroy_process_group()
 
 
@@ -309,8 +309,8 @@ def _roofline(timer, extra=None):
     # workload's algorithmic bytes; the measured ratio is applied to this run's mean algorithmic
     # bytes per launch.
     pmc = _pmc()
-    fam = {"sdf_fd_bwd": ("sdf_fd_bwd_mfma_kernel", "sdf_fd_scatter_kernel", "reduce_partials_mfma_kernel"),
-           "sdf_fd_fwd": ("sdf_fd_fwd_kernel",)}
+    fam = {"sdf_fd_bwd": ("sdf_fd_bwd_mfma_kernel", "sdf_fd_scatter_kernel"),
+           "sdf_fd_fwd": ("sdf_fd_fwd_kernel", "sdf_fd_fwd_shared_kernel")}
     top["traffic"] = None
     if pmc and top["kernel"] in fam:
         side = sum(v.get("hbm_side_bytes", 0.0) for k, v in pmc["kernels"].items()
@@ -321,6 +321,25 @@ def _roofline(timer, extra=None):
     if extra:
         top.update(extra)
     return top
+
+
+def _style_exact_f32_seconds(pipe, inp, dev):
+    try:
+        from drawingspinup_amd.style import generators
+    except ImportError:
+        return None
+    if not hasattr(pipe, "stylize") or not getattr(generators, "EVAL_X3", False):
+        return None
+    _, frames_in, edges_in = inp
+    generators.EVAL_X3 = False
+    try:
+        pipe.stylize(frames_in[:2], edges_in[:2])             # warm-up (weight layouts, tap tables)
+        _sync(dev); t = time.time()
+        pipe.stylize(frames_in, edges_in)
+        _sync(dev)
+        return time.time() - t
+    finally:
+        generators.EVAL_X3 = True
 
 
 def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
@@ -379,14 +398,19 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
     assert len(gathered["views"]) == world and len(gathered["frames"]) == world
     per = {k: v / args.steps for k, v in stage_t.items()}
     per.update({k: v / args.steps for k, v in sub_t.items()})
+    # beside the clock: the stylisation stage once more with the exact-f32 kernels (f32 MFMA; the
+    # arithmetic of the reference's deform_conv2d -> sgemm path, TF32 off), so that the cost of the
+    # headline with them can be read off: value_exact_f32_style = 1 / (s/drawing - style + this)
+    per["style_exact_f32"] = _style_exact_f32_seconds(pipe, inputs[(True, args.steps - 1)], dev)
     stages = {
         "mv": {"bound": "mfma", "unit": "TFLOP/s", "peak": F16_MFMA_PEAK_TF,
                "achieved": 2.913 * args.mv_steps / max(per["mv"], 1e-9)},
-        # evaluation convolutions run as bf16 x 3 (three bf16 MFMA products per f32 product):
-        # achieved = 3 x the 0.84 algorithmic TFLOP of one frame's two generators / stage time
+        # achieved = ALGORITHMIC flops (0.84 TFLOP per frame for the two generators)
+        # / stage time.  The evaluation convolutions issue three bf16 MFMA products per f32 product
+        # (bf16 x 3): the matrix pipe's issued rate is reported beside it, not as the fraction.
         "style": {"bound": "mfma", "unit": "TFLOP/s", "peak": F16_MFMA_PEAK_TF,
-                  "achieved": 3 * 0.84 * args.frames / max(per["style"], 1e-9),
-                  "algorithmic_tflops": 0.84 * args.frames / max(per["style"], 1e-9),
+                  "achieved": 0.84 * args.frames / max(per["style"], 1e-9),
+                  "issued_mfma_tflops": 3 * 0.84 * args.frames / max(per["style"], 1e-9),
                   "f32_mfma_peak": F32_MFMA_PEAK_TF},
     }
     for st in stages.values():
@@ -400,7 +424,7 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
                 stages[name][field] = v
     roof = _roofline(timer, {"stages": stages,
                              "traffic_note": "HBM-side bytes per launch of the dominant family "
-                                             "(MLP part + scatter + partial reduce): (2 x FETCH_SIZE + "
+                                             "(MLP part + scatter): (2 x FETCH_SIZE + "
                                              "WRITE_SIZE) of this round's separate rocprofv3 --pmc passes "
                                              "(profiles/round4_pmc.json, tools/pmc_round4.sh) relative to "
                                              "that workload's algorithmic bytes, applied to this run's "
@@ -410,7 +434,8 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
         "value": world * args.steps / elapsed, "unit": "drawings/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 (diffusion) / f16 table + f32 MLP (NSR) / f32 with bf16 x 3 products (stylisation) / f32 (contour)",
+        "dtype": "f16 (diffusion) / f16 table + f32 MLP (NSR) / f32 with bf16 x 3 products (stylisation; "
+                 "exact-f32 stage time in config.stage_seconds_rank0.style_exact_f32) / f32 (contour)",
         "data": "synthetic",
         "config": {"workload": "one drawing per GPU: contour removal (FFC-ResNet generator, masks, host "
                                "TELEA inpainting, 512^2) -> 6-view diffusion (%d DDIM steps, B=12) -> NSR "
@@ -419,7 +444,10 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
                                "back-projection + shear: the reference YAML's export switches for a uid "
                                "outside the thinning list) -> %d-frame stage1+stage2 stylisation (stage 2 "
                                "on the edge-overlaid stage-1 output); NOT timed: Blender, PNG / OBJ file "
-                               "I/O" % (args.mv_steps, args.nsr_steps, args.frames),
+                               "I/O.  Image resampling between the stages is torch bicubic on the device "
+                               "here (the entry scripts mv.py / recon.py use the Pillow LANCZOS / "
+                               "bicubic routes pinned by tests/test_mv_preprocess.py; no effect on the "
+                               "timing)" % (args.mv_steps, args.nsr_steps, args.frames),
                    "drawings_per_step": world, "parallelism": f"replica-per-drawing x{world}",
                    "stage_seconds_rank0": per, "weights_broadcast_bytes": bcast_bytes,
                    "gathered_bytes_per_step": sum(t.numel() * t.element_size() for k in gathered
@@ -510,9 +538,11 @@ def bench_frames(args, ddist, rank, world, dev, timer, pipe=None, size=512):
                                    "rank 0" % args.frames,
                        "frames_per_rank": len(mine), "parallelism": f"frame-shard x{world}",
                        "gathered_frames_checksum": int(ordered.to(torch.int64).sum())},
+            # algorithmic flops (0.84 TFLOP per frame) / time; the bf16 x 3 kernels
+            # issue three MFMA products per f32 product, reported beside it
             "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F16_MFMA_PEAK_TF,
-                         "achieved": 3 * 0.84 * fps, "frac": 3 * 0.84 * fps / F16_MFMA_PEAK_TF,
-                         "algorithmic_tflops": 0.84 * fps, "f32_mfma_peak": F32_MFMA_PEAK_TF,
+                         "achieved": 0.84 * fps, "frac": 0.84 * fps / F16_MFMA_PEAK_TF,
+                         "issued_mfma_tflops": 3 * 0.84 * fps, "f32_mfma_peak": F32_MFMA_PEAK_TF,
                          "traffic": None, "kernels": timer.summary()[:3]}}
 
 

@@ -17,6 +17,7 @@
 //   feature:  acc = fma((f16)weight, table[index], acc) in binary16 for c = 0..7 (f16 FMA,
 //             one rounding per step), exactly tcnn's half-precision accumulation.
 #include "hashgrid_dev.h"
+#include <utility>
 
 using namespace dsu_hg;
 
@@ -307,18 +308,20 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
     const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
     uint32_t active, float* __restrict__ sdf, float* __restrict__ grad,
     float* __restrict__ feature, float* __restrict__ laplace, __half2* __restrict__ enc,
-    const int32_t* __restrict__ perm) {
+    const int32_t* __restrict__ perm, int fixup) {
   using L = MlpLds<NL>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   DSU_FWD_LOAD_MLP(NL, lds, mlp);
   const int kmax = 3 + 2 * (int)active;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
-    const float p[3] = {pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2]};
     // spatially sorted evaluation order (spatial_sort.hip): point i of `pts` is point perm[i] of
     // the caller's order; the per-point outputs go back to the caller's rows, the feature cache
     // stays in evaluation order (the backward pass walks it in the same order)
     const int64_t oi = perm ? (int64_t)perm[i] : i;
+    // fix-up mode: only the rows the level-outer kernel left as NaN
+    if (fixup && !(sdf[oi] != sdf[oi])) continue;
+    const float p[3] = {pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2]};
     float s[7];
 #pragma unroll 1
     for (int e = 0; e < 7; ++e) {
@@ -344,6 +347,18 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
         for (int l = 0; l < LMAX; ++l)
           if ((uint32_t)l < active) row[l] = __floats2half2_rn(in[3 + 2 * l], in[3 + 2 * l + 1]);
       }
+#if defined(DSU_FWD_ABLATE) && (DSU_FWD_ABLATE & 1)
+      if (true) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int k = 0; k < 3 + 2 * LMAX; ++k) acc += k < kmax ? in[k] : 0.0f;
+        s[e] = acc;
+        if (e == 0 && feature != nullptr) {
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o) feature[oi * NOUT + o] = acc;
+        }
+      } else
+#endif
       if (e == 0 && feature != nullptr) {
         float o_[NOUT];
         DSU_MLP_STREAM(NL, NOUT, LMAX, lds, mlp, in, kmax, o_);
@@ -380,18 +395,29 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
 // centre's cell or moves to the neighbour that shares a face with it, so it reuses 8 or 4 of the
 // centre's corners and gathers 0 or 4 new entries instead of 8.  Same table entries, same weights,
 // same f16 FMA chain over corners 0..7 -> the features are bit-identical to lookup_level's.
-// (Anything else — a clamped point outside the box, an eps of more than a cell — takes the full
-// 8-corner lookup.)  Gathers per point and level: 8 + 4 x (crossings) ~ 17-25 instead of 56.
+// Gathers per point and level: 8 + 4 x (crossings) ~ 17-25 instead of 56.
+//
+// REGULAR points only: every evaluation inside the unit cube (then the other two axes keep their
+// cell, cell coordinates stay in [0, res] and a dense index needs at most one subtraction of the
+// level size instead of tcnn's modulo) and every offset within one cell of the centre.  A point
+// that is not (outside the box, clamped, an eps of more than a cell) gets sdf = NaN and nothing
+// else here; the evaluation-by-evaluation kernel then runs in fix-up mode over the NaN rows (a
+// genuine NaN is recomputed to the same NaN).  ND: levels below ND are dense, the others hashed
+// (4 for the shipped grid; the launcher checks the level table against it).
+//
 // Then the MLP with the hidden units outer and the 7 evaluations inner: one set of scalar weight
 // loads serves 7 evaluations; the interpolated features stay packed f16 in registers and enter
 // the f32 FMAs through the mixed-precision form (widening is exact), the FMA chains (k ascending
 // for the pre-activations, j ascending for the outputs) are those of mlp_stream.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ __half2 interp8(const CellPos& p, const __half2* v) {
+__device__ __forceinline__ __half2 interp8(const float (&fr)[3], const __half2* v) {
   __half2 acc = __float2half2_rn(0.0f);
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
-    float wf = corner_weight(p, c);
+    float wf = 1.0f;                                   // corner_weight's product, same order
+    wf *= (c & 1) ? fr[0] : 1.0f - fr[0];
+    wf *= (c & 2) ? fr[1] : 1.0f - fr[1];
+    wf *= (c & 4) ? fr[2] : 1.0f - fr[2];
     asm volatile("" : "+v"(wf));     // f32 product rounded before the f16 conversion (see lookup_level)
     const __half w = __float2half_rn(wf);
     acc = __hfma2(__half2(w, w), v[c], acc);
@@ -399,8 +425,161 @@ __device__ __forceinline__ __half2 interp8(const CellPos& p, const __half2* v) {
   return acc;
 }
 
-template <int NL, int ACT, bool FEAT>
-__global__ __launch_bounds__(256) void sdf_fd_fwd_shared_kernel(
+// probe builds (tools/fwd_phase_probe.py): DSU_FWD_ABLATE bit 0 = no MLP, bit 1 = no table traffic
+#if defined(DSU_FWD_ABLATE) && (DSU_FWD_ABLATE & 2)
+__device__ __forceinline__ __half2 fwd_fake_load(uint32_t idx) {
+  uint32_t b = (idx & 0x03FF03FFu) | 0x20002000u;
+  return *reinterpret_cast<__half2*>(&b);
+}
+#define DSU_FWD_LOAD(lvl, idx) fwd_fake_load(idx)
+#else
+#define DSU_FWD_LOAD(lvl, idx) (lvl)[idx]
+#endif
+
+// One level of the 7 evaluations of a regular point, as function templates so that the level
+// index is a constant in every instance (a `#pragma unroll`ed loop over levels with this body is
+// refused by the optimizer beyond a size limit, and f[][l] then lives in scratch).
+// What one level keeps between issuing its requests and interpolating: the centre's fractions, the
+// six offsets' fraction / cell step along their axis, the centre's corners, the new faces.
+// (plain arrays with constant indices, two slots; a struct passed down by reference ended up in
+// scratch memory)
+struct FdLevelState {
+  float (&fc)[3];
+  float (&fa)[6];
+  int (&rel)[6];
+  __half2 (&v)[8];
+  __half2 (&g)[6][4];
+};
+
+// Requests of one level for a regular point: 8 corners of the centre's cell + (per offset
+// evaluation that leaves the cell) the 4 entries of the face the centre's cell does not have.
+// Nothing here waits for a load: the new faces' registers are preset to zero, NOT to one of the
+// centre's corners — `rel ? g : v` made the compiler copy v into g's register ahead of the
+// conditional load, i.e. wait for the centre's corners before requesting the faces (two dependent
+// round trips per level).
+template <int l, int ND>
+__device__ __forceinline__ void fd_level_issue(const __half2* __restrict__ table, const GridMeta& m,
+                                               const float (&q)[7][3], FdLevelState& st, bool& bad) {
+  constexpr bool HASHED = l >= ND;
+  const uint32_t hsize = m.off[l + 1] - m.off[l];
+  const __half2* lvl = table + m.off[l];
+  const float scale = m.scale[l];
+  const CellPos pc = cell_of(scale, q[0][0], q[0][1], q[0][2]);
+  // index = combine(term of x, term of y, term of z); the term of coordinate c + 1 (c - 1) is the
+  // term of c plus (minus) the axis' step: x, y * prime / y * res, z * prime / z * res^2
+  const uint32_t res = m.res[l];
+  const uint32_t step[3] = {1u, HASHED ? 2654435761u : res, HASHED ? 805459861u : res * res};
+  uint32_t term[3][2];
+#pragma unroll
+  for (int a = 0; a < 3; ++a) {
+    term[a][0] = pc.c[a] * step[a];
+    term[a][1] = term[a][0] + step[a];
+    st.fc[a] = pc.f[a];
+  }
+  auto index = [&](uint32_t tx, uint32_t ty, uint32_t tz) -> uint32_t {
+    if (HASHED) return (tx ^ ty ^ tz) & (hsize - 1);
+    const uint32_t idx = tx + ty + tz;                 // < 2 * hsize for coordinates in [0, res]
+    return idx >= hsize ? idx - hsize : idx;
+  };
+#pragma unroll
+  for (int c = 0; c < 8; ++c)
+    st.v[c] = DSU_FWD_LOAD(lvl, index(term[0][c & 1], term[1][(c >> 1) & 1], term[2][(c >> 2) & 1]));
+#pragma unroll
+  for (int t = 0; t < 6; ++t) {
+    const int ax = t >> 1, a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+    const float pa = fmaf(scale, q[t + 1][ax], 0.5f), fl = floorf(pa);
+    st.fa[t] = pa - fl;
+    st.rel[t] = (int)((uint32_t)(int)fl - pc.c[ax]);
+    bad = bad || st.rel[t] < -1 || st.rel[t] > 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st.g[t][k] = __float2half2_rn(0.0f);
+    if (st.rel[t] != 0) {
+      const uint32_t tn = st.rel[t] > 0 ? term[ax][1] + step[ax] : term[ax][0] - step[ax];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint32_t tt[3];
+        tt[ax] = tn;
+        tt[a1] = term[a1][k & 1];
+        tt[a2] = term[a2][k >> 1];
+        st.g[t][k] = DSU_FWD_LOAD(lvl, index(tt[0], tt[1], tt[2]));
+      }
+    }
+  }
+}
+
+template <int l, int ACT>
+__device__ __forceinline__ void fd_level_finish(const FdLevelState& st, __half2 (&f)[7][ACT]) {
+  f[0][l] = interp8(st.fc, st.v);
+#pragma unroll
+  for (int t = 0; t < 6; ++t) {
+    const int ax = t >> 1, a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+    float fr[3];
+    fr[ax] = st.fa[t];
+    fr[a1] = st.fc[a1];
+    fr[a2] = st.fc[a2];
+    __half2 w[8];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int lo = ((k & 1) << a1) | ((k >> 1) << a2), hi = lo | (1 << ax);
+      w[lo] = st.rel[t] == 0 ? st.v[lo] : (st.rel[t] > 0 ? st.v[hi] : st.g[t][k]);
+      w[hi] = st.rel[t] == 0 ? st.v[hi] : (st.rel[t] > 0 ? st.g[t][k] : st.v[lo]);
+    }
+    f[t + 1][l] = interp8(fr, w);
+  }
+  // pin the level's features HERE: without a use before the `bad` exit of the kernel, the optimizer
+  // sinks all the interpolation arithmetic behind that exit and keeps every gathered entry of every
+  // level alive until then (396 VGPRs at 4 levels)
+#pragma unroll
+  for (int e = 0; e < 7; ++e) {
+    uint32_t bits = *reinterpret_cast<const uint32_t*>(&f[e][l]);
+    asm volatile("" : "+v"(bits));
+    f[e][l] = *reinterpret_cast<const __half2*>(&bits);
+  }
+}
+
+// requests of level l + 1 go out before level l is interpolated (DSU_FWD_PIPE=1, two level states
+// alive) or after it (0)
+#ifndef DSU_FWD_PIPE
+#define DSU_FWD_PIPE 0
+#endif
+
+template <int ACT, int ND, int... Ls>
+__device__ __forceinline__ void fd_levels(const __half2* __restrict__ table, const GridMeta& m,
+                                          const float (&q)[7][3], __half2 (&f)[7][ACT], bool& bad,
+                                          std::integer_sequence<int, Ls...>) {
+  float fc[2][3], fa[2][6];
+  int rel[2][6];
+  __half2 v[2][8], g[2][6][4];
+  auto issue = [&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    if constexpr (l < ACT) {
+      constexpr int sl = DSU_FWD_PIPE ? (l & 1) : 0;
+      FdLevelState st{fc[sl], fa[sl], rel[sl], v[sl], g[sl]};
+      fd_level_issue<l, ND>(table, m, q, st, bad);
+    }
+  };
+  auto finish = [&](auto lc) {
+    constexpr int l = decltype(lc)::value;
+    constexpr int sl = DSU_FWD_PIPE ? (l & 1) : 0;
+    const FdLevelState st{fc[sl], fa[sl], rel[sl], v[sl], g[sl]};
+    fd_level_finish<l, ACT>(st, f);
+  };
+#if DSU_FWD_PIPE
+  issue(std::integral_constant<int, 0>{});
+  ((issue(std::integral_constant<int, Ls + 1>{}), finish(std::integral_constant<int, Ls>{})), ...);
+#else
+  ((issue(std::integral_constant<int, Ls>{}), finish(std::integral_constant<int, Ls>{})), ...);
+#endif
+}
+
+// waves per SIMD the register allocation aims at: 4 (128 VGPRs) up to 4 active levels, 3 (168) beyond
+#ifndef DSU_FWD_WAVES
+#define DSU_FWD_WAVES (ACT <= 4 ? 4 : 3)
+#endif
+
+template <int NL, int ACT, int ND, bool FEAT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(DSU_FWD_WAVES, DSU_FWD_WAVES)))
+void sdf_fd_fwd_shared_kernel(
     const __half2* __restrict__ table, GridMeta m, dsu_sdf_mlp mlp,
     const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
     float* __restrict__ sdf, float* __restrict__ grad, float* __restrict__ feature,
@@ -417,71 +596,33 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_shared_kernel(
     // contracted coordinates: q[0] the centre; evaluation e > 0 moves axis (e-1)/2 by +-eps and
     // clamps ALL axes to the box ((points_ + offsets).clamp(-radius, radius), geometry.py:170)
     float q[7][3];
+    bool bad = false;
 #pragma unroll
-    for (int a = 0; a < 3; ++a) q[0][a] = contract(p[a], radius);
+    for (int a = 0; a < 3; ++a) {
+      q[0][a] = contract(p[a], radius);
+      // inside the box: clamping leaves the unmoved axes alone, every evaluation stays in [0, 1]
+      bad = bad || !(p[a] >= -radius && p[a] <= radius) || !(q[0][a] >= 0.0f && q[0][a] <= 1.0f);
+    }
 #pragma unroll
     for (int e = 1; e < 7; ++e) {
       const int ax = (e - 1) >> 1;
       const float d = ((e - 1) & 1) ? -eps : eps;
 #pragma unroll
-      for (int a = 0; a < 3; ++a) {
-        const float v = p[a] + (a == ax ? d : 0.0f);
-        q[e][a] = contract(fminf(fmaxf(v, -radius), radius), radius);
-      }
+      for (int a = 0; a < 3; ++a) q[e][a] = q[0][a];
+      q[e][ax] = contract(fminf(fmaxf(p[ax] + d, -radius), radius), radius);
+      bad = bad || !(q[e][ax] >= 0.0f && q[e][ax] <= 1.0f);
+    }
+    if (bad) {                // addresses of an irregular point are not trusted: park it mid-cube
+#pragma unroll
+      for (int e = 0; e < 7; ++e)
+#pragma unroll
+        for (int a = 0; a < 3; ++a) q[e][a] = 0.5f;
     }
     __half2 f[7][ACT];
-#pragma unroll
-    for (int l = 0; l < ACT; ++l) {
-      const uint32_t hsize = m.off[l + 1] - m.off[l];
-      const __half2* lvl = table + m.off[l];
-      const CellPos pc = cell_of(m.scale[l], q[0][0], q[0][1], q[0][2]);
-      __half2 v[8];
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-        v[c] = lvl[grid_index(m.hashed[l], hsize, m.res[l], pc.c[0] + (c & 1),
-                              pc.c[1] + ((c >> 1) & 1), pc.c[2] + ((c >> 2) & 1))];
-      // the six offset evaluations: cell, relation to the centre's cell, new corners requested
-      CellPos pe[6];
-      int dcell[6];
-      bool odd[6];
-      __half2 g[6][4];
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        const int ax = t >> 1, a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
-        pe[t] = cell_of(m.scale[l], q[t + 1][0], q[t + 1][1], q[t + 1][2]);
-        dcell[t] = (int)(pe[t].c[ax] - pc.c[ax]);
-        odd[t] = pe[t].c[a1] != pc.c[a1] || pe[t].c[a2] != pc.c[a2] || dcell[t] < -1 || dcell[t] > 1;
-        if (!odd[t] && dcell[t] != 0) {
-          // the face of the new cell that the centre's cell does not have
-          const uint32_t ca = pe[t].c[ax] + (dcell[t] > 0 ? 1u : 0u);
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            uint32_t cc[3];
-            cc[ax] = ca;
-            cc[a1] = pc.c[a1] + (k & 1);
-            cc[a2] = pc.c[a2] + (k >> 1);
-            g[t][k] = lvl[grid_index(m.hashed[l], hsize, m.res[l], cc[0], cc[1], cc[2])];
-          }
-        }
-      }
-      f[0][l] = interp8(pc, v);
-#pragma unroll
-      for (int t = 0; t < 6; ++t) {
-        const int ax = t >> 1, a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
-        if (odd[t]) {
-          f[t + 1][l] = lookup_level(table, m, l, q[t + 1][0], q[t + 1][1], q[t + 1][2]);
-        } else {
-          __half2 w[8];
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {
-            const int lo = ((k & 1) << a1) | ((k >> 1) << a2), hi = lo | (1 << ax);
-            const __half2 gk = dcell[t] != 0 ? g[t][k] : v[lo];
-            w[lo] = dcell[t] == 0 ? v[lo] : (dcell[t] > 0 ? v[hi] : gk);
-            w[hi] = dcell[t] == 0 ? v[hi] : (dcell[t] > 0 ? gk : v[lo]);
-          }
-          f[t + 1][l] = interp8(pe[t], w);
-        }
-      }
+    fd_levels<ACT, ND>(table, m, q, f, bad, std::make_integer_sequence<int, ACT>{});
+    if (bad) {
+      sdf[oi] = __int_as_float(0x7FC00000);            // left to the fix-up pass
+      continue;
     }
     if (enc != nullptr) {
       // interpolated f16 features kept for the backward pass, layout [eval][point][active level]
@@ -504,8 +645,19 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_shared_kernel(
     for (int o = 0; o < NO0; ++o) o0[o] = b1[o];
 #pragma unroll
     for (int e = 1; e < 7; ++e) s[e] = b1[0];
+#if defined(DSU_FWD_ABLATE) && (DSU_FWD_ABLATE & 1)
+#pragma unroll
+    for (int e = 1; e < 7; ++e)
+#pragma unroll
+      for (int l = 0; l < ACT; ++l) s[e] += __low2float(f[e][l]) + __high2float(f[e][l]) + xin[e][l % 3];
+#pragma unroll
+    for (int l = 0; l < ACT; ++l) o0[0] += __low2float(f[0][l]) + __high2float(f[0][l]) + xin[0][l % 3];
+#pragma unroll 1
+    for (int j = HID; j < HID; j += DSU_FWD_JB) {
+#else
 #pragma unroll 1
     for (int j = 0; j < HID; j += DSU_FWD_JB) {
+#endif
 #pragma unroll
       for (int e = 0; e < 7; ++e) {
         float h[DSU_FWD_JB];
@@ -550,6 +702,36 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_shared_kernel(
       laplace[oi] = ((t0 + t1) + t2) / eps2;
     }
   }
+}
+
+#ifndef DSU_FWD_SHARED_LO
+#define DSU_FWD_SHARED_LO 4
+#endif
+#ifndef DSU_FWD_SHARED_HI
+#define DSU_FWD_SHARED_HI 7
+#endif
+
+template <int... Ks>
+void fd_shared_launch(uint32_t active, bool feat, int blocks, hipStream_t s, const __half2* table,
+                      const GridMeta& m, const dsu_sdf_mlp& mlp, const float* pts, int64_t n,
+                      float radius, float eps, float eps2, float* sdf, float* grad, float* feature,
+                      float* laplace, __half2* enc, const int32_t* perm, bool& launched,
+                      std::integer_sequence<int, Ks...>) {
+  constexpr int ND = 4;        // dense levels of the shipped grid (32 * 1.32^l, 2^19 entries)
+  for (int l = 0; l < (int)active; ++l)
+    if ((m.hashed[l] != 0) != (l >= ND)) return;
+  auto one = [&](auto act_c) {
+    constexpr int ACT = DSU_FWD_SHARED_LO + decltype(act_c)::value;
+    if ((int)active != ACT) return;
+    if (feat)
+      sdf_fd_fwd_shared_kernel<10, ACT, ND, true><<<dim3(blocks), dim3(DSU_FWD_THREADS), 0, s>>>(
+          table, m, mlp, pts, n, radius, eps, eps2, sdf, grad, feature, laplace, enc, perm);
+    else
+      sdf_fd_fwd_shared_kernel<10, ACT, ND, false><<<dim3(blocks), dim3(DSU_FWD_THREADS), 0, s>>>(
+          table, m, mlp, pts, n, radius, eps, eps2, sdf, grad, feature, laplace, enc, perm);
+    launched = true;
+  };
+  (one(std::integral_constant<int, Ks>{}), ...);
 }
 
 // LDS carve-up of the backward kernel (floats): MLP image | 4 per-wave staging areas | cache
@@ -990,40 +1172,21 @@ int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, cons
   hipStream_t s = (hipStream_t)stream;
   const float eps2 = (float)((double)eps * (double)eps);
   const int blocks = dsu_capped_blocks(n, DSU_FWD_THREADS, 8192 * (256 / DSU_FWD_THREADS));
+  int fixup = 0;
 #if !defined(DSU_FWD_PER_EVAL) && !defined(DSU_FWD_LDS_W)
-  // level-outer kernel with shared corners, one instance per number of active levels
-  if (active_levels >= 1 && !dsu_ab_is("DSU_FWD_KERNEL", "per_eval")) {
-#define DSU_FWD_SHARED_CASE(NLv, ACTv)                                                            \
-  case ACTv:                                                                                      \
-    if (feature)                                                                                  \
-      sdf_fd_fwd_shared_kernel<NLv, ACTv, true><<<dim3(blocks), dim3(DSU_FWD_THREADS), 0, s>>>(   \
-          (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, sdf, grad, feature,      \
-          laplace, (__half2*)enc_cache, perm);                                                    \
-    else                                                                                          \
-      sdf_fd_fwd_shared_kernel<NLv, ACTv, false><<<dim3(blocks), dim3(DSU_FWD_THREADS), 0, s>>>(  \
-          (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, sdf, grad, feature,      \
-          laplace, (__half2*)enc_cache, perm);                                                    \
-    break;
-    DSU_DISPATCH_NL(cfg->n_levels, {
-      switch (active_levels) {
-        DSU_FWD_SHARED_CASE(NL, 1) DSU_FWD_SHARED_CASE(NL, 2) DSU_FWD_SHARED_CASE(NL, 3)
-        DSU_FWD_SHARED_CASE(NL, 4) DSU_FWD_SHARED_CASE(NL, 5) DSU_FWD_SHARED_CASE(NL, 6)
-        DSU_FWD_SHARED_CASE(NL, 7) DSU_FWD_SHARED_CASE(NL, 8) DSU_FWD_SHARED_CASE(NL, 9)
-        DSU_FWD_SHARED_CASE(NL, 10)
-        default:
-          if constexpr (NL >= 12) {
-            switch (active_levels) {
-              DSU_FWD_SHARED_CASE(NL, 11) DSU_FWD_SHARED_CASE(NL, 12)
-              default: return DSU_EUNSUP;
-            }
-          } else {
-            return DSU_EUNSUP;
-          }
-      }
-    });
-#undef DSU_FWD_SHARED_CASE
-    DSU_CHECK_LAUNCH();
-    return DSU_OK;
+  // level-outer kernel with shared corners: one instance per number of active levels of the
+  // shipped grid (10 levels; the 3000-step schedule runs 4..6 of them, geometry.py:196-215);
+  // anything else takes the evaluation-by-evaluation kernel below
+  if (cfg->n_levels == 10 && active_levels >= DSU_FWD_SHARED_LO && active_levels <= DSU_FWD_SHARED_HI &&
+      !dsu_ab_is("DSU_FWD_KERNEL", "per_eval")) {
+    bool launched = false;
+    fd_shared_launch(active_levels, feature != nullptr, blocks, s, (const __half2*)table_f16, m, *mlp,
+                     pts, n, radius, eps, eps2, sdf, grad, feature, laplace, (__half2*)enc_cache, perm,
+                     launched, std::make_integer_sequence<int, DSU_FWD_SHARED_HI - DSU_FWD_SHARED_LO + 1>{});
+    if (launched) {
+      DSU_CHECK_LAUNCH();
+      fixup = 1;            // the rows it left as NaN go through the kernel below
+    }
   }
 #endif
   DSU_DISPATCH_NL(cfg->n_levels, {
@@ -1031,11 +1194,11 @@ int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, cons
     if (active_levels <= 6)
       sdf_fd_fwd_kernel<NL, 6><<<dim3(blocks), dim3(DSU_FWD_THREADS), shm, s>>>(
           (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, sdf, grad,
-          feature, laplace, (__half2*)enc_cache, perm);
+          feature, laplace, (__half2*)enc_cache, perm, fixup);
     else
       sdf_fd_fwd_kernel<NL, NL><<<dim3(blocks), dim3(DSU_FWD_THREADS), shm, s>>>(
           (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, sdf, grad,
-          feature, laplace, (__half2*)enc_cache, perm);
+          feature, laplace, (__half2*)enc_cache, perm, fixup);
   });
   DSU_CHECK_LAUNCH();
   return DSU_OK;

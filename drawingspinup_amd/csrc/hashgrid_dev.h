@@ -68,7 +68,11 @@ __device__ __forceinline__ __half2 lookup_level(const __half2* __restrict__ tabl
                         p.c[2] + ((c >> 2) & 1));
   __half2 v[8];
 #pragma unroll
+#if defined(DSU_FWD_ABLATE) && (DSU_FWD_ABLATE & 2)      // probe builds: no table traffic
+  for (int c = 0; c < 8; ++c) { uint32_t b = (idx[c] & 0x03FF03FFu) | 0x20002000u; v[c] = *reinterpret_cast<__half2*>(&b); }
+#else
   for (int c = 0; c < 8; ++c) v[c] = lvl[idx[c]];  // 8 independent 4-byte gathers in flight
+#endif
   __half2 acc = __float2half2_rn(0.0f);
 #pragma unroll
   for (int c = 0; c < 8; ++c) {

@@ -10,12 +10,34 @@ import torch
 import torch.distributed as dist
 
 
-def init(backend=None):
-    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local)."""
+_FORCED = False      # a process group of ONE rank whose collectives really run (see init)
+
+
+def _ranks_on_this_node(world):
+    """LOCAL_WORLD_SIZE (torchrun sets it); else `world` (single node assumed)."""
+    try:
+        n = int(os.environ.get("LOCAL_WORLD_SIZE", "0"))
+    except ValueError:
+        n = 0
+    return n if 0 < n <= world else world
+
+
+def _active():
+    return dist.is_initialized() and (dist.get_world_size() > 1 or _FORCED)
+
+
+def init(backend=None, force=None):
+    """Initialise torch.distributed from the torchrun environment.  Returns (rank, world, local).
+    force (default: DSU_DIST_FORCE=1 in the environment): create the process group even for a
+    world of one rank and run the collectives of this module on it — one GPU is enough to see RCCL
+    initialise and the broadcast / gather / all-reduce return (profiles/round5_rccl_world1.txt)."""
+    global _FORCED
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if force is None:
+        force = os.environ.get("DSU_DIST_FORCE", "0") == "1"
+    if (world > 1 or force) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -27,7 +49,8 @@ def init(backend=None):
         # serial finish of the decimation, sparse solves, torch's intra-op pools) get an equal
         # share instead of N pools of `cores` threads each
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        torch.set_num_threads(max(1, cores // world))
+        torch.set_num_threads(max(1, cores // _ranks_on_this_node(world)))
+        _FORCED = bool(force) and world == 1
     return rank, world, local
 
 
@@ -40,7 +63,7 @@ def shard(items, rank, world):
 def broadcast_module(module, src=0, bucket_bytes=256 << 20):
     """Broadcast every parameter and buffer of `module` from rank `src`, coalesced into large
     flat buckets (xGMI is point-to-point: few big messages, not one per tensor)."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return 0
     tensors = [t for t in list(module.parameters()) + list(module.buffers()) if t.numel() > 0]
     total = 0
@@ -68,7 +91,7 @@ def broadcast_module(module, src=0, bucket_bytes=256 << 20):
 def gather_tensor(t, dst=0):
     """Gather equally-shaped per-rank tensors on `dst` (list on dst, None elsewhere): a gather,
     not an all-gather — only rank `dst` receives the (small) outputs."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    if not _active():
         return [t]
     world = dist.get_world_size()
     out = [torch.empty_like(t) for _ in range(world)] if dist.get_rank() == dst else None
@@ -77,12 +100,12 @@ def gather_tensor(t, dst=0):
 
 
 def barrier():
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
 
 
 def max_over_ranks(value, device):
     t = torch.tensor([float(value)], device=device, dtype=torch.float64)
-    if dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

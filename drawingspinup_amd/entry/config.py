@@ -125,7 +125,10 @@ def load_config(*yaml_files, cli_args=()):
 
 
 def load_stage_job(stage, path=None):
-    """test_stage1.py:23-26: yaml.load(open('configs/config_stage1.yaml'))['job']."""
+    """test_stage1.py:23-26: yaml.load(open('configs/config_stage1.yaml'))['job'].  The built-in
+    copy stands in only for the implicit default file; an explicit `path` must exist."""
+    if path is not None and not os.path.isfile(path):
+        raise FileNotFoundError(f"{path}: no such stage-{stage} config file")
     path = path or f"configs/config_stage{stage}.yaml"
     if os.path.isfile(path):
         with open(path) as f:
@@ -136,6 +139,14 @@ def load_stage_job(stage, path=None):
 # ------------------------------------------------------------------------------------------------
 # adapters: YAML structure -> what OrthoNeuSSystem / NeuSModel consume
 # ------------------------------------------------------------------------------------------------
+def exp_lr_gamma(max_steps, constant_steps):
+    """${calc_exp_lr_decay_rate:0.1,${sub:max_steps,constant_steps}} (recon.py:13).  A run that ends
+    inside the constant phase (smoke runs: --max_steps <= constant_steps) never reaches the
+    exponential scheduler: factor 1.0 instead of the resolver's division by zero / growing rate."""
+    decay_steps = int(max_steps) - int(constant_steps)
+    return 0.1 ** (1.0 / decay_steps) if decay_steps > 0 else 1.0
+
+
 def nsr_configs(conf):
     """(model_config, system_config) of drawingspinup_amd.nsr.system.OrthoNeuSSystem from a resolved
     neuralangelo-ortho-wmask.yaml.  Options the HIP path does not implement raise instead of being
@@ -151,7 +162,7 @@ def nsr_configs(conf):
         raise NotImplementedError("system.scheduler: SequentialLR[ConstantLR(1.0), ExponentialLR] only")
     max_steps = int(conf["trainer"]["max_steps"])
     gamma = sch["schedulers"][1]["args"]["gamma"]
-    want = 0.1 ** (1.0 / (max_steps - s["constant_steps"]))
+    want = exp_lr_gamma(max_steps, s["constant_steps"])
     if abs(gamma - want) > 1e-12:
         raise NotImplementedError(f"ExponentialLR gamma {gamma}: only calc_exp_lr_decay_rate(0.1, "
                                   "max_steps - constant_steps) is implemented")

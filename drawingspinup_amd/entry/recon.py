@@ -62,14 +62,19 @@ def parse(argv=None):
     if args.max_steps is not None:
         conf["trainer"]["max_steps"] = args.max_steps
         sch = conf["system"]["scheduler"]["schedulers"][1]["args"]        # ${calc_exp_lr_decay_rate:...}
-        sch["gamma"] = 0.1 ** (1.0 / (args.max_steps - conf["system"]["constant_steps"]))
+        sch["gamma"] = C.exp_lr_gamma(args.max_steps, conf["system"]["constant_steps"])
     if args.resolution is not None:
         geo["isosurface"]["resolution"] = args.resolution
     return args, conf
 
 
 def uids_and_thinning(args, conf):
-    """recon.py:52-65: the uid list and, per uid, whether export.thinning survives."""
+    """recon.py:52-65: the uid list and, per uid, whether export.thinning applies.
+    Deliberate difference under --all: the reference sets `config.export.thinning = False` at the
+    first uid outside the thinning list and never restores it, so every LATER uid is exported
+    without thinning (and without the `_t` suffix) whatever the list says — an order-dependent
+    side effect that cannot survive sharding the uid list over ranks.  Here the list decides per
+    uid.  A single --uid run (the documented use, README step 2) is identical."""
     ds = conf["dataset"]
     if conf["export"]["thinning"]:
         with open(ds["thinning_uid_list_file"]) as f:             # the reference opens it unconditionally

@@ -552,7 +552,9 @@ class OrthoNeuSSystem:
         if self.device.type == "cuda":
             self.small_opt = SmallAdamW(self.optimizer, tuple(oc.betas), oc.eps)
         # ExponentialLR gamma = 0.1 ** (1 / (max_steps - constant_steps))  (recon.py:13)
-        self._gamma = 0.1 ** (1.0 / (self.config.max_steps - self.config.constant_steps))
+        # (a run that ends inside the constant phase never reaches the decay: factor 1)
+        decay_steps = self.config.max_steps - self.config.constant_steps
+        self._gamma = 0.1 ** (1.0 / decay_steps) if decay_steps > 0 else 1.0
         self.dataset = None
         self.last = {}
         self.use_loss_graph = self.device.type == "cuda"

@@ -94,16 +94,20 @@ def timestep_embedding(t, dim, flip_sin_to_cos=True, shift=0, dtype=torch.float6
 
 class UNetRef:
     def __init__(self, sd, block_out_channels, down_types, up_types, layers_per_block=2, heads=8,
-                 groups=32, eps=1e-5, num_views=6, cd_attention_mid=True, temb_dtype=torch.float64):
-        self.sd = dict(sd)               # widened to float64 on use (p())
+                 groups=32, eps=1e-5, num_views=6, cd_attention_mid=True, temb_dtype=torch.float64,
+                 dtype=torch.float64):
+        self.sd = dict(sd)               # widened to `dtype` on use (p())
         self.temb_dtype = temb_dtype
+        # float64: the oracle the tests compare with.  float32: bench.py's CPU-baseline leg (the
+        # arithmetic BASELINE.md section 2 names for the CPU run); never used as a checker.
+        self.dtype = dtype
         self.taps = None                 # set to {} to record named intermediates
         self.boc, self.down_types, self.up_types = block_out_channels, down_types, up_types
         self.lpb, self.heads, self.groups, self.eps = layers_per_block, heads, groups, eps
         self.num_views, self.cd_mid = num_views, cd_attention_mid
 
     def p(self, name):
-        return self.sd[name].double()
+        return self.sd[name].to(self.dtype)
 
     def tap(self, name, value):
         if self.taps is not None:
@@ -174,9 +178,10 @@ class UNetRef:
         return self.conv(pre + ".proj_out", h, padding=0) + res
 
     def __call__(self, sample, t, ctx, class_labels):
-        x, ctx, cl = sample.double(), ctx.double(), class_labels.double()
+        x, ctx, cl = sample.to(self.dtype), ctx.to(self.dtype), class_labels.to(self.dtype)
         B = x.shape[0]
-        temb = timestep_embedding(t.reshape(-1).expand(B), self.boc[0], dtype=self.temb_dtype)
+        temb = timestep_embedding(t.reshape(-1).expand(B), self.boc[0],
+                                  dtype=self.temb_dtype).to(self.dtype)
         emb = self.lin("time_embedding.linear_2", F.silu(self.lin("time_embedding.linear_1", temb)))
         self.tap("time_embedding", emb)
         cemb = self.lin("class_embedding.linear_2", F.silu(self.lin("class_embedding.linear_1", cl)))

@@ -156,3 +156,41 @@ def test_bench_frames_and_drawing_paths_world2():
     per_rank = 12 * 3 * 16 * 16 * 2 + 3 * 4 * 512 * 512
     assert d0["config"]["gathered_bytes_per_step"] == 2 * per_rank
     assert d0["config"]["weights_broadcast_bytes"] > 0 and "gather" in d0["config"]["stage_seconds_rank0"]
+
+
+def _forced_world1(port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port), DSU_DIST_FORCE="1", LOCAL_WORLD_SIZE="1")
+    from drawingspinup_amd import dist as ddist
+    r, w, _ = ddist.init(backend="gloo")
+    net = torch.nn.Linear(4, 3)
+    nbytes = ddist.broadcast_module(net, 0)
+    out = ddist.gather_tensor(torch.arange(3.0), 0)
+    ddist.barrier()
+    q.put((r, w, torch.distributed.is_initialized(), nbytes, [float(v) for v in out[0]],
+           ddist.max_over_ranks(2.5, "cpu")))
+    torch.distributed.destroy_process_group()
+
+
+def test_forced_single_rank_group_runs_the_collectives():
+    """DSU_DIST_FORCE=1: a process group of one rank is created and broadcast / gather /
+    all-reduce go through the backend instead of being short-circuited (the form that shows RCCL
+    alive on a 1-GPU box)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_forced_world1, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=120)
+    p.join(60)
+    assert got[:3] == (0, 1, True)
+    assert got[3] == (4 * 3 + 3) * 4            # the bytes really broadcast
+    assert got[4] == [0.0, 1.0, 2.0] and got[5] == 2.5
+
+
+def test_threads_are_shared_by_the_ranks_of_one_node(monkeypatch):
+    from drawingspinup_amd import dist as ddist
+    monkeypatch.setenv("LOCAL_WORLD_SIZE", "8")
+    assert ddist._ranks_on_this_node(16) == 8        # 2 nodes x 8 ranks: cores / 8, not / 16
+    monkeypatch.delenv("LOCAL_WORLD_SIZE")
+    assert ddist._ranks_on_this_node(4) == 4

@@ -95,3 +95,21 @@ def test_recon_cli_defaults_are_the_yaml(tmp_path):
     args, conf = recon.parse(["--uid", "u1", "--thinning_uid_list_file", str(tmp_path / "missing.json")])
     with pytest.raises(FileNotFoundError):
         recon.uids_and_thinning(args, conf)
+
+
+def test_explicit_stage_config_must_exist(tmp_path):
+    """A mistyped --config must not silently train with the shipped defaults."""
+    import pytest
+    with pytest.raises(FileNotFoundError):
+        C.load_stage_job(1, str(tmp_path / "config_stage1_typo.yaml"))
+
+
+def test_recon_max_steps_inside_the_constant_phase_keeps_the_rate():
+    """--max_steps <= system.constant_steps (smoke runs): no division by zero, no growing rate."""
+    from drawingspinup_amd.entry import recon
+    for m in ("500", "100"):
+        _, conf = recon.parse(["--uid", "u", "--max_steps", m])
+        assert conf["system"]["scheduler"]["schedulers"][1]["args"]["gamma"] == 1.0
+        C.nsr_configs(conf)                                   # accepted by the adapter
+    _, conf = recon.parse(["--uid", "u", "--max_steps", "600"])
+    assert abs(conf["system"]["scheduler"]["schedulers"][1]["args"]["gamma"] - 0.1 ** (1 / 100)) < 1e-12

@@ -205,6 +205,49 @@ def test_sdf_fd_feature_cache_round_trip(dev):
         assert float((a_ - b_).abs().max()) < 1e-5 * (float(a_.abs().max()) + 1e-12)
 
 
+@pytest.mark.parametrize("active", [4, 5, 6, 7])
+def test_sdf_fd_fwd_seven_evaluations_bit_exact(dev, active):
+    """The level-outer forward (corners of the centre's cell shared with the +-eps evaluations,
+    csrc/hashgrid.hip) against the same seven evaluations done one by one with the plain kernels:
+    the cached f16 features of every evaluation equal dsu_hashgrid_encode_fwd on the offset point
+    (geometry.py:160-171: offsets, clamp to the box, contraction), bit for bit, and sdf / feature
+    equal dsu_sdf_fwd's.  eps follows the reference's progressive rule (geometry.py:196-215:
+    the finest active level's cell) so that the shared-corner path is the one that runs; the rows
+    appended behind it take the fix-up path too: on the box faces, outside the box."""
+    radius = 1.0
+    tab = _table(91, 0.5).to(dev)
+    mlp = [m.to(dev) for m in _mlp(92)]
+    g = torch.Generator().manual_seed(93 + active)
+    pts = torch.rand(20000 + 37, 3, generator=g) * 2 - 1
+    edge = torch.tensor([[1.0, -1.0, 0.3], [-1.0, 1.0, 1.0], [0.99999, 0.0, -0.99999],
+                         [1.2, 0.1, 0.1], [0.0, -1.5, 0.7], [3.0, 3.0, -3.0]])
+    pts = torch.cat([pts, edge]).to(dev)
+    n = pts.shape[0]
+    eps = 2.0 * radius / (CFG.base_resolution * CFG.per_level_scale ** (active - 1))
+    sdf, grad, feat, lap, cache = ops.sdf_fd_fwd(CFG, tab, mlp, pts, radius, eps, active,
+                                                 enc_cache=True)
+    cache = cache.view(7, n, active, 2)
+    e32 = torch.tensor(eps, dtype=torch.float32, device=dev)
+    s = []
+    for e in range(7):
+        q = pts.clone()
+        if e > 0:
+            ax = (e - 1) // 2
+            q[:, ax] = q[:, ax] + (-e32 if (e - 1) & 1 else e32)
+            q = q.clamp(-radius, radius)
+        x = (q + radius) / (2 * radius)              # scale_anything(x, (-r, r), (0, 1))
+        enc = ops.hashgrid_encode_fwd(CFG, tab, x, active)
+        assert torch.equal(cache[e].reshape(n, -1), enc[:, :2 * active]), e
+        out = ops.sdf_fwd(CFG, tab, mlp, q, radius, active, n_out=13)
+        s.append(out[:, 0])
+        if e == 0:
+            assert torch.equal(feat, out)
+    assert torch.equal(sdf, s[0])
+    ref_grad = torch.stack([0.5 * (s[1] - s[2]) / e32, 0.5 * (s[3] - s[4]) / e32,
+                            0.5 * (s[5] - s[6]) / e32], 1)
+    assert torch.equal(grad, ref_grad)
+
+
 def test_sdf_full_size_linearity(dev):
     """BASELINE size (2^21-point export chunk): property check instead of the slow oracle.
     The network is affine in the second-layer bias: out(b1 + c) - out(b1) == c."""
