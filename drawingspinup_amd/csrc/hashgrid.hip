@@ -308,7 +308,7 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
     const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
     uint32_t active, float* __restrict__ sdf, float* __restrict__ grad,
     float* __restrict__ feature, float* __restrict__ laplace, __half2* __restrict__ enc,
-    const int32_t* __restrict__ perm, int fixup) {
+    const int32_t* __restrict__ perm) {
   using L = MlpLds<NL>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   DSU_FWD_LOAD_MLP(NL, lds, mlp);
@@ -319,8 +319,6 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
     // the caller's order; the per-point outputs go back to the caller's rows, the feature cache
     // stays in evaluation order (the backward pass walks it in the same order)
     const int64_t oi = perm ? (int64_t)perm[i] : i;
-    // fix-up mode: only the rows the level-outer kernel left as NaN
-    if (fixup && !(sdf[oi] != sdf[oi])) continue;
     const float p[3] = {pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2]};
     float s[7];
 #pragma unroll 1
@@ -400,10 +398,14 @@ __global__ __launch_bounds__(256) void sdf_fd_fwd_kernel(
 // REGULAR points only: every evaluation inside the unit cube (then the other two axes keep their
 // cell, cell coordinates stay in [0, res] and a dense index needs at most one subtraction of the
 // level size instead of tcnn's modulo) and every offset within one cell of the centre.  A point
-// that is not (outside the box, clamped, an eps of more than a cell) gets sdf = NaN and nothing
-// else here; the evaluation-by-evaluation kernel then runs in fix-up mode over the NaN rows (a
-// genuine NaN is recomputed to the same NaN).  ND: levels below ND are dense, the others hashed
-// (4 for the shipped grid; the launcher checks the level table against it).
+// that is not (outside the box, clamped, an eps of more than a cell: a few dozen of the 266 000
+// of a step, the perturbed regulariser points next to the faces) is redone by its whole wave at
+// the end of the wave's pass, evaluation by evaluation with the plain lookups (fd_point_by_wave:
+// lanes = evaluations for the encoding, = hidden units for the MLP).  Handing such points to a
+// second launch of the per-evaluation kernel cost as much as that whole kernel (0.12 ms measured:
+// one wave's latency through 7 x (gathers + 16 weight groups) is the kernel's duration).  ND:
+// levels below ND are dense, the others hashed (4 for the shipped grid; the launcher checks the
+// level table against it).
 //
 // Then the MLP with the hidden units outer and the 7 evaluations inner: one set of scalar weight
 // loads serves 7 evaluations; the interpolated features stay packed f16 in registers and enter
@@ -572,6 +574,84 @@ __device__ __forceinline__ void fd_levels(const __half2* __restrict__ table, con
 #endif
 }
 
+// One irregular point evaluated by a whole wave: same lookups (lookup_level), same FMA chains (k
+// ascending for the pre-activations, j ascending for the outputs) as the per-evaluation kernel.
+// p[] / i / oi are wave-uniform.  lds: 7 x DIN inputs + 7 x 64 hidden activations of this wave.
+template <int NL, int ACT, bool FEAT>
+__device__ __forceinline__ void fd_point_by_wave(
+    const __half2* __restrict__ table, const GridMeta& m, const dsu_sdf_mlp& mlp, const float (&p)[3],
+    int64_t i, int64_t oi, int64_t n, float radius, float eps, float eps2, float* __restrict__ sdf,
+    float* __restrict__ grad, float* __restrict__ feature, float* __restrict__ laplace,
+    __half2* __restrict__ enc, float* lds) {
+  constexpr int DIN = 3 + 2 * NL, KIN = 3 + 2 * ACT;
+  float* l_in = lds;                 // [7][KIN]
+  float* l_h = lds + 7 * KIN;        // [7][64]
+  const int lane = threadIdx.x & 63;
+  // opaque copies of the pointers: the loads below are invariant in the caller's loops and would
+  // be hoisted to the top of the kernel, where their ~30 registers are alive through everything
+  const float *w0 = mlp.w0, *b0 = mlp.b0, *w1 = mlp.w1, *b1 = mlp.b1;
+  asm volatile("" : "+v"(w0), "+v"(b0), "+v"(w1), "+v"(b1), "+v"(table));
+  if (lane < 7) {
+    const int e = lane, ax = (e - 1) >> 1;
+    const float d = ((e - 1) & 1) ? -eps : eps;
+    float x[3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      float v = p[a];
+      if (e > 0) v = fminf(fmaxf(v + (a == ax ? d : 0.0f), -radius), radius);   // geometry.py:170
+      x[a] = contract(v, radius);
+      l_in[e * KIN + a] = x[a] * 2.0f + -1.0f;
+    }
+#pragma unroll
+    for (int l = 0; l < ACT; ++l) {
+      const __half2 f = lookup_level(table, m, l, x[0], x[1], x[2]);
+      l_in[e * KIN + 3 + 2 * l] = __low2float(f);
+      l_in[e * KIN + 4 + 2 * l] = __high2float(f);
+      if (enc != nullptr) enc[((size_t)e * n + i) * ACT + l] = f;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  {
+    const int j = lane;
+#pragma unroll 1
+    for (int e = 0; e < 7; ++e) {
+      float acc = b0[j];
+#pragma unroll
+      for (int k = 0; k < KIN; ++k) acc = fmaf(w0[j * DIN + k], l_in[e * KIN + k], acc);
+      l_h[e * HID + j] = softplus100(acc);
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+  // lanes 0..12: the 13 outputs of the centre; lanes 13..18: sdf of the offset evaluations 1..6
+  float acc = 0.0f;
+  if (lane < 19 && (FEAT || lane == 0 || lane >= NOUT)) {
+    const int e = lane < NOUT ? 0 : lane - (NOUT - 1), o = lane < NOUT ? lane : 0;
+    acc = b1[o];
+#pragma unroll 4
+    for (int j = 0; j < HID; ++j) acc = fmaf(w1[o * HID + j], l_h[e * HID + j], acc);
+    if (FEAT && lane < NOUT) feature[oi * NOUT + lane] = acc;
+  }
+  float s[7];
+  s[0] = __shfl(acc, 0);
+#pragma unroll
+  for (int e = 1; e < 7; ++e) s[e] = __shfl(acc, NOUT - 1 + e);
+  if (lane == 0) {
+    sdf[oi] = s[0];
+    if (grad != nullptr) {
+      grad[oi * 3 + 0] = 0.5f * (s[1] - s[2]) / eps;
+      grad[oi * 3 + 1] = 0.5f * (s[3] - s[4]) / eps;
+      grad[oi * 3 + 2] = 0.5f * (s[5] - s[6]) / eps;
+    }
+    if (laplace != nullptr) {
+      const float t0 = s[1] + s[2] - 2.0f * s[0];
+      const float t1 = s[3] + s[4] - 2.0f * s[0];
+      const float t2 = s[5] + s[6] - 2.0f * s[0];
+      laplace[oi] = ((t0 + t1) + t2) / eps2;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // the LDS area is reused by the next point
+}
+
 // waves per SIMD the register allocation aims at: 4 (128 VGPRs) up to 4 active levels, 3 (168) beyond
 #ifndef DSU_FWD_WAVES
 #define DSU_FWD_WAVES (ACT <= 4 ? 4 : 3)
@@ -589,8 +669,12 @@ void sdf_fd_fwd_shared_kernel(
   const cfloat_t* b0 = as_const(mlp.b0);
   const cfloat_t* w1 = as_const(mlp.w1);
   const cfloat_t* b1 = as_const(mlp.b1);
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
-       i += (int64_t)gridDim.x * blockDim.x) {
+  __shared__ float fix_lds[DSU_FWD_THREADS / 64][7 * (3 + 2 * ACT) + 7 * HID];
+  // the wave iterates together: an irregular point is redone by all its lanes (fd_point_by_wave)
+  for (int64_t base = blockIdx.x * (int64_t)blockDim.x; base < n;
+       base += (int64_t)gridDim.x * blockDim.x) {
+    const bool valid = base + threadIdx.x < n;
+    const int64_t i = valid ? base + threadIdx.x : n - 1;
     const float p[3] = {pts[i * 3 + 0], pts[i * 3 + 1], pts[i * 3 + 2]};
     const int64_t oi = perm ? (int64_t)perm[i] : i;
     // contracted coordinates: q[0] the centre; evaluation e > 0 moves axis (e-1)/2 by +-eps and
@@ -620,11 +704,8 @@ void sdf_fd_fwd_shared_kernel(
     }
     __half2 f[7][ACT];
     fd_levels<ACT, ND>(table, m, q, f, bad, std::make_integer_sequence<int, ACT>{});
-    if (bad) {
-      sdf[oi] = __int_as_float(0x7FC00000);            // left to the fix-up pass
-      continue;
-    }
-    if (enc != nullptr) {
+    const bool regular = valid && !bad;      // the others compute along and store nothing
+    if (enc != nullptr && regular) {
       // interpolated f16 features kept for the backward pass, layout [eval][point][active level]
 #pragma unroll
       for (int e = 0; e < 7; ++e) {
@@ -685,21 +766,34 @@ void sdf_fd_fwd_shared_kernel(
       }
     }
     s[0] = o0[0];
-    if (FEAT) {
+    if (regular) {
+      if (FEAT) {
 #pragma unroll
-      for (int o = 0; o < NO0; ++o) feature[oi * NOUT + o] = o0[o];
+        for (int o = 0; o < NO0; ++o) feature[oi * NOUT + o] = o0[o];
+      }
+      sdf[oi] = s[0];
+      if (grad != nullptr) {
+        grad[oi * 3 + 0] = 0.5f * (s[1] - s[2]) / eps;     // geometry.py:173
+        grad[oi * 3 + 1] = 0.5f * (s[3] - s[4]) / eps;
+        grad[oi * 3 + 2] = 0.5f * (s[5] - s[6]) / eps;
+      }
+      if (laplace != nullptr) {
+        float t0 = s[1] + s[2] - 2.0f * s[0];               // geometry.py:176
+        float t1 = s[3] + s[4] - 2.0f * s[0];
+        float t2 = s[5] + s[6] - 2.0f * s[0];
+        laplace[oi] = ((t0 + t1) + t2) / eps2;
+      }
     }
-    sdf[oi] = s[0];
-    if (grad != nullptr) {
-      grad[oi * 3 + 0] = 0.5f * (s[1] - s[2]) / eps;     // geometry.py:173
-      grad[oi * 3 + 1] = 0.5f * (s[3] - s[4]) / eps;
-      grad[oi * 3 + 2] = 0.5f * (s[5] - s[6]) / eps;
-    }
-    if (laplace != nullptr) {
-      float t0 = s[1] + s[2] - 2.0f * s[0];               // geometry.py:176
-      float t1 = s[3] + s[4] - 2.0f * s[0];
-      float t2 = s[5] + s[6] - 2.0f * s[0];
-      laplace[oi] = ((t0 + t1) + t2) / eps2;
+    // the wave's irregular points, one after the other, each by all 64 lanes
+    uint64_t todo = __ballot(valid && bad);
+    while (todo) {
+      const int src = __ffsll((unsigned long long)todo) - 1;
+      todo &= todo - 1;
+      const int64_t ib = base + (threadIdx.x & ~63) + src;
+      const float pb[3] = {pts[ib * 3 + 0], pts[ib * 3 + 1], pts[ib * 3 + 2]};   // (not kept in registers)
+      const int64_t oib = perm ? (int64_t)perm[ib] : ib;
+      fd_point_by_wave<NL, ACT, FEAT>(table, m, mlp, pb, ib, oib, n, radius, eps, eps2, sdf, grad,
+                                      feature, laplace, enc, fix_lds[threadIdx.x >> 6]);
     }
   }
 }
@@ -1172,7 +1266,6 @@ int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, cons
   hipStream_t s = (hipStream_t)stream;
   const float eps2 = (float)((double)eps * (double)eps);
   const int blocks = dsu_capped_blocks(n, DSU_FWD_THREADS, 8192 * (256 / DSU_FWD_THREADS));
-  int fixup = 0;
 #if !defined(DSU_FWD_PER_EVAL) && !defined(DSU_FWD_LDS_W)
   // level-outer kernel with shared corners: one instance per number of active levels of the
   // shipped grid (10 levels; the 3000-step schedule runs 4..6 of them, geometry.py:196-215);
@@ -1185,7 +1278,7 @@ int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, cons
                      launched, std::make_integer_sequence<int, DSU_FWD_SHARED_HI - DSU_FWD_SHARED_LO + 1>{});
     if (launched) {
       DSU_CHECK_LAUNCH();
-      fixup = 1;            // the rows it left as NaN go through the kernel below
+      return DSU_OK;
     }
   }
 #endif
@@ -1194,11 +1287,11 @@ int dsu_sdf_fd_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, cons
     if (active_levels <= 6)
       sdf_fd_fwd_kernel<NL, 6><<<dim3(blocks), dim3(DSU_FWD_THREADS), shm, s>>>(
           (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, sdf, grad,
-          feature, laplace, (__half2*)enc_cache, perm, fixup);
+          feature, laplace, (__half2*)enc_cache, perm);
     else
       sdf_fd_fwd_kernel<NL, NL><<<dim3(blocks), dim3(DSU_FWD_THREADS), shm, s>>>(
           (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, sdf, grad,
-          feature, laplace, (__half2*)enc_cache, perm, fixup);
+          feature, laplace, (__half2*)enc_cache, perm);
   });
   DSU_CHECK_LAUNCH();
   return DSU_OK;

@@ -56,10 +56,27 @@ if mode == "capture":
 elif mode == "time":
     saved = torch.load(sys.argv[2])
     reps = int(sys.argv[3]) if len(sys.argv) > 3 else 50
+    g = torch.Generator().manual_seed(0)
+    tab_s = ((torch.rand(cfg.n_entries, 2, generator=g) * 2 - 1) * 0.1).half().to(dev)
+    mlp_s = [(torch.randn(64, 23, generator=g) * 0.3).to(dev), (torch.randn(64, generator=g) * 0.05).to(dev),
+             (torch.randn(13, 64, generator=g) * 0.2).to(dev), (torch.randn(13, generator=g) * 0.1).to(dev)]
     for step, d in sorted(saved.items()):
         fn = lambda: ops.sdf_fd_fwd(cfg, d["tab"], d["mlp"], d["pts"], d["radius"], d["eps"], d["active"],
                                     True, True, False, enc_cache=True, perm=d["perm"])
-        out[f"act{d['active']}_n{d['pts'].shape[0]}_us"] = timeit(fn, reps)
+        key = f"act{d['active']}_n{d['pts'].shape[0]}"
+        out[key + "_us"] = timeit(fn, reps)
+        r = fn()
+        out[key + "_nan_sdf"] = int(torch.isnan(r[0]).sum())
+        # which input makes the difference: real samples with random table / weights, and back
+        out[key + "_us_random_weights"] = timeit(lambda: ops.sdf_fd_fwd(
+            cfg, tab_s, mlp_s, d["pts"], d["radius"], d["eps"], d["active"], True, True, False,
+            enc_cache=True, perm=d["perm"]), reps)
+        out[key + "_us_random_table_only"] = timeit(lambda: ops.sdf_fd_fwd(
+            cfg, tab_s, d["mlp"], d["pts"], d["radius"], d["eps"], d["active"], True, True, False,
+            enc_cache=True, perm=d["perm"]), reps)
+        out[key + "_us_unsorted_identity"] = timeit(lambda: ops.sdf_fd_fwd(
+            cfg, d["tab"], d["mlp"], d["pts"], d["radius"], d["eps"], d["active"], True, True, False,
+            enc_cache=True, perm=None), reps)
 else:
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 50
     g = torch.Generator().manual_seed(0)
