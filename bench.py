@@ -129,9 +129,13 @@ class KernelTimer:
         rows = []
         merged = {name: [len(f["events"]), sum(s.elapsed_time(e) for s, e in f["events"]), f["work"]]
                   for name, f in self.fam.items()}
-        for name, (n, ms, work) in nsr_system.native_timing["totals"].items():
+        flops = {}
+        for name, tot in nsr_system.native_timing["totals"].items():
+            n, ms, work = tot[:3]
             t = merged.setdefault(name, [0, 0.0, 0.0])
             t[0] += n; t[1] += ms; t[2] += work
+            if len(tot) > 3:
+                flops[name] = flops.get(name, 0.0) + tot[3]
         for name, (n, ms, work) in merged.items():
             f = {"work": work}
             if not n or ms <= 0:
@@ -143,6 +147,18 @@ class KernelTimer:
                          "total_ms": ms, "avg_launch_ms": ms / n,
                          "alg_work_per_launch": f["work"] / n, "achieved": ach, "peak": peak,
                          "unit": "GB/s" if hbm else "TFLOP/s", "frac": ach / peak})
+            if name in flops and flops[name] > 0:
+                # what the geometry kernels are actually bound by: the f32 arithmetic of the 64-wide
+                # MLP (f32 MFMA / VALU FMA peak 157.3 TFLOP/s), at one wave per SIMD in the backward
+                # pair (+ 64-bit LDS atomics in its scatter half), not the table traffic
+                tf = flops[name] / (ms * 1e-3) / 1e12
+                rows[-1]["bound_actual"] = {
+                    "bound": "f32 MLP arithmetic (v_mfma_f32_32x32x2_f32 / v_fma_f32)",
+                    "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                    "frac": tf / F32_MFMA_PEAK_TF,
+                    "note": ("MLP part at one wave per SIMD (458 VGPRs) + scatter on 64-bit LDS atomics"
+                             if name == "sdf_fd_bwd" else
+                             "level-outer gathers (shared corners) + VALU MLP, 3-4 waves per SIMD")}
         rows.sort(key=lambda r: -r["total_ms"])
         return rows
 

@@ -177,6 +177,7 @@ _PROTOS = {
     "dsu_nsr_driver_timing": [c_vp, c_i32],
     "dsu_nsr_driver_timing_read": [c_vp, c_i32, C.POINTER(c_i64), C.POINTER(C.c_double),
                                    C.POINTER(C.c_double)],
+    "dsu_nsr_driver_timing_flops": [c_vp, c_i32, C.POINTER(C.c_double)],
     "dsu_spatial_sort": [P, c_i64, c_f32, c_i32, P, P, P, c_i64, P],
     "dsu_spatial_sort_workspace_bytes": [c_i64, c_i32],
     "dsu_ray_aabb": [P, P, c_i64, P, P, c_f32, P, P, P],

@@ -379,6 +379,7 @@ struct dsu_nsr_driver {
   bool timing = false;
   std::vector<hipEvent_t> ev[2];              // family 0: geometry forward, 1: geometry backward
   double work[2] = {0.0, 0.0};                // algorithmic bytes of the timed launches
+  double flops[2] = {0.0, 0.0};               // their algorithmic MLP flops (what actually bounds them)
 };
 
 #define DSU_TRY(expr)            \
@@ -703,11 +704,16 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
   dsu_sdf_mlp mlp{L.w0_eff, c.b0, L.w1_eff, c.b1};
   // ---- forward
   const double alg_bytes = (double)n_all * (7.0 * a->active_levels * 8 * 4 + 12 + 72);
+  // geometry MLP per point: 7 evaluations of 64 x (3 + 2 L) MACs, 13 outputs for the centre and 1
+  // for each offset; the backward pass does the layer-0 product three times (recompute, dIn, gW0)
+  // and the layer-1 product three times (recompute, dH, gW1)
+  const double l0 = 7.0 * 64 * (3 + 2 * a->active_levels), l1 = 64.0 * (13 + 6);
+  const double fwd_flops = (double)n_all * 2.0 * (l0 + l1), bwd_flops = (double)n_all * 2.0 * 3.0 * (l0 + l1);
   DSU_TRY(mark(d, 0, s));
   DSU_TRY(dsu_sdf_fd_fwd_sorted(&c.grid, a->table_img, &mlp, pts, perm, n_all, c.radius, a->eps,
                                 a->active_levels, L.a_sdf, L.a_grad, L.a_feat, nullptr, L.enc_cache, s));
   DSU_TRY(mark(d, 0, s));
-  if (d->timing) d->work[0] += alg_bytes;
+  if (d->timing) { d->work[0] += alg_bytes; d->flops[0] += fwd_flops; }
   if (a->prefetch_next && d->pack_gate == 1) {
     // The packing / sorting launches of the next set (a dozen short, chip-wide kernels) slowed the
     // gather-bound geometry forward by a quarter when they ran beside it (kernel trace: 221 vs
@@ -772,7 +778,7 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
                                      gg + 64 * 23 + 64 + 13 * 64, L.sdf_ws, L.sdf_ws_bytes,
                                      L.enc_cache, d->gate, have_tex_red ? &tex_red : nullptr, s));
   DSU_TRY(mark(d, 1, s));
-  if (d->timing) d->work[1] += alg_bytes;
+  if (d->timing) { d->work[1] += alg_bytes; d->flops[1] += bwd_flops; }
   if (a->prefetch_next && d->pack_gate == 2) {
     const int q = (int)((a->step + 1) % 3);
     dsu_nsr_step_args na = *a;
@@ -816,6 +822,7 @@ int dsu_nsr_driver_timing(dsu_nsr_driver* d, int32_t enable) {
     for (hipEvent_t e : d->ev[f]) (void)hipEventDestroy(e);
     d->ev[f].clear();
     d->work[f] = 0.0;
+    d->flops[f] = 0.0;
   }
   d->timing = enable != 0;
   return DSU_OK;
@@ -836,6 +843,12 @@ int dsu_nsr_driver_timing_read(dsu_nsr_driver* d, int32_t family, int64_t* launc
   *launches = (int64_t)pairs;
   *total_ms = ms;
   *alg_bytes = d->work[family];
+  return DSU_OK;
+}
+
+int dsu_nsr_driver_timing_flops(dsu_nsr_driver* d, int32_t family, double* mlp_flops) {
+  if (!d || family < 0 || family > 1 || !mlp_flops) return DSU_EINVAL;
+  *mlp_flops = d->flops[family];
   return DSU_OK;
 }
 

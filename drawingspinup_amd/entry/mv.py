@@ -38,6 +38,13 @@ def main(argv=None):
                          "outputs are noise)")
     ap.add_argument("--seed", type=int, default=None)
     ap.add_argument("--num_inference_steps", type=int, default=None)
+    ap.add_argument("--matting", default="silhouette", choices=["silhouette", "isnet"],
+                    help="side-view masks (mv.py:113-122): 'isnet' = remove_background through the "
+                         "IS-Net session of mv/matting.py (needs --isnet_weights to mean anything), "
+                         "'silhouette' = the filled not-white silhouette stand-in")
+    ap.add_argument("--isnet_weights", default=None,
+                    help="DIS IS-Net state_dict (isnet-general-use.pth); mv.py:17 loads "
+                         "dis_pretrained/isnet_dis.onnx, the same network exported to ONNX")
     args = ap.parse_args(argv)
     from . import config as C
     conf = C.load_config(args.config)
@@ -73,6 +80,15 @@ def main(argv=None):
             pipe.image_encoder = ck.load_image_encoder(args.image_encoder, dev)
     for m in (pipe.unet, pipe.vae, pipe.image_encoder):
         ddist.broadcast_module(m, 0)
+    matting_fn = None
+    if args.matting == "isnet":                             # mv.py:17-18: the session is made once
+        if args.isnet_weights is None and not args.random_init:
+            raise SystemExit("mv: --matting isnet needs --isnet_weights FILE (--random_init runs on "
+                             "random weights and produces noise)")
+        from ..mv import matting
+        net = matting.load_isnet(args.isnet_weights, dev)
+        ddist.broadcast_module(net, 0)
+        matting_fn = matting.matting_fn(matting.IsnetSession(net, dev))
     uids = json.load(open(args.uid_list_file)) if args.all else [args.uid]
     for uid in ddist.shard(uids, rank, world):
         img_fn = os.path.join(args.data_root, uid, args.img_fn)
@@ -89,7 +105,7 @@ def main(argv=None):
         out = pipe(imgs.to(dev, torch.float16), cam.to(dev, torch.float16), generator=g, output_type="pt",
                    num_images_per_prompt=1, **kw)
         D.write_mv_outputs(os.path.join(args.data_root, uid, args.save_folder), out[:6], out[6:], single,
-                           res=tuple(conf["resolution"]), uid=uid)
+                           res=tuple(conf["resolution"]), uid=uid, matting_fn=matting_fn)
         print(uid, flush=True)
 
 

@@ -448,8 +448,11 @@ class NativeStepDriver:
             n, ms, work = C.c_int64(), C.c_double(), C.c_double()
             ops.check(self._lib.lib().dsu_nsr_driver_timing_read(
                 self.handle, fam, C.byref(n), C.byref(ms), C.byref(work)), "dsu_nsr_driver_timing_read")
-            t = native_timing["totals"].setdefault(name, [0, 0.0, 0.0])
-            t[0] += n.value; t[1] += ms.value; t[2] += work.value
+            fl = C.c_double()
+            ops.check(self._lib.lib().dsu_nsr_driver_timing_flops(self.handle, fam, C.byref(fl)),
+                      "dsu_nsr_driver_timing_flops")
+            t = native_timing["totals"].setdefault(name, [0, 0.0, 0.0, 0.0])
+            t[0] += n.value; t[1] += ms.value; t[2] += work.value; t[3] += fl.value
         ops.check(self._lib.lib().dsu_nsr_driver_timing(self.handle, 1), "dsu_nsr_driver_timing")
 
     @property

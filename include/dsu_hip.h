@@ -850,6 +850,10 @@ const float* dsu_nsr_driver_terms(const dsu_nsr_driver* d);
 int dsu_nsr_driver_timing(dsu_nsr_driver* d, int32_t enable);
 int dsu_nsr_driver_timing_read(dsu_nsr_driver* d, int32_t family, int64_t* launches,
                                double* total_ms, double* alg_bytes);
+/* Algorithmic MLP flops of the same launches (points x 2 x (7 x 64 x (3 + 2 active_levels) + 64 x 19),
+ * three times that for the backward family): these kernels are bound by the f32 arithmetic of
+ * VanillaMLP (network_utils.py:107-138), not by the table traffic the contract prices them on. */
+int dsu_nsr_driver_timing_flops(dsu_nsr_driver* d, int32_t family, double* mlp_flops);
 /* dsu_occgrid_refresh with the driver's own effective weights, inv_s, grid, radius, step size, aabb
  * and seed filled in (args->grid / mlp / inv_s / aabb / seed / radius / render_step_size are
  * ignored): the refresh of every 16th step without leaving the native path. */

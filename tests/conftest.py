@@ -34,7 +34,7 @@ def pytest_collection_modifyitems(config, items):
 _PARITY_ORDER = [
     "test_gpu_hashgrid.py", "test_gpu_nsr_reference_step.py", "test_gpu_render.py",
     "test_gpu_nsr_step.py", "test_gpu_nsr_model.py", "test_gpu_mesh.py", "test_gpu_unet.py",
-    "test_gpu_attention.py", "test_gpu_conv_f16.py", "test_gpu_style.py", "test_gpu_shims.py",
+    "test_gpu_attention.py", "test_gpu_conv_f16.py", "test_gpu_style.py", "test_gpu_shims.py", "test_gpu_matting.py",
     "test_gpu_thinning.py", "test_gpu_mesh_post.py", "test_gpu_decimate.py",
     "test_gpu_style_train.py", "test_contour_host.py", "test_contour_inpaint.py",
 ]

@@ -1,0 +1,43 @@
+"""IS-Net forward of the side-view matting seam on the library's convolution kernel (mv/matting.py)
+against the same module evaluated by torch on the CPU, and the session contract on the device."""
+import numpy as np
+import pytest
+import torch
+
+from drawingspinup_amd.mv import matting
+
+pytestmark = pytest.mark.gpu
+
+
+def _randomise_bn(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+
+
+def test_isnet_forward_on_the_hip_convolution_matches_torch_cpu(dev):
+    net = matting.load_isnet(None, "cpu", seed=3)
+    _randomise_bn(net, 4)
+    x = torch.rand(1, 3, 208, 176, generator=torch.Generator().manual_seed(5)) - 0.5   # odd pooled sizes below
+    with torch.no_grad():
+        ref = net(x)
+        got = net.to(dev)(x.to(dev)).cpu()
+    assert got.shape == ref.shape == (1, 1, 208, 176)
+    assert float(ref.std()) > 1e-4                                   # not a constant map
+    torch.testing.assert_close(got, ref, rtol=0, atol=2e-4)
+
+
+def test_remove_background_through_the_device_session(dev):
+    net = matting.load_isnet(None, dev, seed=6)
+    sess = matting.IsnetSession(net, dev)
+    rng = np.random.default_rng(7)
+    from PIL import Image
+    img = Image.fromarray(rng.integers(0, 256, (256, 256, 3), dtype=np.uint8), "RGB")
+    m = matting.remove_background(sess, img)
+    assert m.mode == "L" and m.size == (256, 256)
+    again = matting.remove_background(sess, img)
+    assert np.array_equal(np.array(m), np.array(again))

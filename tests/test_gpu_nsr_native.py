@@ -147,6 +147,10 @@ def test_native_step_timing_counters(dev):
     assert t["sdf_fd_bwd"][0] == 5 and t["sdf_fd_fwd"][0] == 5
     assert 0.05 < t["sdf_fd_bwd"][1] / 5 < 5.0                 # ms per launch
     assert t["sdf_fd_bwd"][2] > 5 * 50000 * (7 * 4 * 32 + 84) * 0.5      # algorithmic bytes
+    # algorithmic MLP flops: backward = 3 x forward, forward = points x 2 x (7 x 64 x 11 + 64 x 19) at 4 levels
+    assert abs(t["sdf_fd_bwd"][3] / t["sdf_fd_fwd"][3] - 3.0) < 1e-9
+    pts = t["sdf_fd_fwd"][2] / (7 * 4 * 32 + 84)
+    assert abs(t["sdf_fd_fwd"][3] / (pts * 2 * (7 * 64 * 11 + 64 * 19)) - 1.0) < 1e-6
     S.native_timing["totals"].clear()
 
 
