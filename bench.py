@@ -69,9 +69,16 @@ class KernelTimer:
     families are timed there, with HIP events on the stream the kernels run on
     (dsu_nsr_driver_timing); the families launched from Python are wrapped here."""
 
-    def __init__(self):
+    # Every event pair costs main-queue time (measured: the four records of an NSR step 28 us of its
+    # 1.05 ms; ~40 000 pairs around the convolutions / attentions of one drawing's diffusion), so the
+    # families are SAMPLED: every STRIDE-th call (step) is timed, the averages are over those.
+    STRIDE = 7
+
+    def __init__(self, stride=None):
         self._enabled = False
         self.fam = {}
+        self.stride = int(stride or self.STRIDE)
+        self._calls = {}
 
     @property
     def enabled(self):
@@ -82,6 +89,7 @@ class KernelTimer:
         from drawingspinup_amd.nsr import system as nsr_system
         self._enabled = bool(on)
         nsr_system.native_timing["enabled"] = bool(on)
+        nsr_system.native_timing["stride"] = self.stride
 
     def _wrap(self, module, name, family, work):
         orig = getattr(module, name)
@@ -89,6 +97,9 @@ class KernelTimer:
 
         def timed(*a, **k):
             if not timer.enabled:
+                return orig(*a, **k)
+            c = timer._calls[family] = timer._calls.get(family, 0) + 1
+            if c % timer.stride:
                 return orig(*a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -285,13 +296,16 @@ _PMC_CACHE = []
 
 
 def _pmc():
-    """profiles/round4_pmc.json (tools/pmc_round4.sh) or None."""
+    """profiles/round5_pmc.json (tools/pmc_round5.sh; round 4's file when it is absent) or None."""
     if not _PMC_CACHE:
-        path = os.path.join(ROOT, "profiles", "round4_pmc.json")
-        try:
-            with open(path) as f:
-                _PMC_CACHE.append(json.load(f))
-        except (OSError, ValueError):
+        for name in ("round5_pmc.json", "round4_pmc.json"):
+            try:
+                with open(os.path.join(ROOT, "profiles", name)) as f:
+                    _PMC_CACHE.append(dict(json.load(f), source="profiles/" + name))
+                break
+            except (OSError, ValueError):
+                continue
+        else:
             _PMC_CACHE.append(None)
     return _PMC_CACHE[0]
 
@@ -317,9 +331,11 @@ def _roofline(timer, extra=None):
         return None
     top = dict(rows[0])
     top["kernels"] = rows[:3]
+    # `launches` / `total_ms` count the TIMED launches: every stride-th call of a family
+    top["timed_launch_stride"] = timer.stride
     # HBM-side bytes per launch of the dominant family: not collectable inside this process (PMC
     # counters need their own rocprofv3 --pmc passes, FETCH_SIZE and WRITE_SIZE one pass each, as
-    # MI355X_MICROARCH.md prescribes).  profiles/round4_pmc.json holds this round's passes over
+    # MI355X_MICROARCH.md prescribes).  profiles/round5_pmc.json holds this round's passes over
     # tools/pmc_sdf_kernels.py (N = 262 144 Morton-ordered samples, 5 levels): per kernel
     # (2 x FETCH_SIZE + WRITE_SIZE) — the guide's gfx950 correction for coalesced reads — and the
     # workload's algorithmic bytes; the measured ratio is applied to this run's mean algorithmic
@@ -333,7 +349,7 @@ def _roofline(timer, extra=None):
                    if any(k.startswith(f) for f in fam[top["kernel"]]))
         if side > 0:
             top["traffic"] = side / pmc["sdf_algorithmic_bytes"] * top["alg_work_per_launch"]
-            top["traffic_source"] = "profiles/round4_pmc.json"
+            top["traffic_source"] = pmc["source"]
     if extra:
         top.update(extra)
     return top
@@ -432,7 +448,7 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
     for st in stages.values():
         st["frac"] = st["achieved"] / st["peak"]
     # matrix-pipe busy share of the wave cycles and the parked / issue-stalled shares of the stage's
-    # MFMA kernels, from this round's SQ pass (profiles/round4_pmc.json; one UNet forward / one frame)
+    # MFMA kernels, from the SQ pass (profiles/round{5,4}_pmc.json; one UNet forward / one frame)
     for name, pre in (("mv", ("conv_f16_kernel", "mv_attention_kernel")), ("style", ("conv_x3_kernel",))):
         for field in ("mfma_busy_of_wave_cycles", "parked_frac", "issue_stall_frac"):
             v = _sq_share(pre, field)
@@ -441,8 +457,8 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
     roof = _roofline(timer, {"stages": stages,
                              "traffic_note": "HBM-side bytes per launch of the dominant family "
                                              "(MLP part + scatter): (2 x FETCH_SIZE + "
-                                             "WRITE_SIZE) of this round's separate rocprofv3 --pmc passes "
-                                             "(profiles/round4_pmc.json, tools/pmc_round4.sh) relative to "
+                                             "WRITE_SIZE) of separate rocprofv3 --pmc passes "
+                                             "(roofline.traffic_source, tools/pmc_round5.sh) relative to "
                                              "that workload's algorithmic bytes, applied to this run's "
                                              "mean algorithmic bytes per launch"})
     out = {

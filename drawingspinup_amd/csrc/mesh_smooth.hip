@@ -14,7 +14,12 @@
 //                                                    (smooth_update_kernel)
 // and every tenth iteration the energy x . Q x / 2 as per-workgroup partial sums in a fixed order
 // (smooth_energy_kernel; the host adds the partials: the stopping test is deterministic).
-// HBM traffic per iteration ~ nv * (7 + 3 + 9 + 2) * 8 B + 2 * 6 * 4 B of slots; the band of a
+// The iteration itself runs as ONE kernel per step (smooth_fused_kernel): the three rows a voxel
+// needs per axis — its own and its two neighbours' — are recomputed from x with the very
+// expressions of smooth_rows_kernel (same operands, same order: bit-identical values), so y is
+// neither written nor read; x ping-pongs between the caller's x and the first nv doubles of y.
+// Unique memory per iteration: slots 24 nv + x 8 nv in + 8 nv out + bounds 16 nv = 56 nv bytes
+// against ~ (2 x 24 + 24 + 24 + 72 + 16 + 16) nv = 200 nv of the two-pass form; the band of a
 // 512^3 export is 2-5 M voxels, i.e. it lives in the Infinity Cache across iterations.
 #include "common.h"
 
@@ -74,6 +79,44 @@ __global__ __launch_bounds__(256) void smooth_update_kernel(const int32_t* __res
   }
 }
 
+// y_a(j) = cd_a(j) x(j) + x(n-_a(j)) + x(n+_a(j)): smooth_rows_kernel's expression for voxel j
+__device__ __forceinline__ double row_of(const int32_t* __restrict__ nbr, int64_t nv,
+                                         const double* __restrict__ x, int a, int64_t j) {
+  const int m = nbr[(size_t)(2 * a) * nv + j], p = nbr[(size_t)(2 * a + 1) * nv + j];
+  const double cd = -2.0 + (m < 0 ? 1.0 : 0.0) + (p < 0 ? 1.0 : 0.0);
+  return cd * x[j] + at_or_zero(x, m) + at_or_zero(x, p);
+}
+
+// one whole iteration: xo = clamp(w * (-(Q x - d x) / d) + (1 - w) x), Q x from rows recomputed
+// on the fly (q_and_diag's sum, with y_a(.) = row_of(.))
+__global__ __launch_bounds__(256) void smooth_fused_kernel(const int32_t* __restrict__ nbr, int64_t nv,
+                                                           const double* __restrict__ x,
+                                                           const double* __restrict__ lower,
+                                                           const double* __restrict__ upper,
+                                                           double weight, double* __restrict__ xo) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nv;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const double xi = x[i];
+    double q = 0.0, d = 0.0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const int m = nbr[(size_t)(2 * a) * nv + i], p = nbr[(size_t)(2 * a + 1) * nv + i];
+      const double hm = m < 0 ? 0.0 : 1.0, hp = p < 0 ? 0.0 : 1.0;
+      const double cd = -2.0 + (1.0 - hm) + (1.0 - hp);
+      const double cd_rows = -2.0 + (m < 0 ? 1.0 : 0.0) + (p < 0 ? 1.0 : 0.0);
+      const double ya_i = cd_rows * xi + at_or_zero(x, m) + at_or_zero(x, p);
+      const double ya_m = m >= 0 ? row_of(nbr, nv, x, a, m) : 0.0;
+      const double ya_p = p >= 0 ? row_of(nbr, nv, x, a, p) : 0.0;
+      q += cd * ya_i + ya_m + ya_p;
+      d += cd * cd + hm + hp;
+    }
+    const double x1 = -(1.0 / d) * (q - d * xi);                 // -D^-1 R x
+    double xn = weight * x1 + (1.0 - weight) * xi;
+    xn = fmin(fmax(xn, lower[i]), upper[i]);
+    xo[i] = xn;
+  }
+}
+
 constexpr int EN_BLOCKS = 1024;
 
 __global__ __launch_bounds__(256) void smooth_energy_kernel(const int32_t* __restrict__ nbr,
@@ -108,11 +151,24 @@ int dsu_smooth_iterate(const int32_t* nbr, int64_t nv, const double* lower, cons
   if (nv == 0 || iters == 0) return DSU_OK;
   hipStream_t s = (hipStream_t)stream;
   const int blocks = dsu_capped_blocks(nv, 256, 8192);
+  if (dsu_ab_is("DSU_SMOOTH", "two_pass")) {      // the form of rounds 2-4 (variant builds, A/B)
+    for (int it = 0; it < iters; ++it) {
+      smooth_rows_kernel<<<dim3(blocks), dim3(256), 0, s>>>(nbr, nv, x, y);
+      smooth_update_kernel<<<dim3(blocks), dim3(256), 0, s>>>(nbr, nv, y, lower, upper, weight, x);
+    }
+    DSU_CHECK_LAUNCH();
+    return DSU_OK;
+  }
+  double* cur = x;
+  double* nxt = y;                                  // first nv doubles of the scratch
   for (int it = 0; it < iters; ++it) {
-    smooth_rows_kernel<<<dim3(blocks), dim3(256), 0, s>>>(nbr, nv, x, y);
-    smooth_update_kernel<<<dim3(blocks), dim3(256), 0, s>>>(nbr, nv, y, lower, upper, weight, x);
+    smooth_fused_kernel<<<dim3(blocks), dim3(256), 0, s>>>(nbr, nv, cur, lower, upper, weight, nxt);
+    double* t = cur; cur = nxt; nxt = t;
   }
   DSU_CHECK_LAUNCH();
+  if (cur != x &&
+      hipMemcpyAsync(x, cur, (size_t)nv * sizeof(double), hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return DSU_ELAUNCH;
   return DSU_OK;
 }
 

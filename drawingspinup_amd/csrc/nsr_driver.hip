@@ -376,7 +376,9 @@ struct dsu_nsr_driver {
   float aabb[6];
   int32_t rowcap;
   // optional HIP-event timing of the two geometry families (bench.py's roofline object)
-  bool timing = false;
+  bool timing = false;                        // this step's launches are timed
+  int32_t timing_stride = 0;                  // 0: off; n: every n-th step (an event pair costs ~7 us
+                                              // of main-queue time: 28 us per step when all are timed)
   std::vector<hipEvent_t> ev[2];              // family 0: geometry forward, 1: geometry backward
   double work[2] = {0.0, 0.0};                // algorithmic bytes of the timed launches
   double flops[2] = {0.0, 0.0};               // their algorithmic MLP flops (what actually bounds them)
@@ -610,6 +612,7 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
   const dsu_nsr_driver_cfg& c = d->cfg;
   Layout& L = d->L;
   hipStream_t s = (hipStream_t)main_stream;
+  d->timing = d->timing_stride > 0 && a->step % d->timing_stride == 0;
   const int p = (int)(a->step % 3);
   Prefetch& f = L.pf[p];
   float* terms = L.terms + 8 * (int)(a->step & 1);   // two sets: the optimizer kernel pre-zeroes the next one
@@ -824,7 +827,8 @@ int dsu_nsr_driver_timing(dsu_nsr_driver* d, int32_t enable) {
     d->work[f] = 0.0;
     d->flops[f] = 0.0;
   }
-  d->timing = enable != 0;
+  d->timing_stride = enable > 0 ? enable : 0;
+  d->timing = false;
   return DSU_OK;
 }
 

@@ -352,7 +352,9 @@ class SmallAdamW:
 
 # HIP-event timing of the native driver's geometry launches (bench.py's roofline object): bench.py
 # flips "enabled"; finished drivers add their (launches, ms, algorithmic bytes) to "totals".
-native_timing = {"enabled": False, "totals": {}}
+# "stride": every n-th step is timed (1 = all; bench.py uses 7: the event records of a timed step
+# cost ~28 us of its ~1.05 ms).
+native_timing = {"enabled": False, "totals": {}, "stride": 1}
 
 
 class NativeStepDriver:
@@ -432,11 +434,12 @@ class NativeStepDriver:
             m.occupancy_grid.native_refresh = self.occ_refresh
 
     def set_timing(self, on):
+        """on: 0 / False = off, n = time every n-th step."""
+        on = int(on)
         if on != self.timing_on:
             if self.timing_on:
                 self.flush_timing()
-            ops.check(self._lib.lib().dsu_nsr_driver_timing(self.handle, int(on)),
-                      "dsu_nsr_driver_timing")
+            ops.check(self._lib.lib().dsu_nsr_driver_timing(self.handle, on), "dsu_nsr_driver_timing")
             self.timing_on = on
 
     def flush_timing(self):
@@ -453,7 +456,8 @@ class NativeStepDriver:
                       "dsu_nsr_driver_timing_flops")
             t = native_timing["totals"].setdefault(name, [0, 0.0, 0.0, 0.0])
             t[0] += n.value; t[1] += ms.value; t[2] += work.value; t[3] += fl.value
-        ops.check(self._lib.lib().dsu_nsr_driver_timing(self.handle, 1), "dsu_nsr_driver_timing")
+        ops.check(self._lib.lib().dsu_nsr_driver_timing(self.handle, int(self.timing_on)),
+                  "dsu_nsr_driver_timing")
 
     @property
     def system(self):
@@ -724,7 +728,7 @@ class OrthoNeuSSystem:
             if drv is not None:
                 drv.close()
             drv = self._native = NativeStepDriver(self)
-        drv.set_timing(bool(native_timing["enabled"]))
+        drv.set_timing(int(native_timing.get("stride", 1)) if native_timing["enabled"] else 0)
         a = drv.args
         inject = inject or {}
         if "batch" in inject:

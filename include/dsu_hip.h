@@ -844,9 +844,10 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* args, void* main_s
  * multiplied by its lambda).  A set is reused (zeroed) at the end of the following step. */
 const float* dsu_nsr_driver_terms(const dsu_nsr_driver* d);
 /* HIP-event timing of the two geometry launches of a step (family 0: dsu_sdf_fd_fwd_sorted,
- * 1: dsu_sdf_fd_bwd_sorted) on the stream they run on: enable (resets) / disable, then read the
- * number of timed launches, their summed duration and their algorithmic bytes
- * (points x (7 x active_levels x 8 x 4 + 84)). */
+ * 1: dsu_sdf_fd_bwd_sorted) on the stream they run on: enable = n > 0 times the steps whose index
+ * is a multiple of n (resets; 1 = every step — the four event records cost ~28 us of main-queue time
+ * per step), 0 disables; then read the number of timed launches, their summed duration and their
+ * algorithmic bytes (points x (7 x active_levels x 8 x 4 + 84)). */
 int dsu_nsr_driver_timing(dsu_nsr_driver* d, int32_t enable);
 int dsu_nsr_driver_timing_read(dsu_nsr_driver* d, int32_t family, int64_t* launches,
                                double* total_ms, double* alg_bytes);

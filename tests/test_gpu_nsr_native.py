@@ -135,7 +135,7 @@ def test_native_step_timing_counters(dev):
     from drawingspinup_amd.nsr import system as S
     sysm, _ = _system(dev, 9, "native")
     S.native_timing["totals"].clear()
-    S.native_timing["enabled"] = True
+    S.native_timing["enabled"], S.native_timing["stride"] = True, 1
     try:
         for _ in range(5):
             sysm.training_step()
@@ -144,13 +144,25 @@ def test_native_step_timing_counters(dev):
         S.native_timing["enabled"] = False
     t = S.native_timing["totals"]
     print("native timing totals", t)
-    assert t["sdf_fd_bwd"][0] == 5 and t["sdf_fd_fwd"][0] == 5
+    assert t["sdf_fd_bwd"][0] == 5 and t["sdf_fd_fwd"][0] == 5      # stride 1: every step
     assert 0.05 < t["sdf_fd_bwd"][1] / 5 < 5.0                 # ms per launch
     assert t["sdf_fd_bwd"][2] > 5 * 50000 * (7 * 4 * 32 + 84) * 0.5      # algorithmic bytes
     # algorithmic MLP flops: backward = 3 x forward, forward = points x 2 x (7 x 64 x 11 + 64 x 19) at 4 levels
     assert abs(t["sdf_fd_bwd"][3] / t["sdf_fd_fwd"][3] - 3.0) < 1e-9
     pts = t["sdf_fd_fwd"][2] / (7 * 4 * 32 + 84)
     assert abs(t["sdf_fd_fwd"][3] / (pts * 2 * (7 * 64 * 11 + 64 * 19)) - 1.0) < 1e-6
+    S.native_timing["totals"].clear()
+    # sampled timing (what bench.py uses): only the steps whose index is a multiple of the stride
+    S.native_timing["enabled"], S.native_timing["stride"] = True, 3
+    try:
+        first = int(sysm.global_step)
+        for _ in range(7):
+            sysm.training_step()
+        sysm._native.flush_timing()
+    finally:
+        S.native_timing["enabled"], S.native_timing["stride"] = False, 1
+    want = sum(1 for k in range(first, first + 7) if k % 3 == 0)
+    assert S.native_timing["totals"]["sdf_fd_fwd"][0] == want
     S.native_timing["totals"].clear()
 
 

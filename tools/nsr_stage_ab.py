@@ -6,13 +6,13 @@ import bench
 from drawingspinup_amd.drawing import DrawingPipeline, synthetic_drawing
 dev = torch.device("cuda:0")
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 1500
-timer = bench.KernelTimer(); timer.install()
+timer = bench.KernelTimer(int(os.environ.get('NSR_AB_STRIDE', '7'))); timer.install()
 pipe = DrawingPipeline(dev, seed=0, mv_steps=3, nsr_steps=steps, n_frames=1, with_contour=False)
 pipe.time_substages = True
 drawing = synthetic_drawing(0, device=dev)
 normals, colors = pipe.multiview(drawing, 123456)
 torch.cuda.synchronize()
-timer.enabled = True
+timer.enabled = os.environ.get("NSR_AB_TIMING", "1") != "0"     # 0: no HIP-event marks around the geometry families
 t = time.time()
 pipe.reconstruct(normals, colors, drawing, 123456)
 torch.cuda.synchronize()
