@@ -384,7 +384,7 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
                                n_frames=args.frames)
     bcast_bytes = sum(ddist.broadcast_module(m, 0) for m in pipe.shared_modules())
     stage_t = {"contour": 0.0, "mv": 0.0, "nsr": 0.0, "style": 0.0, "gather": 0.0}
-    sub_t = {"nsr_fit": 0.0, "nsr_export": 0.0, "nsr_post": 0.0}
+    sub_t = {"nsr_matting": 0.0, "nsr_fit": 0.0, "nsr_export": 0.0, "nsr_post": 0.0}
     pipe.time_substages = True               # one extra synchronize between fit and export
 
     # inputs are generated before the clock starts and wait in HBM (the reference reads them
@@ -470,7 +470,9 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
                  "exact-f32 stage time in config.stage_seconds_rank0.style_exact_f32) / f32 (contour)",
         "data": "synthetic",
         "config": {"workload": "one drawing per GPU: contour removal (FFC-ResNet generator, masks, host "
-                               "TELEA inpainting, 512^2) -> 6-view diffusion (%d DDIM steps, B=12) -> NSR "
+                               "TELEA inpainting, 512^2) -> 6-view diffusion (%d DDIM steps, B=12) -> "
+                               "IS-Net matting forward on the four 1024^2 side views (mv.py:113-150; random "
+                               "weights: the filled-silhouette stand-in supplies the masks) -> NSR "
                                "recon (%d steps, 2x512^3 export: smoothing, marching cubes, quadric remeshing "
                                "to 50 000 faces, then save_mesh's Laplacian smoothing + colour "
                                "back-projection + shear: the reference YAML's export switches for a uid "

@@ -74,7 +74,8 @@ class DrawingPipeline:
     """Holds the shared read-only weights (diffusion UNet/VAE/CLIP) and runs drawings."""
 
     def __init__(self, device="cuda", seed=0, mv_steps=75, nsr_steps=3000, n_frames=24,
-                 with_clip=True, export_resolution=512, with_mv=True, with_contour=True, mesh_post=True):
+                 with_clip=True, export_resolution=512, with_mv=True, with_contour=True, mesh_post=True,
+                 with_matting=None, isnet_weights=None):
         self.device = torch.device(device)
         self.mv_steps, self.nsr_steps, self.n_frames = mv_steps, nsr_steps, n_frames
         self.style_batch = 4                 # frames per generator call
@@ -86,6 +87,14 @@ class DrawingPipeline:
         torch.manual_seed(seed + 1)
         self.gen1 = build_model("GeneratorJ_RIC", STYLE_ARGS, self.device).eval()
         self.gen2 = build_model("GeneratorJ", STYLE_ARGS, self.device).eval()
+        # side-view matting (mv.py:113-150): the IS-Net forward on the four predicted side views.
+        # With a DIS checkpoint its mattes are the side masks; with random weights the network RUNS
+        # (its cost belongs to a drawing) and the filled-silhouette stand-in supplies the masks.
+        self.isnet, self.isnet_trained = None, isnet_weights is not None
+        if with_mv if with_matting is None else with_matting:
+            from .mv import matting
+            self.isnet = matting.load_isnet(isnet_weights, self.device, seed=seed + 3)
+        self.last_side_mattes = None
         self.contour = None
         if with_contour:
             from .contour.predict import load_generator
@@ -115,6 +124,8 @@ class DrawingPipeline:
                 mods.append(self.mv.image_encoder)
         if self.contour is not None:
             mods.append(self.contour)
+        if self.isnet is not None:
+            mods.append(self.isnet)
         return mods
 
     # ---------------------------------------------------------------- stage 1: predict.py
@@ -170,8 +181,28 @@ class DrawingPipeline:
         # front: the drawing's alpha, back: mirrored (mv.py:113-116); side views: matte of the
         # predicted colour image (distance to the white background, entry/data.py
         # side_mask_from_prediction — the reference runs a CPU ONNX matting model there)
-        side = (1.0 - col).amax(-1) > 12.0 / 255.0
-        side = torch.stack([fill_holes(m) for m in side])                  # a filled silhouette, as a matte is
+        mattes = None
+        if self.time_substages:
+            torch.cuda.synchronize(dev)
+        t_m = time.time()
+        if self.isnet is not None:
+            # remove_background (mv.py:134-150) on the 8-bit side-view images, in memory: (x / 255 -
+            # 0.5) / 1.0 in CHW, the network, clip to [0, 1], * 255 -> uint8.  The four views go
+            # through as one batch (the reference calls the session once per view; the network is
+            # per-image in eval mode, and the convolutions fill the chip better at B = 4)
+            with torch.no_grad():
+                u8 = (col[[1, 2, 4, 5]].permute(0, 3, 1, 2) * 255).to(torch.uint8)
+                mattes = (self.isnet(u8.float() / 255.0 - 0.5).clamp(0, 1) * 255).to(torch.uint8)[:, 0]
+            self.last_side_mattes = mattes
+        if self.time_substages:
+            torch.cuda.synchronize(dev)
+            self.substage_seconds["nsr_matting"] = time.time() - t_m
+        if mattes is not None and self.isnet_trained:
+            side = torch.zeros(col.shape[:3], dtype=torch.bool, device=dev)
+            side[[1, 2, 4, 5]] = mattes > 127                              # load_mask's threshold (ortho.py)
+        else:
+            side = (1.0 - col).amax(-1) > 12.0 / 255.0
+            side = torch.stack([fill_holes(m) for m in side])              # a filled silhouette, as a matte is
         masks = torch.stack([alpha > 0.5, side[1], side[2], alpha.flip(1) > 0.5, side[4], side[5]])
         nrm = nrm * masks[..., None]
         front = torch.from_numpy(inv_rt(rt_opengl2opencv(ideal_w2c("front")))[:3, :3]).float().to(dev)
@@ -214,7 +245,8 @@ class DrawingPipeline:
             self.last_mesh_post = {"verts": v, "faces": f, "colors": c}
         if self.time_substages:
             torch.cuda.synchronize(dev)
-            self.substage_seconds = {"nsr_fit": t1 - t0, "nsr_export": t2 - t1, "nsr_post": time.time() - t2}
+            self.substage_seconds.update({"nsr_fit": t1 - t0, "nsr_export": t2 - t1,
+                                          "nsr_post": time.time() - t2})
         return system, mesh["binary"]
 
     # ---------------------------------------------------------------- stage 3: test_stage1/2.py

@@ -64,6 +64,28 @@ class REBNCONV(nn.Module):
         return self.relu_s1(self.bn_s1(self.conv_s1(x)))
 
 
+# Convolution arithmetic on the device: True = bf16 x 3 products on the bf16 MFMA (dsu_conv2d_fwd_x3,
+# ~2^-16 relative per product: far inside what a matte thresholded at 127 / 255 needs), False =
+# exact-f32 products on the f32 MFMA (dsu_conv2d_fwd).  A module attribute for tools and tests.
+EVAL_X3 = True
+
+
+def _packed(conv):
+    """The convolution's weight in the bf16 x 3 kernels' layout, cached on the module."""
+    w = conv.weight
+    ver = (w._version, w.data_ptr(), w.device)
+    cache = getattr(conv, "_dsu_pack", None)
+    if cache is None or cache[0] != ver:
+        conv._dsu_pack = cache = (ver, ops.PackedConvWeight(w))
+    return cache[1]
+
+
+def _conv(x, conv, bias, stride, padding, scale=None, shift=None, act=None):
+    if EVAL_X3:
+        return ops.conv2d_x3(x, _packed(conv), bias, stride, padding, scale, shift, act)
+    return ops.conv2d(x, conv.weight.float().contiguous(), bias, stride, padding, scale, shift, act)
+
+
 def _fold(conv, bn):
     scale = bn.weight / torch.sqrt(bn.running_var + bn.eps)
     shift = bn.bias - bn.running_mean * scale
@@ -79,27 +101,25 @@ def _rebnconv_hip(m, x):
     conv = m.conv_s1
     d, s = conv.dilation[0], conv.stride[0]
     scale, shift = _fold(conv, m.bn_s1)
-    w = conv.weight.float().contiguous()
     x = x.float()
     if d == 1:
-        return ops.conv2d(x.contiguous(), w, None, s, 1, scale, shift, "relu")
+        return _conv(x.contiguous(), conv, None, s, 1, scale, shift, "relu")
     assert s == 1
     B, _, H, W = x.shape
-    out = torch.empty((B, w.shape[0], H, W), dtype=torch.float32, device=x.device)
+    out = torch.empty((B, conv.weight.shape[0], H, W), dtype=torch.float32, device=x.device)
     for i in range(d):
         for j in range(d):
             sub = x[:, :, i::d, j::d]
             if sub.numel():
-                out[:, :, i::d, j::d] = ops.conv2d(sub.contiguous(), w, None, 1, 1, scale, shift, "relu")
+                out[:, :, i::d, j::d] = _conv(sub.contiguous(), conv, None, 1, 1, scale, shift, "relu")
     return out
 
 
 def _conv_hip(conv, x, stride=1):
     """plain nn.Conv2d 3x3 (conv_in, side outputs) on the HIP kernel when on the device."""
     if x.is_cuda:
-        return ops.conv2d(x.float().contiguous(), conv.weight.float().contiguous(),
-                          None if conv.bias is None else conv.bias.float().contiguous(),
-                          stride, conv.padding[0])
+        return _conv(x.float().contiguous(), conv,
+                     None if conv.bias is None else conv.bias.float().contiguous(), stride, conv.padding[0])
     return conv(x)
 
 

@@ -19,7 +19,9 @@ def _randomise_bn(net, seed):
             m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
 
 
-def test_isnet_forward_on_the_hip_convolution_matches_torch_cpu(dev):
+@pytest.mark.parametrize("x3", [True, False])
+def test_isnet_forward_on_the_hip_convolution_matches_torch_cpu(dev, x3, monkeypatch):
+    monkeypatch.setattr(matting, "EVAL_X3", x3)
     net = matting.load_isnet(None, "cpu", seed=3)
     _randomise_bn(net, 4)
     x = torch.rand(1, 3, 208, 176, generator=torch.Generator().manual_seed(5)) - 0.5   # odd pooled sizes below

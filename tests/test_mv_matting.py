@@ -78,6 +78,7 @@ def test_dilated_convolution_as_sublattice_convolutions(monkeypatch):
         y = F.conv2d(x, w, bias, stride, padding) * scale[None, :, None, None] + shift[None, :, None, None]
         return F.relu(y) if act == "relu" else y
     monkeypatch.setattr(matting.ops, "conv2d", conv2d)
+    monkeypatch.setattr(matting, "EVAL_X3", False)
     torch.manual_seed(1)
     for d, hw in ((2, (16, 16)), (4, (32, 32)), (8, (32, 32)), (2, (13, 18)), (4, (9, 7))):
         m = matting.REBNCONV(5, 7, dirate=d).eval()
