@@ -286,7 +286,8 @@ int dsu_accumulate_fwd(const float* weights, const float* values, int32_t channe
 /* OccupancyGrid._update tail (nerfacc 0.3.3 grid.py): occs[idx] = max(occs[idx]*decay, occ).
  * idx may be NULL (= all cells, warm-up; scratch unused).  With idx, every old value is read
  * before any is written (the indexed assignment gathers first) and a cell listed several times
- * keeps the largest of its candidates: scratch = n floats of the caller. */
+ * keeps the largest of its candidates: scratch = n floats of the caller.  occ are opacities (>= 0):
+ * a negative candidate is stored as 0. */
 int dsu_occgrid_ema(float* occs, const int64_t* idx, const float* occ, int64_t n, float decay,
                     float* scratch, void* stream);
 /* binary = occs > thre  (thre = min(mean(occs), occ_thre) computed by the caller). */

@@ -29,6 +29,15 @@ def test_entry_points_chain(dev, tmp_path):
         files = sorted(os.listdir(os.path.join(root, uid, "mv", sub)))
         assert files == sorted(f"{v}.png" for v in ("front", "front_right", "right", "back", "left", "front_left"))
     assert Image.open(os.path.join(root, uid, "mv", "color", "front.png")).size == (1024, 1024)
+    # the side masks through the IS-Net session (mv.py:17-18,120-122) instead of the silhouette stand-in
+    mv.main(["--uid", uid, "--data_root", root, "--num_inference_steps", "2", "--random_init",
+             "--matting", "isnet", "--save_folder", "mv_isnet"])
+    for v in ("front_right", "right", "left", "front_left"):
+        m = Image.open(os.path.join(root, uid, "mv_isnet", "mask", f"{v}.png"))
+        assert m.mode == "L" and m.size == (1024, 1024)
+    for v in ("front", "back"):                                       # the input's alpha, as before
+        assert np.array_equal(np.array(Image.open(os.path.join(root, uid, "mv_isnet", "mask", f"{v}.png"))),
+                              np.array(Image.open(os.path.join(root, uid, "mv", "mask", f"{v}.png"))))
     _drawing().split()[-1].save(os.path.join(root, uid, "char", "mask.png"))     # front mask (ortho.py:153-156)
     import json
     thin_list = os.path.join(root, "drawings_uids_thinning.json")
