@@ -552,10 +552,24 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
   const int64_t r0 = blockIdx.x * per;
   const int64_t r1 = r0 + per < n ? r0 + per : n;
   for (int64_t bbase = r0; bbase < r1; bbase += blockDim.x) {
-    const int64_t i = bbase + threadIdx.x;
+    // The last, partial iteration of a range holds one or two 64-point blocks (n ~ 2^18 + 4096
+    // leaves 32 points per workgroup): walked like the full ones it costs wave 0 (and 1) seven
+    // evaluations while the others wait — a ninth point half where 8.1 are needed, 1/9 of the
+    // kernel.  The evaluations of a point are independent here (per-wave partial sums, dIn rows
+    // per evaluation), so the waves share the blocks instead: all four take block 0 and every
+    // fourth evaluation (two evaluations at most), or two waves per block and every second one.
+    int blk = wave, e_start = 0, e_step = 1;
+#ifndef DSU_K1_PLAIN_TAIL
+    if (SPLIT && ENC) {
+      const int64_t left = r1 - bbase;
+      if (left <= 64) { blk = 0; e_start = wave; e_step = 4; }
+      else if (left <= 128) { blk = wave & 1; e_start = wave >> 1; e_step = 2; }
+    }
+#endif
+    const int64_t i = bbase + blk * 64 + lane;
     const bool valid = i < r1;
     const int64_t ii = valid ? i : r1 - 1;
-    const int64_t wave_first = bbase + wave * 64;            // wave-uniform
+    const int64_t wave_first = bbase + blk * 64;             // wave-uniform
     const float p[3] = {pts[ii * 3], pts[ii * 3 + 1], pts[ii * 3 + 2]};
     float ds = 0.f, dl = 0.f, dg[3] = {0.f, 0.f, 0.f};
     // sorted evaluation order: the upstream gradients stay in the caller's row order
@@ -592,7 +606,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     if (ENC) {
       // (unconditional loads from a clamped column: a branch per level kept the compiler from
       // issuing the row's loads together; masked levels are zeroed where the row is used)
-      const __half2* row = enc + (size_t)ii * active;
+      const __half2* row = enc + ((size_t)e_start * n + ii) * active;
 #pragma unroll
       for (int l = 0; l < NL; ++l) rw[l] = row[(uint32_t)l < active ? l : 0];
       if (HANDOVER) {
@@ -605,7 +619,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     }
     const int n_eval = wave_first < r1 ? 7 : 0;             // a wave beyond the range only joins the barriers
 #pragma unroll 1
-    for (int e = 0; e < n_eval; ++e) {
+    for (int e = e_start; e < n_eval; e += e_step) {
       float q[3];
       fd_point(p, e, eps, radius, q);
       const float cx = contract(q[0], radius), cy = contract(q[1], radius),
@@ -624,8 +638,8 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
           in[2 * l] = (uint32_t)l < active ? f.x : 0.0f;
           in[2 * l + 1] = (uint32_t)l < active ? f.y : 0.0f;
         }
-        if (e < 6) {
-          const __half2* row = enc + ((size_t)(e + 1) * n + ii) * active;
+        if (e + e_step < 7) {
+          const __half2* row = enc + ((size_t)(e + e_step) * n + ii) * active;
 #pragma unroll
           for (int l = 0; l < NL; ++l) {
             if (HANDOVER) rwn[HANDOVER ? l : 0] = row[(uint32_t)l < active ? l : 0];
@@ -892,7 +906,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
         }
         DSU_PROF(7)   // gW1 GEMM / column
         }  // live
-        if (ENC && HANDOVER && half == 1 && e < 6) {
+        if (ENC && HANDOVER && half == 1 && e + e_step < 7) {
           // the next evaluation's row, requested ~30 k clocks ago; the stores in flight are the
           // first half's (~8 k clocks old)
 #pragma unroll
