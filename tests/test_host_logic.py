@@ -177,3 +177,40 @@ def test_small_adamw_entries_and_step_counts(monkeypatch):
     assert seen == [3, 2, 3, 3]
     assert [sopt.state[id(p)][2] for p in ps] == [4, 3, 4]
     assert math.isclose(topt.state[rs[1]]["step"].item(), 3)
+
+
+def test_level_outer_forward_preconditions_of_the_shipped_grid():
+    """What sdf_fd_fwd_shared_kernel (csrc/hashgrid.hip) relies on for REGULAR points, checked with
+    the oracle's level table and the reference's progressive eps (geometry.py:196-215):
+    levels 0-3 dense / 4-9 hashed (its ND = 4); a +-eps offset moves less than one cell on every
+    active level (so the offset's cell is the centre's or its face neighbour); cell coordinates of
+    points in [0, 1] stay in [0, res - 1], hence a dense corner index is below 2 x the level size
+    (one subtraction replaces tcnn's modulo)."""
+    import numpy as np
+    from oracle import hashgrid as oh
+    lv = oh.make_levels()
+    assert lv["hashed"] == [0, 0, 0, 0, 1, 1, 1, 1, 1, 1]
+    f32 = np.float32
+    rng = np.random.default_rng(0)
+    p = (rng.random((200000, 3), dtype=np.float32) * 2 - 1).astype(f32)
+    p[:6] = [[1, -1, 0.3], [-1, 1, 1], [0.99999, 0, -0.99999], [1, 1, 1], [-1, -1, -1], [0, 0, 0]]
+    radius = f32(1.0)
+    contract = lambda x: ((x - (-radius)) / (radius - (-radius))).astype(f32)
+    for active in range(1, 11):
+        eps = f32(2.0 * 1.0 / (32 * 1.3195079107728942 ** (active - 1)))
+        q0 = contract(p)
+        for l in range(active):
+            scale, res = f32(lv["scale"][l]), lv["resolution"][l]
+            size = lv["offsets"][l + 1] - lv["offsets"][l]
+            assert float(eps) / 2 * float(scale) < 1.0
+            c0 = np.floor((np.float64(scale) * q0.astype(np.float64) + 0.5).astype(f32))
+            assert c0.min() >= 0 and c0.max() <= res - 1
+            if not lv["hashed"][l]:
+                assert res + res * res + res ** 3 < 2 * size      # largest corner index (coordinate res)
+            for ax in range(3):
+                for sgn in (1.0, -1.0):
+                    qe = contract(np.clip(p[:, ax] + f32(sgn) * eps, -radius, radius).astype(f32))
+                    assert qe.min() >= 0.0 and qe.max() <= 1.0
+                    ce = np.floor((np.float64(scale) * qe.astype(np.float64) + 0.5).astype(f32))
+                    rel = ce - c0[:, ax]
+                    assert rel.min() >= -1 and rel.max() <= 1, (active, l, ax, sgn)
