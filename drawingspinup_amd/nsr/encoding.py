@@ -27,6 +27,9 @@ class _EncodeFn(torch.autograd.Function):
         return None, g, None, None
 
 
+_INIT_CACHE = {}
+
+
 class Encoding(nn.Module):
     def __init__(self, n_input_dims, encoding_config, seed=1337, dtype=None):
         super().__init__()
@@ -41,10 +44,17 @@ class Encoding(nn.Module):
             per_level_scale=float(encoding_config.get("per_level_scale", 2.0)))
         self.n_input_dims = 3
         self.n_output_dims = self.cfg.n_output_dims
-        g = torch.Generator().manual_seed(seed)
-        # tcnn initialises grid parameters U(-1e-4, 1e-4)
-        init = (torch.rand(self.cfg.n_params, generator=g) * 2 - 1) * 1e-4
-        self.params = nn.Parameter(init)
+        # tcnn initialises grid parameters U(-1e-4, 1e-4) from its own fixed seed (1337): every
+        # encoding of a given size starts from the same values, so the draw (7.7 M values: ~20 ms of
+        # a drawing's reconstruction on the host) is made once per process and copied
+        key = (self.cfg.n_params, int(seed))
+        init = _INIT_CACHE.get(key)
+        if init is None:
+            g = torch.Generator().manual_seed(seed)
+            init = (torch.rand(self.cfg.n_params, generator=g) * 2 - 1) * 1e-4
+            _INIT_CACHE.clear()                       # one size at a time (30 MB of host memory)
+            _INIT_CACHE[key] = init
+        self.params = nn.Parameter(init.clone())
         self._shadow = None
         self._shadow_version = -1
         self._shadow_locked = False
