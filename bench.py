@@ -227,10 +227,11 @@ def cpu_baseline(nsr_steps, frames, mv_steps):
     # (c) NSR: the geometry network's share of one optimisation step (7 finite-difference
     # evaluations per point, forward AND backward through autograd) on 40 000 points with the
     # multi-threaded torch-CPU restatement (oracle/hashgrid_torch.py: index_select gathers +
-    # F.linear), scaled to the step's 262 144 + 4 096 points; marching, compositing,
+    # F.linear) on 131 072 points, scaled to the step's 262 144 + 4 096 points; marching, compositing,
     # texture MLP and losses are not charged.  Export: 2 x 512^3 forward-only evaluations.
     from oracle import hashgrid_torch as ht
-    n_pts = 40000
+    n_pts = 131072                                   # half a step's points (round 4: 40 000)
+    ht.training_work_seconds(8192, active_levels=5, threads=cores)          # warm-up (thread pools, allocator)
     t_fwd, t_fb = ht.training_work_seconds(n_pts, active_levels=5, threads=cores)
     step_pts = 262144 + 4096
     legs["nsr_s"] = nsr_steps * t_fb * step_pts / n_pts + 2 * 512 ** 3 * t_fwd / (7 * n_pts)
