@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Benchmark of the DrawingSpinUp hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W [--config drawing|nsr50k|frames]
+    python bench.py --gpus N --steps K --warmup W [--config drawing|unet|nsr50k|frames]
 
 `--config drawing` (default; BASELINE.json's metric, configs[4] per GPU): one "step" = ONE drawing
 through the hot path on each rank (weak scaling, one drawing per GPU per step):
@@ -15,6 +15,8 @@ marching cubes (device), the fine stage's quadric remeshing to 50 000 faces (hos
 library) and save_mesh's smoothing / colour back-projection / shear — the reference YAML's export
 switches for a uid outside the thinning list.  Not inside (stated in config.workload): Blender
 rendering, PNG / OBJ file I/O.
+`--config unet` (BASELINE configs[1]): one step = one forward of the multi-view UNet on the 12-sample
+batch of one drawing (6 views x 2 domains, 256x256 images = 32x32 latents, f16, random weights).
 `--config nsr50k` (BASELINE configs[2] micro-benchmark): one step = one NSR optimisation
 iteration with 50 000 rays marched through a 128^3 occupancy grid (synthetic sphere).
 `--config frames` (BASELINE configs[3]): one step = 24 frames through stage 1 + stage 2, the
@@ -47,16 +49,16 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=None)
     ap.add_argument("--warmup", type=int, default=None)
-    ap.add_argument("--config", default="drawing", choices=["drawing", "nsr50k", "frames"])
+    ap.add_argument("--config", default="drawing", choices=["drawing", "unet", "nsr50k", "frames"])
     ap.add_argument("--mv-steps", type=int, default=75)
     ap.add_argument("--nsr-steps", type=int, default=3000)
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args(argv)
     if a.steps is None:
-        a.steps = {"drawing": 1, "nsr50k": 50, "frames": 3}[a.config]
+        a.steps = {"drawing": 1, "unet": 50, "nsr50k": 50, "frames": 3}[a.config]
     if a.warmup is None:
-        a.warmup = {"drawing": 1, "nsr50k": 10, "frames": 1}[a.config]
+        a.warmup = {"drawing": 1, "unet": 5, "nsr50k": 10, "frames": 1}[a.config]
     return a
 
 
@@ -79,6 +81,8 @@ class KernelTimer:
         self.fam = {}
         self.stride = int(stride or self.STRIDE)
         self._calls = {}
+        import random
+        self._rng = random.Random(0x5eed)
 
     @property
     def enabled(self):
@@ -98,8 +102,11 @@ class KernelTimer:
         def timed(*a, **k):
             if not timer.enabled:
                 return orig(*a, **k)
-            c = timer._calls[family] = timer._calls.get(family, 0) + 1
-            if c % timer.stride:
+            # sampled by a seeded draw per call, not by call count: the diffusion UNet issues a
+            # periodic sequence of convolution / attention shapes, and a count-based stride that
+            # shares a factor with the calls per forward would time the same layers every step
+            timer._calls[family] = timer._calls.get(family, 0) + 1
+            if timer._rng.random() * timer.stride >= 1.0:
                 return orig(*a, **k)
             s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             s.record()
@@ -154,7 +161,9 @@ class KernelTimer:
             hbm = name.startswith("sdf_")
             ach = f["work"] / (ms * 1e-3) / (1e9 if hbm else 1e12)
             peak = HBM_PEAK_GBS if hbm else F16_MFMA_PEAK_TF
+            calls = self._calls.get(name)
             rows.append({"kernel": name, "bound": "hbm" if hbm else "mfma", "launches": n,
+                         "sampled_call_fraction": (n / calls) if calls else 1.0 / self.stride,
                          "total_ms": ms, "avg_launch_ms": ms / n,
                          "alg_work_per_launch": f["work"] / n, "achieved": ach, "peak": peak,
                          "unit": "GB/s" if hbm else "TFLOP/s", "frac": ach / peak})
@@ -225,10 +234,11 @@ def cpu_baseline(nsr_steps, frames, mv_steps):
     legs["mv_s"] = mv_steps * t_unet
     del un, ref
     # (c) NSR: the geometry network's share of one optimisation step (7 finite-difference
-    # evaluations per point, forward AND backward through autograd) on 40 000 points with the
-    # multi-threaded torch-CPU restatement (oracle/hashgrid_torch.py: index_select gathers +
-    # F.linear) on 131 072 points, scaled to the step's 262 144 + 4 096 points; marching, compositing,
-    # texture MLP and losses are not charged.  Export: 2 x 512^3 forward-only evaluations.
+    # evaluations per point, forward AND backward through autograd) with the multi-threaded
+    # torch-CPU restatement (oracle/hashgrid_torch.py: index_select gathers + F.linear, SURVEY.md
+    # 8d) on 131 072 points after a warm-up, scaled to the step's 262 144 + 4 096 points; marching,
+    # compositing, texture MLP and losses are not charged.  Export: 2 x 512^3 forward-only
+    # evaluations.
     from oracle import hashgrid_torch as ht
     n_pts = 131072                                   # half a step's points (round 4: 40 000)
     ht.training_work_seconds(8192, active_levels=5, threads=cores)          # warm-up (thread pools, allocator)
@@ -260,7 +270,9 @@ def run(args):
     dev = torch.device("cuda", local)
     timer = KernelTimer()
     timer.install()
-    if args.config == "nsr50k":
+    if args.config == "unet":
+        out = bench_unet(args, ddist, rank, world, dev, timer)
+    elif args.config == "nsr50k":
         out = bench_nsr50k(args, ddist, rank, world, dev, timer)
     elif args.config == "frames":
         out = bench_frames(args, ddist, rank, world, dev, timer)
@@ -356,15 +368,19 @@ def _roofline(timer, extra=None):
     return top
 
 
-def _style_exact_f32_seconds(pipe, inp, dev):
+def _style_seconds_with(pipe, inp, dev, **switches):
+    """The stylisation stage once more, beside the clock, with other arithmetic switches of
+    style/generators.py (EVAL_X3 / EVAL_DEFORM_X3)."""
     try:
         from drawingspinup_amd.style import generators
     except ImportError:
         return None
-    if not hasattr(pipe, "stylize") or not getattr(generators, "EVAL_X3", False):
+    if not hasattr(pipe, "stylize") or not hasattr(generators, "EVAL_DEFORM_X3"):
         return None
     _, frames_in, edges_in = inp
-    generators.EVAL_X3 = False
+    saved = {k: getattr(generators, k) for k in switches}
+    for k, v in switches.items():
+        setattr(generators, k, v)
     try:
         pipe.stylize(frames_in[:2], edges_in[:2])             # warm-up (weight layouts, tap tables)
         _sync(dev); t = time.time()
@@ -372,7 +388,8 @@ def _style_exact_f32_seconds(pipe, inp, dev):
         _sync(dev)
         return time.time() - t
     finally:
-        generators.EVAL_X3 = True
+        for k, v in saved.items():
+            setattr(generators, k, v)
 
 
 def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
@@ -431,19 +448,27 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
     assert len(gathered["views"]) == world and len(gathered["frames"]) == world
     per = {k: v / args.steps for k, v in stage_t.items()}
     per.update({k: v / args.steps for k, v in sub_t.items()})
-    # beside the clock: the stylisation stage once more with the exact-f32 kernels (f32 MFMA; the
-    # arithmetic of the reference's deform_conv2d -> sgemm path, TF32 off), so that the cost of the
-    # headline with them can be read off: value_exact_f32_style = 1 / (s/drawing - style + this)
-    per["style_exact_f32"] = _style_exact_f32_seconds(pipe, inputs[(True, args.steps - 1)], dev)
+    # The clock runs the reference's arithmetic per operator: stage 1's deform_conv2d layers in exact
+    # f32 (torchvision im2col + f32 addmm, TF32 off by default), stage 2's nn.Conv2d layers on bf16 x 3
+    # products (finer than the cuDNN TF32 the reference gets by default), IS-Net in exact f32 (f32
+    # ONNX session).  Beside the clock, for comparison with earlier rounds' lines: the stage with
+    # every layer on bf16 x 3, and with every layer in exact f32.
+    per["style_all_bf16x3"] = _style_seconds_with(pipe, inputs[(True, args.steps - 1)], dev,
+                                                  EVAL_X3=True, EVAL_DEFORM_X3=True)
+    per["style_all_exact_f32"] = _style_seconds_with(pipe, inputs[(True, args.steps - 1)], dev,
+                                                     EVAL_X3=False, EVAL_DEFORM_X3=False)
     stages = {
         "mv": {"bound": "mfma", "unit": "TFLOP/s", "peak": F16_MFMA_PEAK_TF,
                "achieved": 2.913 * args.mv_steps / max(per["mv"], 1e-9)},
-        # achieved = ALGORITHMIC flops (0.84 TFLOP per frame for the two generators)
-        # / stage time.  The evaluation convolutions issue three bf16 MFMA products per f32 product
-        # (bf16 x 3): the matrix pipe's issued rate is reported beside it, not as the fraction.
+        # achieved = ALGORITHMIC flops (0.84 TFLOP per frame for the two generators:
+        # 0.298 stage 1 + 0.544 stage 2) / stage time, against the bf16 MFMA peak the contract names.
+        # Stage 1 runs exact f32 products (f32 MFMA peak 157.3 TFLOP/s), stage 2 three bf16 MFMA
+        # products per f32 product: the stage is a mix of the two pipes, so the fraction against
+        # either single peak understates it; the per-pipe peaks are listed beside it.
         "style": {"bound": "mfma", "unit": "TFLOP/s", "peak": F16_MFMA_PEAK_TF,
                   "achieved": 0.84 * args.frames / max(per["style"], 1e-9),
-                  "issued_mfma_tflops": 3 * 0.84 * args.frames / max(per["style"], 1e-9),
+                  "stage1_tflop_exact_f32": 0.298 * args.frames,
+                  "stage2_tflop_bf16x3_issued": 3 * 0.544 * args.frames,
                   "f32_mfma_peak": F32_MFMA_PEAK_TF},
     }
     for st in stages.values():
@@ -467,8 +492,9 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
         "value": world * args.steps / elapsed, "unit": "drawings/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f16 (diffusion) / f16 table + f32 MLP (NSR) / f32 with bf16 x 3 products (stylisation; "
-                 "exact-f32 stage time in config.stage_seconds_rank0.style_exact_f32) / f32 (contour)",
+        "dtype": "f16 (diffusion) / f16 table + f32 MLP (NSR) / f32 (stage-1 deformable convolutions, "
+                 "IS-Net, contour) / f32 with bf16 x 3 products (stage-2 convolutions; the reference: "
+                 "cuDNN TF32)",
         "data": "synthetic",
         "config": {"workload": "one drawing per GPU: contour removal (FFC-ResNet generator, masks, host "
                                "TELEA inpainting, 512^2) -> 6-view diffusion (%d DDIM steps, B=12) -> "
@@ -484,6 +510,16 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
                                "bicubic routes pinned by tests/test_mv_preprocess.py; no effect on the "
                                "timing)" % (args.mv_steps, args.nsr_steps, args.frames),
                    "drawings_per_step": world, "parallelism": f"replica-per-drawing x{world}",
+                   # arithmetic per stage next to the reference's own (file:line in DESIGN.md 4)
+                   "stage_dtype": {
+                       "contour": "f32 (exact f32 MFMA; reference: cuDNN / cuFFT f32)",
+                       "mv": "f16 (reference: weight_dtype = torch.float16, mv.py:15)",
+                       "matting": "f32 (exact f32 MFMA; reference: f32 ONNX session, mv.py:17-18)",
+                       "nsr": "f16 table + f32 MLP (reference: tcnn f16 grid, f32 VanillaMLP)",
+                       "style_stage1": "f32 (exact f32 MFMA; reference: torchvision deform_conv2d "
+                                       "= im2col + f32 addmm, TF32 off by default)",
+                       "style_stage2": "f32 activations, bf16 x 3 products, f32 accumulation (2^-15 "
+                                       "per product; reference: cuDNN with TF32 allowed by default, 2^-11)"},
                    "stage_seconds_rank0": per, "weights_broadcast_bytes": bcast_bytes,
                    "gathered_bytes_per_step": sum(t.numel() * t.element_size() for k in gathered
                                                   for t in gathered[k])},
@@ -492,6 +528,45 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
     if not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.nsr_steps, args.frames, args.mv_steps)
     return out
+
+
+def bench_unet(args, ddist, rank, world, dev, timer):
+    """BASELINE configs[1]: 'single drawing, mvdiffusion 6-view 256x256 UNet forward, random weights':
+    UNetMV2DConditionModel.forward (unet_mv2d_condition.py:760-1054) on (12, 8, 32, 32) latents —
+    noise + image latents of 6 views x 2 domains — with the CLIP embedding and the camera / domain
+    class labels; every rank runs its own replica."""
+    from drawingspinup_amd.mv.unet import UNetMV2DConditionModel
+    torch.manual_seed(0)
+    unet = UNetMV2DConditionModel().half().to(dev).eval()
+    ddist.broadcast_module(unet, 0)
+    g = torch.Generator().manual_seed(1 + rank)
+    x = torch.randn(12, 8, 32, 32, generator=g).half().to(dev)
+    ctx = torch.randn(12, 1, 768, generator=g).half().to(dev)
+    cl = torch.randn(12, 10, generator=g).half().to(dev)
+    ts = torch.tensor([500], device=dev)
+
+    @torch.no_grad()
+    def step(s, timed):
+        return unet(x, ts, ctx, cl)
+
+    elapsed, out = _timed_loop(args, ddist, dev, timer, step)
+    if rank != 0:
+        return None
+    assert out.shape == (12, 4, 32, 32) and bool(torch.isfinite(out).all())
+    fps = world * args.steps / elapsed
+    tflop = 2.913                                  # algorithmic flops of one forward (SURVEY.md 8d)
+    return {"metric": "multi-view UNet forwards/sec (6 views x 2 domains, 256x256, B=12)",
+            "value": fps, "unit": "forwards/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": "one UNetMV2DConditionModel forward per step on (12,8,32,32) f16 "
+                                   "latents, one CLIP token, 10 class-label values; random-init weights "
+                                   "of the shipped architecture (320/640/1280/1280, 2 layers per block)",
+                       "parallelism": f"replica x{world}"},
+            "roofline": {"bound": "mfma", "unit": "TFLOP/s", "peak": F16_MFMA_PEAK_TF,
+                         "achieved": tflop * fps / world, "frac": tflop * fps / world / F16_MFMA_PEAK_TF,
+                         "traffic": None, "kernels": timer.summary()[:3]}}
 
 
 def bench_nsr50k(args, ddist, rank, world, dev, timer):

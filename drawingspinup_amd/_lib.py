@@ -103,6 +103,8 @@ class NsrStepArgs(C.Structure):                      # dsu_nsr_step_args
                 ("table_grad", c_vp),
                 ("inj_index", c_vp), ("inj_x", c_vp), ("inj_y", c_vp), ("inj_jitter", c_vp),
                 ("inj_pts_random", c_vp), ("inj_perturb", c_vp),
+                ("inj_rays", c_vp), ("inj_rgb", c_vp), ("inj_normal", c_vp), ("inj_mask", c_vp),
+                ("inj_cosines", c_vp), ("inj_view_weights", c_vp),
                 ("table_p", c_vp), ("table_m", c_vp), ("table_v", c_vp), ("table_n", c_i64),
                 ("table_lr", c_f32), ("table_bc1", c_f32), ("table_bc2_sqrt", c_f32),
                 ("table_eps", c_f32), ("table_wd", c_f32),
@@ -173,6 +175,7 @@ _PROTOS = {
     "dsu_nsr_driver_destroy": [c_vp],
     "dsu_nsr_driver_step": [c_vp, C.POINTER(NsrStepArgs), P],
     "dsu_nsr_driver_terms": [c_vp],
+    "dsu_nsr_driver_adam_moments": [c_vp, c_i32],
     "dsu_nsr_driver_sync": [c_vp],
     "dsu_nsr_driver_timing": [c_vp, c_i32],
     "dsu_nsr_driver_timing_read": [c_vp, c_i32, C.POINTER(c_i64), C.POINTER(C.c_double),
@@ -257,12 +260,18 @@ _PROTOS = {
                                   P, P, c_i32, P, P, P],
     "dsu_conv2d_fwd_x3": [P, P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                           c_i32, P, P, c_i32, P, P, P],
+    "dsu_conv_f32p_pack_weights": [P, c_i32, c_i32, c_i32, P, P],
+    "dsu_deform_conv3x3_fwd_f32p": [P, P, c_i64, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                                    P, P, c_i32, P, P, P],
+    "dsu_conv2d_fwd_f32p": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
+                            P, P, c_i32, P, P, P],
     "dsu_conv2d_fwd": [P, P, P, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32,
                        P, P, c_i32, P, P, P],
 }
 
 # return types that are neither an error code nor a byte count
 _RESTYPES = {"dsu_nsr_driver_destroy": None, "dsu_nsr_driver_terms": c_vp,
+             "dsu_nsr_driver_adam_moments": c_vp,
              "dsu_conv_x3_packed_elems": C.c_int64}
 
 _lib = None

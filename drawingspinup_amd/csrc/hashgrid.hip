@@ -814,6 +814,14 @@ void fd_shared_launch(uint32_t active, bool feat, int blocks, hipStream_t s, con
   constexpr int ND = 4;        // dense levels of the shipped grid (32 * 1.32^l, 2^19 entries)
   for (int l = 0; l < (int)active; ++l)
     if ((m.hashed[l] != 0) != (l >= ND)) return;
+  // the dense levels' index shortcut (one subtraction instead of a modulo) needs
+  // x + y res + z res^2 < 2 hsize for every corner (coordinates <= res): checked here, not only by
+  // the CPU test of the shipped configuration — another base resolution / table size takes the
+  // per-evaluation kernel instead of reading out of range
+  for (int l = 0; l < ND && l < (int)active; ++l) {
+    const uint64_t res = m.res[l], hsize = (uint64_t)m.off[l + 1] - m.off[l];
+    if (res + res * res + res * res * res >= 2 * hsize) return;
+  }
   auto one = [&](auto act_c) {
     constexpr int ACT = DSU_FWD_SHARED_LO + decltype(act_c)::value;
     if ((int)active != ACT) return;

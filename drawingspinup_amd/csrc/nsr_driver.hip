@@ -404,8 +404,9 @@ int enqueue_march(dsu_nsr_driver* d, int p, int64_t step, int32_t n_rays,
   Prefetch& f = d->L.pf[p];
   const int64_t* index = f.index; const int64_t* px = f.px; const int64_t* py = f.py;
   const float* jitter = f.jitter;
-  const bool need_draw = !injected || !a.inj_index || !a.inj_x || !a.inj_y || !a.inj_pts_random ||
-                         !a.inj_perturb || (a.randomized && !a.inj_jitter);
+  const bool have_rays = a.inj_rays || (a.inj_index && a.inj_x && a.inj_y);
+  const bool need_draw = !injected || !have_rays || !a.inj_pts_random || !a.inj_perturb ||
+                         (a.randomized && !a.inj_jitter);
   if (need_draw)
     DSU_TRY(dsu_nsr_draws(c.seed, step, n_rays, c.V, c.H, c.W, f.index, f.px, f.py, f.jitter,
                           c.n_random, f.pts_random, f.perturb, s));
@@ -415,12 +416,30 @@ int enqueue_march(dsu_nsr_driver* d, int p, int64_t step, int32_t n_rays,
     if (a.inj_y) py = a.inj_y;
     if (a.inj_jitter) jitter = a.inj_jitter;
   }
-  // rays (n,6) and, from the same launch, contiguous origins / directions for the marcher and the
-  // compositing kernels (they used to be two strided copies per step)
-  DSU_TRY(dsu_ortho_ray_batch_split(index, px, py, n_rays, c.c2w, c.origins, c.directions, c.images,
-                                    c.image_channels, c.normals, c.masks, c.view_weights, c.H, c.W,
-                                    f.rays, f.rgb, f.normal, f.mask, f.cosines, f.vw, f.rays_o,
-                                    f.rays_d, s));
+  if (injected && a.inj_rays) {
+    // tests: a whole ray batch (what preprocess_data returns) instead of dataset draws — the rows
+    // are copied into the prefetch set, the rays split into origins / directions
+    if (!a.inj_rgb || !a.inj_normal || !a.inj_mask || !a.inj_cosines || !a.inj_view_weights)
+      return DSU_EINVAL;
+    const size_t n = (size_t)n_rays;
+    DSU_HIP(hipMemcpyAsync(f.rays, a.inj_rays, n * 6 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    DSU_HIP(hipMemcpyAsync(f.rgb, a.inj_rgb, n * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    DSU_HIP(hipMemcpyAsync(f.normal, a.inj_normal, n * 3 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    DSU_HIP(hipMemcpyAsync(f.mask, a.inj_mask, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    DSU_HIP(hipMemcpyAsync(f.cosines, a.inj_cosines, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    DSU_HIP(hipMemcpyAsync(f.vw, a.inj_view_weights, n * sizeof(float), hipMemcpyDeviceToDevice, s));
+    DSU_HIP(hipMemcpy2DAsync(f.rays_o, 3 * sizeof(float), a.inj_rays, 6 * sizeof(float),
+                             3 * sizeof(float), n, hipMemcpyDeviceToDevice, s));
+    DSU_HIP(hipMemcpy2DAsync(f.rays_d, 3 * sizeof(float), a.inj_rays + 3, 6 * sizeof(float),
+                             3 * sizeof(float), n, hipMemcpyDeviceToDevice, s));
+  } else {
+    // rays (n,6) and, from the same launch, contiguous origins / directions for the marcher and the
+    // compositing kernels (they used to be two strided copies per step)
+    DSU_TRY(dsu_ortho_ray_batch_split(index, px, py, n_rays, c.c2w, c.origins, c.directions, c.images,
+                                      c.image_channels, c.normals, c.masks, c.view_weights, c.H, c.W,
+                                      f.rays, f.rgb, f.normal, f.mask, f.cosines, f.vw, f.rays_o,
+                                      f.rays_d, s));
+  }
   DSU_TRY(dsu_ray_aabb(f.rays_o, f.rays_d, n_rays, d->aabb, a.randomized ? jitter : nullptr,
                        c.render_step_size, f.tmin, f.tmax, s));
   DSU_TRY(dsu_ray_march_scratch(f.rays_o, f.rays_d, f.tmin, f.tmax, n_rays, d->aabb, a.occ_binary,
@@ -605,6 +624,10 @@ void dsu_nsr_driver_destroy(dsu_nsr_driver* d) {
 
 const float* dsu_nsr_driver_terms(const dsu_nsr_driver* d) { return d ? d->L.terms : nullptr; }
 
+const float* dsu_nsr_driver_adam_moments(const dsu_nsr_driver* d, int32_t second) {
+  return d ? (second ? d->L.adam_v : d->L.adam_m) : nullptr;
+}
+
 int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stream) {
   if (!d || !a || a->n_rays <= 0 || a->n_rays > d->cfg.cap_rays || !a->table_img || !a->table_grad ||
       a->active_levels == 0 || a->active_levels > d->cfg.grid.n_levels || a->adam_step < 1)
@@ -642,7 +665,7 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
   }
   // ---- this step's samples: prefetched by the previous call, or produced now
   const bool injected = a->inj_index || a->inj_x || a->inj_y || a->inj_jitter || a->inj_pts_random ||
-                        a->inj_perturb;
+                        a->inj_perturb || a->inj_rays;
   if (d->pf_valid[p] && d->pf_step[p] == a->step && d->pf_rays[p] == a->n_rays && !injected &&
       d->pf_randomized[p] == a->randomized && d->pf_occ[p] == a->occ_binary &&
       d->pf_occ_res[p] == a->occ_res) {
@@ -689,6 +712,7 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
     dsu_nsr_step_args na = *a;
     na.inj_index = na.inj_x = na.inj_y = nullptr;
     na.inj_jitter = na.inj_pts_random = na.inj_perturb = nullptr;
+    na.inj_rays = nullptr;
     DSU_TRY(enqueue_march(d, q, a->step + 1, next_rays, na, false, d->side));
     d->pf_step[q] = a->step + 1;
     d->pf_rays[q] = next_rays;
@@ -725,6 +749,7 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
     dsu_nsr_step_args na = *a;
     na.inj_index = na.inj_x = na.inj_y = nullptr;
     na.inj_jitter = na.inj_pts_random = na.inj_perturb = nullptr;
+    na.inj_rays = nullptr;
     DSU_HIP(hipEventRecord(d->fwd_done, s));
     DSU_HIP(hipStreamWaitEvent(d->side, d->fwd_done, 0));
     DSU_TRY(enqueue_pack(d, q, next_rays, na, false, d->side));
@@ -787,6 +812,7 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
     dsu_nsr_step_args na = *a;
     na.inj_index = na.inj_x = na.inj_y = nullptr;
     na.inj_jitter = na.inj_pts_random = na.inj_perturb = nullptr;
+    na.inj_rays = nullptr;
     DSU_HIP(hipStreamWaitEvent(d->side, d->gate, 0));          // recorded inside the call above
     DSU_TRY(enqueue_pack(d, q, next_rays, na, false, d->side));
     DSU_HIP(hipEventRecord(d->ready[q], d->side));

@@ -37,6 +37,7 @@ struct XArgs {
   const float* in;
   const uint4* w_hi;         // (Opad, CB, KK, 16) bf16, two uint4 per (o, cb, tap)
   const uint4* w_mid;
+  const uint4* w_f32;        // F32 kernels: (Opad, CB, KK, 16) f32, four uint4 per (o, cb, tap)
   const float* bias;
   const float* offset;       // deform only: (18,H,W)
   int64_t offset_bstride;
@@ -80,16 +81,29 @@ __device__ __forceinline__ uint32_t tap_flags(float h, float w, int H, int W) {
 
 // MODE 0: plain conv (KS x KS taps, stride STRIDE); MODE 1: 3x3 deformable, stride 1.
 // G = k-steps (taps) per LDS weight group, G | KS*KS.
-template <int MODE, int KS, int STRIDE, int BN, int G>
+// F32 = false: bf16 x 3 products on v_mfma_f32_32x32x16_bf16 (one k-step = 3 MFMAs per tile).
+// F32 = true : exact f32 products on v_mfma_f32_32x32x2_f32 — the arithmetic of the reference's
+//   deform_conv2d (im2col + f32 addmm, TF32 off by default) and of an f32 ONNX / cuDNN-without-TF32
+//   convolution.  Same k-step (one tap x 16 channels, the lane's 8 values straight from registers):
+//   MFMA j of a k-step contracts channel 16 cb + j (lanes 0-31) with channel 16 cb + 8 + j (lanes
+//   32-63), so its B operand is the lane's value j as it is and its A operand the lane's weight
+//   W[o = 32 n + (lane & 31)][16 cb + 8 (lane >> 5) + j][tap] — 8 consecutive floats of the packed
+//   row, read from LDS as two b128 (rows padded to 20 floats: conflict-free for the b128 lane
+//   groups).  8 MFMAs of 64 clocks per tile and k-step; the im2col side (gathers, blend) is the
+//   same ~130 VALU + 32 loads as in the bf16 form and hides behind them at two waves per SIMD.
+template <int MODE, int KS, int STRIDE, int BN, int G, bool F32>
 __global__ __launch_bounds__(256, 2) void conv_x3_kernel(XArgs a) {
   constexpr int KK = KS * KS;
   static_assert(KK % G == 0, "a weight group never straddles two channel blocks");
   constexpr int NG = KK / G;
   constexpr int NT = BN / 32;
   constexpr int NRAW = MODE == 1 ? 32 : 8;
-  constexpr int A_ITEMS = 2 * BN * 2;                     // uint4 per k-step: [hi|mid][o][kh]
+  constexpr int AROW = 20;                                // F32: floats per LDS weight row (16 + 4)
+  // uint4 per k-step: bf16 [hi|mid][o][kh], f32 [o][4]
+  constexpr int A_ITEMS = F32 ? BN * 4 : 2 * BN * 2;
   constexpr int NQ = (A_ITEMS + 255) / 256;
-  __shared__ uint4 sA[2][G][2][BN][2];                    // [buf][k-step][hi|mid][o][kh]
+  __shared__ uint4 sA[F32 ? 1 : 2][F32 ? 1 : G][2][F32 ? 1 : BN][2];   // bf16: [buf][k-step][hi|mid][o][kh]
+  __shared__ __attribute__((aligned(16))) float sAf[F32 ? 2 : 1][F32 ? G : 1][F32 ? BN : 1][AROW];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l31 = lane & 31, kh = lane >> 5;
@@ -133,25 +147,35 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(XArgs a) {
 
   // ---- weights: global -> registers -> LDS, one k-step's worth at a time (few live registers);
   // the whole group of G k-steps is in the other buffer by the barrier that ends the group
-  const size_t w_row = (size_t)a.CB * KK * 2;             // uint4 per output channel
+  const size_t w_row = (size_t)a.CB * KK * (F32 ? 4 : 2);   // uint4 per output channel
   auto load_A = [&](uint4 (&ra)[NQ], int cb, int t) {
-    const size_t s0 = ((size_t)cb * KK + t) * 2;
+    const size_t s0 = ((size_t)cb * KK + t) * (F32 ? 4 : 2);
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int id = tid + 256 * q;
-      const int k2 = id & 1, o = (id >> 1) % BN, part = (id >> 1) / BN;
       // rows past Opad (a tile wider than the layer) re-read the last row: their accumulators are
       // never stored; threads past A_ITEMS (BN = 32) repeat the first items
-      const uint4* w = (part & 1) ? a.w_mid : a.w_hi;
-      ra[q] = w[(size_t)min(o_base + o, a.Opad - 1) * w_row + s0 + k2];
+      if (F32) {
+        const int k4 = id & 3, o = (id >> 2) % BN;
+        ra[q] = a.w_f32[(size_t)min(o_base + o, a.Opad - 1) * w_row + s0 + k4];
+      } else {
+        const int k2 = id & 1, o = (id >> 1) % BN, part = (id >> 1) / BN;
+        const uint4* w = (part & 1) ? a.w_mid : a.w_hi;
+        ra[q] = w[(size_t)min(o_base + o, a.Opad - 1) * w_row + s0 + k2];
+      }
     }
   };
   auto store_A = [&](const uint4 (&ra)[NQ], int buf, int i) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
       const int id = tid + 256 * q;
-      const int k2 = id & 1, o = (id >> 1) % BN, part = (id >> 1) / BN;
-      sA[buf][i][part & 1][o][k2] = ra[q];
+      if (F32) {
+        const int k4 = id & 3, o = (id >> 2) % BN;
+        *reinterpret_cast<uint4*>(&sAf[buf][i][o][4 * k4]) = ra[q];
+      } else {
+        const int k2 = id & 1, o = (id >> 1) % BN, part = (id >> 1) / BN;
+        sA[buf][i][part & 1][o][k2] = ra[q];
+      }
     }
   };
 
@@ -201,8 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(XArgs a) {
       for (int j = 0; j < 8; ++j) rv[j] = ld(j, o);
     }
   };
-  auto make_B = [&](int t, bf16x8& bh, bf16x8& bm) {
-    float v[8];
+  auto make_B = [&](int t, float (&v)[8]) {
     if (MODE == 1) {
       uint32_t f = tflags[t / 5];
       float lh = taps[t].lh, lw = taps[t].lw;
@@ -225,7 +248,6 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(XArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) v[j] = __builtin_amdgcn_fmed3f(rv[j], lo, hi);
     }
-    split8(v, bh, bm);
   };
 
   // one k-step: this tap's B operand from the raw values in flight, the next k-step's raw loads
@@ -234,8 +256,10 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(XArgs a) {
     const int t = tg * G + i;
     const bool last_t = t + 1 == KK;
     bf16x8 bh, bm;
+    float v[8];
     uint4 ra[NQ];
-    make_B(t, bh, bm);
+    make_B(t, v);
+    if (!F32) split8(v, bh, bm);
     if (last_t) {
       lb = min(cb + 1, a.CB - 1);
       kh_b = lb * 16 + 8 >= a.C ? 0u : kh_full;
@@ -244,13 +268,30 @@ __global__ __launch_bounds__(256, 2) void conv_x3_kernel(XArgs a) {
     // (unconditional: after the last group this re-reads valid weights into the buffer nobody
     // reads any more — a branch here made the compiler park the piece in scratch)
     load_A(ra, tg + 1 < NG ? cb : min(cb + 1, a.CB - 1), (tg + 1 < NG ? (tg + 1) * G : 0) + i);
+    if (F32) {
 #pragma unroll
-    for (int n = 0; n < NT; ++n) {
-      const bf16x8 ah = __builtin_bit_cast(bf16x8, sA[buf][i][0][n * 32 + l31][kh]);
-      const bf16x8 am = __builtin_bit_cast(bf16x8, sA[buf][i][1][n * 32 + l31][kh]);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[n], 0, 0, 0);
-      acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[n], 0, 0, 0);
+      for (int n = 0; n < NT; ++n) {
+        const float* ap = &sAf[buf][i][n * 32 + l31][8 * kh];
+        const float4 a0 = *reinterpret_cast<const float4*>(ap);
+        const float4 a1 = *reinterpret_cast<const float4*>(ap + 4);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.x, v[0], acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.y, v[1], acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.z, v[2], acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.w, v[3], acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.x, v[4], acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.y, v[5], acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.z, v[6], acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.w, v[7], acc[n], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int n = 0; n < NT; ++n) {
+        const bf16x8 ah = __builtin_bit_cast(bf16x8, sA[buf][i][0][n * 32 + l31][kh]);
+        const bf16x8 am = __builtin_bit_cast(bf16x8, sA[buf][i][1][n * 32 + l31][kh]);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[n], 0, 0, 0);
+        acc[n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[n], 0, 0, 0);
+      }
     }
     store_A(ra, buf ^ 1, i);
   };
@@ -331,26 +372,40 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, int O, int C, i
   mid[idx] = __builtin_bit_cast(uint16_t, m);
 }
 
+// f32 form of the packed layout (the F32 kernels' A operand): (Opad, CB, KK, 16) floats, zero padded
+__global__ void pack_weights_f32_kernel(const float* __restrict__ w, int O, int C, int KK, int CB,
+                                        int64_t total, float* __restrict__ out) {
+  const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  const int k = (int)(idx & 15);
+  int64_t r = idx >> 4;
+  const int t = (int)(r % KK); r /= KK;
+  const int cb = (int)(r % CB);
+  const int o = (int)(r / CB);
+  const int c = cb * 16 + k;
+  out[idx] = (o < O && c < C) ? w[((size_t)o * C + c) * KK + t] : 0.0f;
+}
+
 inline int opad_of(int O) { return (O + 31) & ~31; }
 inline int cb_of(int C) { return (C + 15) / 16; }
 
-template <int MODE, int KS, int STRIDE, int G>
+template <int MODE, int KS, int STRIDE, int G, bool F32 = false>
 int launch_x3(const XArgs& a, hipStream_t s) {
   const int npix = a.OH * a.OW;
   const int gx = (npix + 127) / 128;
   // as in style_conv.hip: small images get 32-channel tiles so that the launch covers the chip
   if (a.Opad > 32 && (int64_t)gx * ((a.Opad + 127) / 128) * a.B < 256) {
     dim3 grid(gx, a.Opad / 32, a.B);
-    conv_x3_kernel<MODE, KS, STRIDE, 32, G><<<grid, 256, 0, s>>>(a);
+    conv_x3_kernel<MODE, KS, STRIDE, 32, G, F32><<<grid, 256, 0, s>>>(a);
   } else if (a.Opad > 64) {
     dim3 grid(gx, (a.Opad + 127) / 128, a.B);
-    conv_x3_kernel<MODE, KS, STRIDE, 128, G><<<grid, 256, 0, s>>>(a);
+    conv_x3_kernel<MODE, KS, STRIDE, 128, G, F32><<<grid, 256, 0, s>>>(a);
   } else if (a.Opad > 32) {
     dim3 grid(gx, 1, a.B);
-    conv_x3_kernel<MODE, KS, STRIDE, 64, G><<<grid, 256, 0, s>>>(a);
+    conv_x3_kernel<MODE, KS, STRIDE, 64, G, F32><<<grid, 256, 0, s>>>(a);
   } else {
     dim3 grid(gx, 1, a.B);
-    conv_x3_kernel<MODE, KS, STRIDE, 32, G><<<grid, 256, 0, s>>>(a);
+    conv_x3_kernel<MODE, KS, STRIDE, 32, G, F32><<<grid, 256, 0, s>>>(a);
   }
   if (hipGetLastError() != hipSuccess) return DSU_ELAUNCH;
   return DSU_OK;
@@ -392,6 +447,60 @@ int dsu_deform_conv3x3_fwd_x3(const float* input, const float* offset, int64_t o
   a.B = B; a.C = C; a.CB = cb_of(C); a.H = H; a.W = W; a.O = O; a.Opad = opad_of(O);
   a.OH = H; a.OW = W; a.pad = 1; a.act = act; a.in_relu = in_relu;
   return launch_x3<1, 3, 1, 3>(a, (hipStream_t)stream);
+}
+
+int dsu_conv_f32p_pack_weights(const float* weight, int32_t O, int32_t C, int32_t k, float* w_packed,
+                               void* stream) {
+  if (!weight || !w_packed || O <= 0 || C <= 0 || k <= 0) return DSU_EINVAL;
+  if (((uintptr_t)w_packed) & 15) return DSU_EINVAL;
+  const int64_t total = dsu_conv_x3_packed_elems(O, C, k);
+  pack_weights_f32_kernel<<<dsu_blocks_for(total, 256), 256, 0, (hipStream_t)stream>>>(
+      weight, O, C, k * k, cb_of(C), total, w_packed);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_deform_conv3x3_fwd_f32p(const float* input, const float* offset, int64_t offset_batch_stride,
+                                const float* w_packed, int32_t B, int32_t C, int32_t H, int32_t W,
+                                int32_t O, int32_t in_relu, const float* ep_scale,
+                                const float* ep_shift, int32_t act, const float* residual, float* out,
+                                void* stream) {
+  if (!input || !offset || !w_packed || !out) return DSU_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || O <= 0 || act < 0 || act > 3) return DSU_EINVAL;
+  if ((ep_scale == nullptr) != (ep_shift == nullptr)) return DSU_EINVAL;
+  if ((int64_t)C * H * W >= (1ll << 30) || (C & 7)) return DSU_EUNSUP;
+  XArgs a{};
+  a.in = input; a.w_f32 = (const uint4*)w_packed; a.bias = nullptr;
+  a.offset = offset; a.offset_bstride = offset_batch_stride;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.residual = residual; a.out = out;
+  a.B = B; a.C = C; a.CB = cb_of(C); a.H = H; a.W = W; a.O = O; a.Opad = opad_of(O);
+  a.OH = H; a.OW = W; a.pad = 1; a.act = act; a.in_relu = in_relu;
+  return launch_x3<1, 3, 1, 3, true>(a, (hipStream_t)stream);
+}
+
+int dsu_conv2d_fwd_f32p(const float* input, const float* w_packed, const float* bias, int32_t B,
+                        int32_t C, int32_t H, int32_t W, int32_t O, int32_t k, int32_t stride,
+                        int32_t pad, int32_t in_relu, const float* ep_scale, const float* ep_shift,
+                        int32_t act, const float* residual, float* out, void* stream) {
+  if (!input || !w_packed || !out) return DSU_EINVAL;
+  if (B <= 0 || C <= 0 || H <= 0 || W <= 0 || O <= 0 || act < 0 || act > 3 || pad < 0)
+    return DSU_EINVAL;
+  if ((ep_scale == nullptr) != (ep_shift == nullptr)) return DSU_EINVAL;
+  if ((int64_t)C * H * W >= (1ll << 30) || (C & 7)) return DSU_EUNSUP;
+  XArgs a{};
+  a.in = input; a.w_f32 = (const uint4*)w_packed; a.bias = bias;
+  a.offset = nullptr; a.offset_bstride = 0;
+  a.ep_scale = ep_scale; a.ep_shift = ep_shift; a.residual = residual; a.out = out;
+  a.B = B; a.C = C; a.CB = cb_of(C); a.H = H; a.W = W; a.O = O; a.Opad = opad_of(O);
+  a.pad = pad; a.act = act; a.in_relu = in_relu;
+  a.OH = (H + 2 * pad - k) / stride + 1;
+  a.OW = (W + 2 * pad - k) / stride + 1;
+  if (a.OH <= 0 || a.OW <= 0) return DSU_EINVAL;
+  hipStream_t s = (hipStream_t)stream;
+  if (k == 1 && stride == 1) return launch_x3<0, 1, 1, 1, true>(a, s);
+  if (k == 3 && stride == 1) return launch_x3<0, 3, 1, 3, true>(a, s);
+  if (k == 3 && stride == 2) return launch_x3<0, 3, 2, 3, true>(a, s);
+  return DSU_EUNSUP;             // 7x7: the LDS weight group of a kernel row does not fit in f32
 }
 
 int dsu_conv2d_fwd_x3(const float* input, const uint16_t* w_hi, const uint16_t* w_mid,

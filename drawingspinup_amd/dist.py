@@ -50,7 +50,12 @@ def init(backend=None, force=None):
         # share instead of N pools of `cores` threads each
         cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
         torch.set_num_threads(max(1, cores // _ranks_on_this_node(world)))
-        _FORCED = bool(force) and world == 1
+    # also when the caller (or a torchrun wrapper, or an earlier init()) created the group: a forced
+    # one-rank run must exercise the collectives, not skip them silently
+    _FORCED = bool(force) and world == 1 and dist.is_initialized()
+    if _FORCED and rank == 0:
+        print("[dsu dist] forced one-rank process group: collectives run (DSU_DIST_FORCE)",
+              flush=True)
     return rank, world, local
 
 

@@ -191,7 +191,8 @@ class DrawingPipeline:
             # through as one batch (the reference calls the session once per view; the network is
             # per-image in eval mode, and the convolutions fill the chip better at B = 4)
             with torch.no_grad():
-                u8 = (col[[1, 2, 4, 5]].permute(0, 3, 1, 2) * 255).to(torch.uint8)
+                # 8-bit quantisation as tensor2pil does (mv.py:46-48: mul 255, add 0.5, clamp)
+                u8 = (col[[1, 2, 4, 5]].permute(0, 3, 1, 2) * 255 + 0.5).clamp(0, 255).to(torch.uint8)
                 mattes = (self.isnet(u8.float() / 255.0 - 0.5).clamp(0, 1) * 255).to(torch.uint8)[:, 0]
             self.last_side_mattes = mattes
         if self.time_substages:

@@ -64,26 +64,26 @@ class REBNCONV(nn.Module):
         return self.relu_s1(self.bn_s1(self.conv_s1(x)))
 
 
-# Convolution arithmetic on the device: True = bf16 x 3 products on the bf16 MFMA (dsu_conv2d_fwd_x3,
-# ~2^-16 relative per product: far inside what a matte thresholded at 127 / 255 needs), False =
-# exact-f32 products on the f32 MFMA (dsu_conv2d_fwd).  A module attribute for tools and tests.
-EVAL_X3 = True
+# Convolution arithmetic on the device.  The reference runs the network as an f32 ONNX session
+# (mv.py:17-18): False (default) = exact-f32 products on the f32 MFMA (dsu_conv2d_fwd_f32p); True =
+# bf16 x 3 products on the bf16 MFMA (dsu_conv2d_fwd_x3, ~2^-16 relative per product: far inside
+# what a matte thresholded at 127 / 255 needs, but not the reference's arithmetic — an A/B switch
+# for tools and tests).
+EVAL_X3 = False
 
 
-def _packed(conv):
-    """The convolution's weight in the bf16 x 3 kernels' layout, cached on the module."""
+def _packed(conv, exact):
+    """The convolution's weight in the evaluation kernels' packed layout, cached on the module."""
     w = conv.weight
-    ver = (w._version, w.data_ptr(), w.device)
+    ver = (w._version, w.data_ptr(), w.device, bool(exact))
     cache = getattr(conv, "_dsu_pack", None)
     if cache is None or cache[0] != ver:
-        conv._dsu_pack = cache = (ver, ops.PackedConvWeight(w))
+        conv._dsu_pack = cache = (ver, ops.PackedConvWeight(w, exact=exact))
     return cache[1]
 
 
 def _conv(x, conv, bias, stride, padding, scale=None, shift=None, act=None):
-    if EVAL_X3:
-        return ops.conv2d_x3(x, _packed(conv), bias, stride, padding, scale, shift, act)
-    return ops.conv2d(x, conv.weight.float().contiguous(), bias, stride, padding, scale, shift, act)
+    return ops.conv2d_x3(x, _packed(conv, not EVAL_X3), bias, stride, padding, scale, shift, act)
 
 
 def _fold(conv, bn):
@@ -230,10 +230,14 @@ class ISNetDIS(nn.Module):
 def load_isnet(path=None, device="cuda", seed=0):
     """ISNetDIS in eval mode; `path`: a DIS state_dict (`isnet-general-use.pth`; keys of the
     unused training-time modules are ignored), None: seeded random weights."""
-    torch.manual_seed(seed)
-    net = ISNetDIS()
-    if path is not None:
-        sd = torch.load(path, map_location="cpu")
+    if path is None:
+        # seeded random weights without touching the caller's global RNG stream
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(seed)
+            net = ISNetDIS()
+    else:
+        net = ISNetDIS()
+        sd = torch.load(path, map_location="cpu", weights_only=True)
         sd = sd.get("state_dict", sd)
         missing, unexpected = net.load_state_dict(sd, strict=False)
         if missing:

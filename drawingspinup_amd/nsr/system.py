@@ -731,9 +731,20 @@ class OrthoNeuSSystem:
         drv.set_timing(int(native_timing.get("stride", 1)) if native_timing["enabled"] else 0)
         a = drv.args
         inject = inject or {}
-        if "batch" in inject:
-            raise ValueError("the native step takes injected draws (index, x, y, ...), not a ray batch")
         keep = []
+        # tests may hand over a whole ray batch (rays, rgb, normal, mask, cosines, view_weights), as
+        # to training_step_fused: copied into the driver's sample set instead of the dataset gathers
+        batch = inject.get("batch") or {}
+        for field, key in (("inj_rays", "rays"), ("inj_rgb", "rgb"), ("inj_normal", "normal"),
+                           ("inj_mask", "mask"), ("inj_cosines", "cosines"),
+                           ("inj_view_weights", "view_weights")):
+            t = batch.get(key)
+            if t is not None:
+                t = t.to(self.device, torch.float32).contiguous()
+                keep.append(t)
+            setattr(a, field, None if t is None else t.data_ptr())
+        if batch and int(batch["rays"].shape[0]) != int(self.train_num_rays):
+            raise ValueError("injected ray batch: train_num_rays must equal its row count")
         for field, key, dt in (("inj_index", "index", torch.int64), ("inj_x", "x", torch.int64),
                                ("inj_y", "y", torch.int64), ("inj_jitter", "jitter", torch.float32),
                                ("inj_pts_random", "pts_random", torch.float32),
@@ -766,6 +777,8 @@ class OrthoNeuSSystem:
         n_tab, lr_tab, bc1, bc2s = topt.prepare_step(int(geo.active_levels), lrs["geometry"])
         a.table_img, a.table_grad = topt.img.data_ptr(), topt.grad.data_ptr()
         a.table_p, a.table_m, a.table_v = enc.params.data_ptr(), topt.m.data_ptr(), topt.v.data_ptr()
+        if self.keep_table_grad:              # tests: no table update, its gradient stays in topt.grad
+            a.table_p = None
         a.table_n, a.table_lr, a.table_bc1, a.table_bc2_sqrt = int(n_tab), lr_tab, bc1, bc2s
         a.table_eps, a.table_wd = float(topt.eps), float(topt.wd)
         # the step's loss terms come back as a copy in fresh memory (the driver's two sets are reused
@@ -789,7 +802,10 @@ class OrthoNeuSSystem:
         n_rays = int(self.train_num_rays)
         if m.config.dynamic_ray_sampling:
             self.train_num_rays = int(a.out_next_n_rays)
-        topt.commit_step(lr_tab)               # the update itself was launched by the driver
+        if self.keep_table_grad:
+            enc.params.grad = topt.grad.clone()
+        else:
+            topt.commit_step(lr_tab)           # the update itself was launched by the driver
         self.global_step += 1
         t = terms_copy
         L = self.config.loss

@@ -685,17 +685,25 @@ def conv2d(x, weight, bias=None, stride=1, padding=0, ep_scale=None, ep_shift=No
 
 
 class PackedConvWeight:
-    """A convolution weight split into bf16 hi/mid parts in the layout the bf16 x 3 evaluation
-    kernels read (dsu_conv_x3_pack_weights): built on the device, once per weight version."""
+    """A convolution weight in the layout the evaluation kernels read, built on the device once per
+    weight version: split into bf16 hi/mid parts (dsu_conv_x3_pack_weights; bf16 x 3 kernels) or,
+    with exact=True, as f32 (dsu_conv_f32p_pack_weights; exact-f32 kernels)."""
 
-    def __init__(self, weight):
+    def __init__(self, weight, exact=False):
         weight = _f32c(weight.detach())
         self.O, self.C, self.k, k2 = weight.shape
         assert self.k == k2
+        self.exact = bool(exact)
         self.C8 = (self.C + 7) & ~7      # the kernels read channels in groups of eight
         n = int(lib().dsu_conv_x3_packed_elems(self.O, self.C, self.k))
         if n <= 0:
             raise DsuError("dsu_conv_x3_packed_elems: unsupported shape")
+        if self.exact:
+            self.f32 = torch.empty(n, dtype=torch.float32, device=weight.device)
+            check(lib().dsu_conv_f32p_pack_weights(ptr(weight), self.O, self.C, self.k,
+                                                   ptr(self.f32), stream()),
+                  "dsu_conv_f32p_pack_weights")
+            return
         self.hi = torch.empty(n, dtype=torch.int16, device=weight.device)
         self.mid = torch.empty(n, dtype=torch.int16, device=weight.device)
         check(lib().dsu_conv_x3_pack_weights(ptr(weight), self.O, self.C, self.k, ptr(self.hi),
@@ -723,12 +731,19 @@ def _channels8(x, packed):
 
 def deform_conv3x3_x3(x, offset, packed, ep_scale=None, ep_shift=None, act=None, residual=None,
                       in_relu=False):
-    """deform_conv3x3 with a PackedConvWeight (bf16 x 3 products, f32 accumulation)."""
+    """deform_conv3x3 with a PackedConvWeight: bf16 x 3 products with f32 accumulation, or — for a
+    weight packed with exact=True — exact f32 products (dsu_deform_conv3x3_fwd_f32p)."""
     x, offset = _channels8(_f32c(x), packed), _f32c(offset)
     B, Cin, H, W = x.shape
     assert packed.k == 3, "dsu deform conv: 3x3, groups=1 only"
     bstride = 0 if offset.dim() == 3 or offset.shape[0] == 1 else 18 * H * W
     out = torch.empty((B, packed.O, H, W), dtype=torch.float32, device=x.device)
+    if packed.exact:
+        check(lib().dsu_deform_conv3x3_fwd_f32p(ptr(x), ptr(offset), bstride, ptr(packed.f32), B, Cin,
+                                                H, W, packed.O, int(in_relu), ptr(ep_scale),
+                                                ptr(ep_shift), ACT[act], ptr(residual), ptr(out),
+                                                stream()), "dsu_deform_conv3x3_fwd_f32p")
+        return out
     check(lib().dsu_deform_conv3x3_fwd_x3(ptr(x), ptr(offset), bstride, ptr(packed.hi),
                                           ptr(packed.mid), B, Cin, H, W, packed.O, int(in_relu),
                                           ptr(ep_scale), ptr(ep_shift), ACT[act], ptr(residual),
@@ -738,13 +753,20 @@ def deform_conv3x3_x3(x, offset, packed, ep_scale=None, ep_shift=None, act=None,
 
 def conv2d_x3(x, packed, bias=None, stride=1, padding=0, ep_scale=None, ep_shift=None, act=None,
               residual=None, in_relu=False):
-    """conv2d with a PackedConvWeight (bf16 x 3 products, f32 accumulation)."""
+    """conv2d with a PackedConvWeight: bf16 x 3 products with f32 accumulation, or — for a weight
+    packed with exact=True — exact f32 products (dsu_conv2d_fwd_f32p; k in {1, 3})."""
     x = _channels8(_f32c(x), packed)
     B, Cin, H, W = x.shape
     k = packed.k
     OH = (H + 2 * padding - k) // stride + 1
     OW = (W + 2 * padding - k) // stride + 1
     out = torch.empty((B, packed.O, OH, OW), dtype=torch.float32, device=x.device)
+    if packed.exact:
+        check(lib().dsu_conv2d_fwd_f32p(ptr(x), ptr(packed.f32), ptr(bias), B, Cin, H, W, packed.O,
+                                        k, stride, padding, int(in_relu), ptr(ep_scale),
+                                        ptr(ep_shift), ACT[act], ptr(residual), ptr(out), stream()),
+              "dsu_conv2d_fwd_f32p")
+        return out
     check(lib().dsu_conv2d_fwd_x3(ptr(x), ptr(packed.hi), ptr(packed.mid), ptr(bias), B, Cin, H, W,
                                   packed.O, k, stride, padding, int(in_relu), ptr(ep_scale),
                                   ptr(ep_shift), ACT[act], ptr(residual), ptr(out), stream()),

@@ -529,6 +529,26 @@ int dsu_conv2d_fwd_x3(const float* input, const uint16_t* w_hi, const uint16_t* 
                       const float* ep_scale, const float* ep_shift, int32_t act,
                       const float* residual, float* out, void* stream);
 
+/* Exact-f32 evaluation variants on the same im2col-in-registers structure (f32 MFMA,
+ * v_mfma_f32_32x32x2_f32: every product and sum an f32 fmaf, the arithmetic of
+ * torchvision.ops.deform_conv2d's im2col + f32 addmm with TF32 off, which is PyTorch's default
+ * for matmuls: models.py:302-351 via test_stage1.py:42-71; and of the f32 ONNX session behind
+ * mv.py:17-18,134-150).  Same tensors, epilogue and argument meaning as dsu_deform_conv3x3_fwd /
+ * dsu_conv2d_fwd; the weight comes packed as (roundup(O,32), ceil(C/16), k*k, 16) f32, zero padded
+ * (dsu_conv_x3_packed_elems(O, C, k) floats, 16-byte aligned).  C % 8 == 0 (callers pad with zero
+ * channels); k in {1,3} (stride 2 for k = 3 only), others DSU_EUNSUP -> dsu_conv2d_fwd. */
+int dsu_conv_f32p_pack_weights(const float* weight, int32_t O, int32_t C, int32_t k, float* w_packed,
+                               void* stream);
+int dsu_deform_conv3x3_fwd_f32p(const float* input, const float* offset, int64_t offset_batch_stride,
+                                const float* w_packed, int32_t B, int32_t C, int32_t H, int32_t W,
+                                int32_t O, int32_t in_relu, const float* ep_scale,
+                                const float* ep_shift, int32_t act, const float* residual, float* out,
+                                void* stream);
+int dsu_conv2d_fwd_f32p(const float* input, const float* w_packed, const float* bias, int32_t B,
+                        int32_t C, int32_t H, int32_t W, int32_t O, int32_t k, int32_t stride,
+                        int32_t pad, int32_t in_relu, const float* ep_scale, const float* ep_shift,
+                        int32_t act, const float* residual, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------
  * Style translator, per-character TRAINING (3_style_translator/training/trainers.py:140-192:
  * autograd through GeneratorJ / GeneratorJ_RIC, DiscriminatorN_IN and PerceptualVGG19 on
@@ -813,6 +833,11 @@ typedef struct dsu_nsr_step_args {
   /* injected draws for THIS step (tests; any NULL = the driver's own draw) */
   const int64_t *inj_index, *inj_x, *inj_y;
   const float *inj_jitter, *inj_pts_random, *inj_perturb;
+  /* tests: a whole ray batch as OrthoNeuSSystem.preprocess_data returns it (neus_ortho.py:26-82) in
+   * place of the (index, x, y) gathers: rays (n,6) = [origin | direction], rgb (n,3), normal (n,3),
+   * mask, cosines, view_weights (n); inj_rays NULL = the dataset path; with it the other five are
+   * required */
+  const float *inj_rays, *inj_rgb, *inj_normal, *inj_mask, *inj_cosines, *inj_view_weights;
   /* the hash table's AdamW step (dsu_table_adamw), launched by the driver behind the backward:
    * master parameters and moments, number of floats of the active levels, this step's lr and
    * bias corrections (the caller keeps the level / decay bookkeeping); table_p NULL = skip */
@@ -844,6 +869,13 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* args, void* main_s
  * loss terms: rgb_mse, rgb_l1, normal, mask, eikonal, sparsity, normal_smooth (each already
  * multiplied by its lambda).  A set is reused (zeroed) at the end of the following step. */
 const float* dsu_nsr_driver_terms(const dsu_nsr_driver* d);
+/* Device pointer to the first (second = 0) or second (1) AdamW moments of the 13 small tensors,
+ * 7 902 floats in the order lin0.weight_v (64x23), lin0.weight_g (64), lin0.bias (64),
+ * lin1.weight_v (13x64), lin1.weight_g (13), lin1.bias (13), the texture MLP's w0 b0 w1 b1 w2 b2,
+ * variance (1).  After ONE step from zeroed moments m / (1 - beta1) is that step's gradient per
+ * parameter — how tests/test_gpu_nsr_native.py compares the library-sequenced step with the
+ * reference's loss.backward() (systems/neus_ortho.py:79-169). */
+const float* dsu_nsr_driver_adam_moments(const dsu_nsr_driver* d, int32_t second);
 /* HIP-event timing of the two geometry launches of a step (family 0: dsu_sdf_fd_fwd_sorted,
  * 1: dsu_sdf_fd_bwd_sorted) on the stream they run on: enable = n > 0 times the steps whose index
  * is a multiple of n (resets; 1 = every step — the four event records cost ~28 us of main-queue time

@@ -289,3 +289,131 @@ def test_native_occupancy_refresh_own_draws(dev):
     assert torch.equal(grid.occs, first)
     # the step after a refresh runs (the driver re-marches with the new grid)
     sysm.training_step()
+
+
+def test_native_occupancy_refresh_subsamples_a_dense_grid(dev):
+    """More occupied cells than N/4 (grid.py _update: `if n < len(occupied_indices)`: N/4 of them
+    drawn WITH replacement) — the branch a sphere scene never reaches.  The grid is made dense by
+    hand (a ball of radius 0.85: 32 % of the cells); the exported selection is checked for its
+    structure and replayed through the torch form from the same state."""
+    sysm, ds = _system(dev, 13, "native")
+    for _ in range(2):
+        sysm.training_step()
+    drv, m = sysm._native, sysm.model
+    grid = m.occupancy_grid
+    n, res = grid.num_cells, grid.res
+    c = (torch.arange(res, device=dev) + 0.5) / res * 2 - 1
+    ball = (c[:, None, None] ** 2 + c[None, :, None] ** 2 + c[None, None, :] ** 2).sqrt() <= 0.85
+    grid._binary = ball
+    grid._binary_u8 = ball.reshape(-1).to(torch.uint8).contiguous()
+    grid.occs.copy_(ball.reshape(-1).float() * 0.5 + 1e-4)
+    was_on = torch.nonzero(ball.reshape(-1))[:, 0]
+    assert was_on.numel() > n // 4
+    occs0, bin0 = grid.occs.clone(), grid.binary_u8().clone()
+    ex = {}
+    assert drv.occ_refresh(grid, 800, False, 0.01, 0.95, export=ex)
+    occs_nat, bin_nat = grid.occs.clone(), grid.binary_u8().clone()
+    cells, rand = ex["cells"].long(), ex["rand"]
+    assert cells.numel() == 2 * (n // 4)
+    occ = cells[n // 4:]
+    assert int(occ.min()) >= 0                                            # every slot used
+    assert bool(ball.reshape(-1)[occ].all())                              # drawn from the occupied cells
+    uniq = torch.unique(occ).numel()
+    # n/4 draws with replacement from K cells hit K (1 - exp(-n / 4K)) distinct ones
+    K = was_on.numel()
+    expect = K * (1.0 - np.exp(-(n // 4) / K))
+    assert abs(uniq - expect) < 0.02 * expect and uniq < occ.numel()
+    assert not bool((occ[1:] >= occ[:-1]).all())                          # not the ordered list
+    assert abs(float(occ.float().mean()) - float(was_on.float().mean())) < 0.01 * n   # uniform over them
+    grid.occs.copy_(occs0)
+    grid._binary_u8 = bin0.clone()
+    grid._binary = bin0.view(res, res, res).bool()
+    grid._update(800, m.occ_eval_fn, occ_thre=0.01, ema_decay=0.95, rand=rand, indices=cells)
+    occs_py, bin_py = grid.occs.clone(), grid.binary_u8().clone()
+    torch.testing.assert_close(occs_nat, occs_py, rtol=1e-5, atol=1e-6)
+    thre_py = float(torch.clamp(occs_py.mean(), max=0.01))
+    border = (occs_py - thre_py).abs() < 3e-6
+    assert torch.equal(bin_nat[~border], bin_py[~border])
+    # same call, same state: same draws (the subsample is keyed by (seed, step) too)
+    grid.occs.copy_(occs0)
+    grid._binary_u8 = bin0.clone()
+    grid._binary = bin0.view(res, res, res).bool()
+    ex2 = {}
+    assert drv.occ_refresh(grid, 800, False, 0.01, 0.95, export=ex2)
+    assert torch.equal(ex2["cells"], ex["cells"]) and torch.equal(grid.occs, occs_nat)
+
+
+# ------------------------------------------------------------------------------------------------
+# The library-sequenced step (what bench.py times) against the REFERENCE's own training_step and
+# loss.backward() directly: tests/golden/nsr_step_reference.npz / nsr_grad_reference.npz, made by the
+# imported reference modules (tests/golden/make_nsr_{step,grad}_golden.py).  The fixture's ray batch
+# goes in through dsu_nsr_step_args.inj_rays..., its random points through inj_pts_random /
+# inj_perturb; with zero learning rates the parameters stay put and the driver's first AdamW
+# moments are (1 - beta1) x the step's gradients (dsu_nsr_driver_adam_moments).
+# ------------------------------------------------------------------------------------------------
+def test_native_step_matches_reference_training_step_and_backward_fixture(dev):
+    import test_gpu_nsr_reference_step as R
+    GOLD, GRAD, L = R.GOLD, R.GRAD, R.L
+    sysm = OrthoNeuSSystem(device=dev, seed=0)
+    ref_model = R._model(dev)
+    sysm.model.load_state_dict(ref_model.state_dict())
+    m = sysm.model
+    m.occupancy_grid._binary = ref_model.occupancy_grid._binary
+    m.occupancy_grid._binary_u8 = None
+    m.occupancy_grid.every_n_step = lambda *a, **k: None      # the fixture's grid stays as given
+    m.geometry.hashgrid.invalidate()
+    m.randomized = False
+    m.config["randomized"] = False
+    sysm.dataset = OrthoData.synthetic_sphere(256, device=dev)  # resident tensors the driver binds; unread
+    sysm.step_mode = "native"
+    sysm.global_step = int(GOLD["step"])
+    sysm.train_num_rays = int(GOLD["rays"].shape[0])
+    sysm._base_lrs = [0.0 for _ in sysm._base_lrs]              # the step leaves the parameters alone
+    sysm.keep_table_grad = True
+    t = lambda k: torch.from_numpy(GOLD[k]).to(dev)
+    batch = {k: t("batch." + k) for k in ("rays", "rgb", "normal", "mask", "cosines", "view_weights")}
+    before = {n: p.detach().clone() for n, p in m.named_parameters()}
+    last = sysm.training_step_native({"batch": batch, "pts_random": t("pts_random"),
+                                      "perturb": t("perturb")})
+    # sample count and the loss terms of the reference's training_step
+    assert last["n_samples"] == int(GOLD["fwd.num_samples"][0])
+    want = {"rgb_mse": float(GOLD["loss.loss_rgb_mse"]) * L.lambda_rgb_mse,
+            "normal": float(GOLD["loss.loss_normal"]) * L.lambda_normal,
+            "mask": float(GOLD["loss.loss_mask"]) * L.lambda_mask,
+            "eikonal": float(GOLD["loss.loss_eikonal"]) * L.lambda_eikonal,
+            "sparsity": float(GOLD["loss.loss_sparsity"]) * L.lambda_sparsity,
+            "normal_smooth": float(GOLD["loss.loss_3d_normal_smooth"]) * L.lambda_3d_normal_smooth}
+    for k, w in want.items():
+        assert abs(float(last[k]) - w) <= 1e-4 * max(abs(w), 1e-6), (k, float(last[k]), w)
+    want_loss = float(GRAD["loss.total"])
+    assert abs(float(last["loss"]) - want_loss) < 2e-5 * abs(want_loss)
+    for n, p in m.named_parameters():                          # lr = 0: nothing moved
+        assert torch.equal(p.detach(), before[n]), n
+    # gradients of the 13 small tensors from the first moments
+    drv = sysm._native
+    beta1 = float(sysm.config.optimizer.betas[0])
+    base = int(_lib.lib().dsu_nsr_driver_adam_moments(drv.handle, 0)) - drv.workspace.data_ptr()
+    n_small = sum(p.numel() for p in drv.params)
+    mom = drv.workspace[base:base + 4 * n_small].view(torch.float32).clone() / (1.0 - beta1)
+    names = {id(p): n for n, p in m.named_parameters()}
+    rel = lambda got, w: float(np.linalg.norm((got - w).ravel()) / (np.linalg.norm(w.ravel()) + 1e-30))
+    off, seen = 0, 0
+    for p in drv.params:
+        name = names[id(p)]
+        got = mom[off:off + p.numel()].cpu().numpy().reshape(tuple(p.shape))
+        off += p.numel()
+        w = GRAD["grad." + name].reshape(got.shape)
+        assert rel(got, w) < 1e-3, (name, rel(got, w))
+        np.testing.assert_allclose(got, w, rtol=0, atol=2e-3 * np.abs(w).max())
+        seen += 1
+    assert seen == 13 and off == n_small
+    # the hash table's gradient (left in place: table_p = NULL skips the fused table update)
+    (tk,) = [k[len("gradnz_idx."):] for k in GRAD.files if k.startswith("gradnz_idx.")]
+    got = m.geometry.hashgrid.params.grad.detach().cpu().numpy().reshape(-1).astype(np.float64)
+    assert got.size == int(GRAD["gradnz_numel." + tk])
+    w = np.zeros_like(got)
+    w[GRAD["gradnz_idx." + tk]] = GRAD["gradnz_val." + tk]
+    assert rel(got, w) < 1e-2, rel(got, w)
+    big = float(np.abs(w).max())
+    assert abs(np.count_nonzero(got) - np.count_nonzero(w)) < 1e-3 * np.count_nonzero(w)
+    assert float(np.abs(got[w == 0]).max()) < 1e-5 * big

@@ -169,6 +169,78 @@ def test_x3_rejects_what_it_does_not_cover(dev):
         ops.conv2d_x3(x, ops.PackedConvWeight(_rand((8, 16, 4, 4), 2).to(dev)), None, 1, 1)
 
 
+# ------------------------------------------------------------------ exact-f32 packed-weight kernels
+# (style_conv_x3.hip, F32 = true: the evaluation path of GeneratorJ_RIC's deformable layers and of
+# IS-Net).  Exact f32 products and sums: the bar is the f32 kernels' (1e-4 on unit-scale outputs
+# against the f64 oracle), and the difference to style_conv.hip is summation order alone.
+@pytest.mark.parametrize("C,O,H,W", [(6, 32, 32, 32), (32, 64, 24, 40), (128, 128, 16, 16),
+                                     (166, 64, 20, 20), (5, 3, 9, 7), (256, 128, 40, 40),
+                                     (24, 40, 13, 130), (192, 128, 48, 48)])
+def test_deform_conv_f32p_vs_oracle(dev, C, O, H, W):
+    x = _rand((2, C, H, W), 1)
+    w = _rand((O, C, 3, 3), 2, 0.1)
+    off = _rand((1, 18, H, W), 3, 1.5)            # includes samples that leave the image
+    pk = ops.PackedConvWeight(w.to(dev), exact=True)
+    ref = sr.deform_conv2d(x, off.expand(2, -1, -1, -1), w)
+    got = ops.deform_conv3x3_x3(x.to(dev), off[0].to(dev), pk).cpu().double()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    off2 = _rand((2, 18, H, W), 4, 1.0)           # per-image offsets, ReLU on the input
+    ref2 = sr.deform_conv2d(F.relu(x), off2, w)
+    got2 = ops.deform_conv3x3_x3(x.to(dev), off2.to(dev), pk, in_relu=True).cpu().double()
+    torch.testing.assert_close(got2, ref2, rtol=1e-4, atol=1e-4)
+    # against the older exact-f32 kernel: same products, another summation order
+    f32 = ops.deform_conv3x3(x.to(dev), off2.to(dev), w.to(dev), in_relu=True).cpu().double()
+    assert float((got2 - f32).abs().max()) <= 4e-6 * float(f32.abs().max())
+
+
+def test_deform_conv_f32p_ric_epilogue(dev):
+    H = W = 64
+    x = _rand((1, 64, H, W), 7)
+    w = _rand((128, 64, 3, 3), 8, 0.05)
+    off = sr.generate_coordinates(H, W)
+    scale, shift = _rand((128,), 9).abs() + 0.5, _rand((128,), 10)
+    res = _rand((1, 128, H, W), 11)
+    ref = sr.deform_conv2d(x, off[None], w)
+    ref = F.relu(ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)) + res.double()
+    got = ops.deform_conv3x3_x3(x.to(dev), off.to(dev), ops.PackedConvWeight(w.to(dev), exact=True),
+                                scale.to(dev), shift.to(dev), "relu", res.to(dev)).cpu().double()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("k,s,p,C,O,H,W,bias,act", [
+    (3, 2, 1, 3, 64, 40, 40, True, None),
+    (3, 2, 1, 64, 128, 21, 19, False, "relu"),
+    (3, 1, 1, 128, 128, 16, 16, False, None),
+    (3, 1, 1, 192, 128, 24, 24, False, "relu"),
+    (3, 1, 1, 200, 72, 50, 50, False, "relu"),
+    (1, 1, 0, 64, 3, 32, 32, True, "tanh"),
+    (1, 1, 0, 40, 200, 70, 70, True, None),
+])
+def test_conv2d_f32p_vs_oracle(dev, k, s, p, C, O, H, W, bias, act):
+    x = _rand((2, C, H, W), 1)
+    w = _rand((O, C, k, k), 2, 1.0 / np.sqrt(C * k * k))
+    b = _rand((O,), 3) if bias else None
+    g, beta = _rand((O,), 4).abs() + 0.5, _rand((O,), 5)
+    mean, var = _rand((O,), 6, 0.1), _rand((O,), 7).abs() + 0.5
+    ref = sr.conv_bn_act(x, w, b, s, p, (g, beta, mean, var, 1e-5), act)
+    scale = g / torch.sqrt(var + 1e-5)
+    shift = beta - mean * scale
+    got = ops.conv2d_x3(x.to(dev), ops.PackedConvWeight(w.to(dev), exact=True),
+                        None if b is None else b.to(dev), s, p, scale.to(dev), shift.to(dev),
+                        act).cpu().double()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=1e-4)
+    old = ops.conv2d(x.to(dev), w.to(dev), None if b is None else b.to(dev), s, p, scale.to(dev),
+                     shift.to(dev), act).cpu().double()
+    assert float((got - old).abs().max()) <= 4e-6 * max(float(old.abs().max()), 1.0)
+
+
+def test_f32p_rejects_what_it_does_not_cover(dev):
+    from drawingspinup_amd._lib import DsuError
+    x = _rand((1, 16, 12, 12), 1).to(dev)
+    with pytest.raises(DsuError):          # 7x7: a kernel row of f32 weights does not fit the LDS group
+        ops.conv2d_x3(x, ops.PackedConvWeight(_rand((8, 16, 7, 7), 2).to(dev), exact=True), None, 1, 3)
+
+
 # ------------------------------------------------------------------ whole generators vs golden
 import os  # noqa: E402
 
@@ -183,8 +255,25 @@ def _to_image_space(x):     # training/custom_transforms.py:8-9
     return ((np.clip(x, -1, 1) + 1) / 2 * 255).astype(np.uint8)
 
 
+def _set_arithmetic(monkeypatch, mode):
+    """default: what ships (plain convolutions bf16 x 3 = finer than the reference's cuDNN TF32,
+    deformable convolutions exact f32 = the reference's addmm); the other two force one arithmetic
+    on every layer."""
+    if mode != "default":
+        monkeypatch.setattr(G, "EVAL_X3", mode == "x3")
+        monkeypatch.setattr(G, "EVAL_DEFORM_X3", mode == "x3")
+
+
+def test_default_arithmetic_is_the_references():
+    assert G.EVAL_DEFORM_X3 is False        # deform_conv2d: f32 addmm in the reference
+    from drawingspinup_amd.mv import matting
+    assert matting.EVAL_X3 is False         # IS-Net: f32 ONNX session in the reference
+
+
+@pytest.mark.parametrize("mode", ["default", "exact", "x3"])
 @pytest.mark.parametrize("name", ["GeneratorJ", "GeneratorJ_RIC"])
-def test_generator_matches_reference_fixture(dev, name):
+def test_generator_matches_reference_fixture(dev, name, mode, monkeypatch):
+    _set_arithmetic(monkeypatch, mode)
     net = G.build_model(name, ARGS)
     sd = {k.split(".sd.")[1]: torch.from_numpy(GOLD[k]) for k in GOLD.files
           if k.startswith(name + ".sd.")}
@@ -215,13 +304,15 @@ def test_generator_full_size_runs(dev, name):
     assert float(y1.abs().max()) <= 1.0 and torch.equal(y1, y2)
 
 
+@pytest.mark.parametrize("mode", ["default", "exact", "x3"])
 @pytest.mark.parametrize("name", ["GeneratorJ", "GeneratorJ_RIC"])
-def test_generator_shipped_config_512_matches_reference_fixture(dev, name):
+def test_generator_shipped_config_512_matches_reference_fixture(dev, name, mode, monkeypatch):
     """BASELINE size: the reference's own class at the shipped widths on one 512x512 frame
     (tests/golden/make_style_fullsize_golden.py; weights and input rebuilt from the stored seeds).
     Same bar as the reduced fixture: 2e-4 absolute on the float output (stride-3 lattice stored),
     <= 1/255 on >= 99.9 % of the full-resolution uint8 image."""
     from oracle import style_ref
+    _set_arithmetic(monkeypatch, mode)
     FULL_ARGS, frame = style_ref.FULLSIZE_ARGS, style_ref.fullsize_frame
     gold = np.load(os.path.join(os.path.dirname(__file__), "golden", "style_fullsize_reference.npz"))
     seed, stride = int(gold[name + ".seed"]), int(gold["stride"])

@@ -74,11 +74,11 @@ def test_isnet_session_contract_on_cpu():
 def test_dilated_convolution_as_sublattice_convolutions(monkeypatch):
     """The decomposition _rebnconv_hip uses (d x d ordinary convolutions on x[i::d, j::d]) against
     torch's dilated convolution, with the library call replaced by its torch meaning."""
-    def conv2d(x, w, bias, stride, padding, scale, shift, act):
-        y = F.conv2d(x, w, bias, stride, padding) * scale[None, :, None, None] + shift[None, :, None, None]
+    def conv(x, conv, bias, stride, padding, scale, shift, act):
+        y = F.conv2d(x, conv.weight, bias, stride, padding) * scale[None, :, None, None] \
+            + shift[None, :, None, None]
         return F.relu(y) if act == "relu" else y
-    monkeypatch.setattr(matting.ops, "conv2d", conv2d)
-    monkeypatch.setattr(matting, "EVAL_X3", False)
+    monkeypatch.setattr(matting, "_conv", conv)
     torch.manual_seed(1)
     for d, hw in ((2, (16, 16)), (4, (32, 32)), (8, (32, 32)), (2, (13, 18)), (4, (9, 7))):
         m = matting.REBNCONV(5, 7, dirate=d).eval()

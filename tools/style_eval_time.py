@@ -1,5 +1,7 @@
-"""Time the two shipped generators in eval mode at the bench's shape (4 frames of 512x512),
-exact-f32 kernels vs the bf16 x 3 kernels, and report the largest output difference.
+"""Time the two shipped generators in eval mode at the bench's shape (4 frames of 512x512):
+the older exact-f32 kernels (style_conv.hip, im2col through LDS), the packed-weight exact-f32
+kernels (style_conv_x3.hip, F32) and the bf16 x 3 kernels, and report the largest output difference
+to the older exact-f32 result.
 
     python tools/style_eval_time.py [batch] [reps]
 """
@@ -25,8 +27,23 @@ def main():
         net = net.to(dev).eval()
         x = torch.cat([style_ref.fullsize_frame(11 + i) for i in range(batch)]).to(dev)
         out = {}
-        for x3 in (False, True):
-            G.EVAL_X3 = x3
+        packed_ok = G._packed_ok
+        for mode in ("f32_lds", "f32_packed", "x3"):
+            G.EVAL_X3 = G.EVAL_DEFORM_X3 = mode == "x3"
+            # f32_lds: route every layer to style_conv.hip (the kernels before round 6)
+            G._packed_ok = (lambda conv, exact: False) if mode == "f32_lds" else packed_ok
+            if mode == "f32_lds":
+                dc = G.ops.deform_conv3x3_x3
+                G.ops.deform_conv3x3_x3 = lambda x, off, pk, *a, _w={}: G.ops.deform_conv3x3(
+                    x[:, :pk.C].contiguous(), off, pk._src, *a)
+                PW = G.ops.PackedConvWeight
+
+                class _Raw:                      # carries the OIHW weight instead of a packed one
+                    def __init__(self, w, exact=False):
+                        self._src, self.C = w, w.shape[1]
+                G.ops.PackedConvWeight = _Raw
+            for m in net.modules():
+                m.__dict__.pop("_dsu_pack", None)
             with torch.no_grad():
                 y = net(x)
                 torch.cuda.synchronize()
@@ -34,11 +51,16 @@ def main():
                 for _ in range(reps):
                     y = net(x)
                 torch.cuda.synchronize()
-            out[x3] = (y, (time.perf_counter() - t0) / reps)
-        d = (out[True][0] - out[False][0]).abs()
-        print("%-15s f32 %.2f ms   bf16x3 %.2f ms   (x%.2f)   max|dy| %.2e  mean %.2e" % (
-            name, out[False][1] * 1e3, out[True][1] * 1e3, out[False][1] / out[True][1],
-            float(d.max()), float(d.mean())))
+            out[mode] = (y, (time.perf_counter() - t0) / reps)
+            if mode == "f32_lds":
+                G.ops.deform_conv3x3_x3, G.ops.PackedConvWeight = dc, PW
+        G._packed_ok = packed_ok
+        ref = out["f32_lds"][0]
+        print("%-15s f32 (LDS im2col) %.2f ms   f32 (packed) %.2f ms   bf16x3 %.2f ms   "
+              "max|dy| packed %.2e  x3 %.2e" % (
+                  name, out["f32_lds"][1] * 1e3, out["f32_packed"][1] * 1e3, out["x3"][1] * 1e3,
+                  float((out["f32_packed"][0] - ref).abs().max()),
+                  float((out["x3"][0] - ref).abs().max())))
 
 
 if __name__ == "__main__":
