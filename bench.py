@@ -505,10 +505,10 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
                                "back-projection + shear: the reference YAML's export switches for a uid "
                                "outside the thinning list) -> %d-frame stage1+stage2 stylisation (stage 2 "
                                "on the edge-overlaid stage-1 output); NOT timed: Blender, PNG / OBJ file "
-                               "I/O.  Image resampling between the stages is torch bicubic on the device "
-                               "here (the entry scripts mv.py / recon.py use the Pillow LANCZOS / "
-                               "bicubic routes pinned by tests/test_mv_preprocess.py; no effect on the "
-                               "timing)" % (args.mv_steps, args.nsr_steps, args.frames),
+                               "I/O.  Image resampling between the stages (512 -> 256 RGBA bicubic, 256 -> 1024 "
+                               "and 1024 -> 2048 LANCZOS) is Pillow's arithmetic restated on the device, "
+                               "bit for bit (tests/test_mv_preprocess.py), on the 8-bit images the "
+                               "reference's PNG hand-offs hold" % (args.mv_steps, args.nsr_steps, args.frames),
                    "drawings_per_step": world, "parallelism": f"replica-per-drawing x{world}",
                    # arithmetic per stage next to the reference's own (file:line in DESIGN.md 4)
                    "stage_dtype": {

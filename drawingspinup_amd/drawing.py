@@ -16,6 +16,7 @@ import torch.nn.functional as F
 
 from .entry.data import fill_holes
 from .mv.pipeline import build_random_pipeline
+from .mv.preprocess import pil_resize_rgba_u8, pil_resize_u8
 from .nsr.system import OrthoData, OrthoNeuSSystem, VIEWS, inv_rt, rt_opengl2opencv, ideal_w2c
 from .style.generators import build_model
 
@@ -68,6 +69,12 @@ def synthetic_edges(frames):
 def to_image_space(x):
     """custom_transforms.py:8-9 on the device: clip -> uint8."""
     return ((x.clamp(-1, 1) + 1) / 2 * 255).to(torch.uint8)
+
+
+def _u8_hwc(t):
+    """tensor2pil (mv.py:46-48) on the device: (C,H,W) float in [0,1] -> (H,W,C) uint8 with
+    mul 255, add 0.5, clamp — what the reference's PNG hand-offs hold."""
+    return (t.float() * 255 + 0.5).clamp(0, 255).to(torch.uint8).permute(1, 2, 0).contiguous()
 
 
 class DrawingPipeline:
@@ -157,9 +164,12 @@ class DrawingPipeline:
     def multiview(self, drawing_rgba, seed):
         """SingleImageDataset (white-background 256x256 x6 views) -> 12-sample batch ->
         pipeline (mv.py:70-86).  Returns normals (6,3,256,256), colours (6,3,256,256) in [0,1]."""
-        rgb, a = drawing_rgba[:3], drawing_rgba[3:4]
-        img = F.interpolate((rgb * a + (1 - a))[None], size=(256, 256), mode="bicubic",
-                            align_corners=False).clamp(0, 1)
+        # single_image_dataset.py:97-130 as entry/data.py load_image_rgba restates it: the RGBA image
+        # through Pillow's default (bicubic, premultiplied-alpha) resize to 256^2 — the resampler of
+        # mv/preprocess.py, bit for bit Pillow's (tests/test_mv_preprocess.py) — then composited on
+        # white in f32
+        small = pil_resize_rgba_u8(_u8_hwc(drawing_rgba), (256, 256), "bicubic").float() / 255.0
+        img = (small[..., :3] * small[..., 3:4] + (1.0 - small[..., 3:4])).permute(2, 0, 1)[None]
         imgs_in = img.expand(12, -1, -1, -1).contiguous()
         g = torch.Generator(device=self.device).manual_seed(seed)
         out = self.mv(imgs_in, generator=g, guidance_scale=1.0, output_type="pt", eta=1.0,
@@ -173,10 +183,12 @@ class DrawingPipeline:
         optimisation and the export (2 x 512^3 SDF volumes -> smoothing -> marching cubes)."""
         dev = self.device
         size = 1024
-        up = lambda t: F.interpolate(t.float(), size=(size, size), mode="bicubic",
-                                     align_corners=False).clamp(0, 1)
-        col = up(colors).permute(0, 2, 3, 1)
-        nrm = up(normals).permute(0, 2, 3, 1) * 2 - 1                      # img2normal
+        # mv.py:105-106: tensor2pil(view).resize((1024, 1024), Image.LANCZOS), saved as PNG and read
+        # back as k / 255 (ortho.py:54-97) — the same 8-bit images, held in memory
+        up8 = lambda t: torch.stack([pil_resize_u8(_u8_hwc(v), (size, size), "lanczos") for v in t])
+        col8, nrm8 = up8(colors), up8(normals)                             # (6,1024,1024,3) uint8
+        col = col8.float() / 255.0
+        nrm = nrm8.float() / 255.0 * 2 - 1                                 # img2normal
         alpha = F.interpolate(drawing_rgba[3:4][None], size=(size, size), mode="nearest")[0, 0]
         # front: the drawing's alpha, back: mirrored (mv.py:113-116); side views: matte of the
         # predicted colour image (distance to the white background, entry/data.py
@@ -191,8 +203,7 @@ class DrawingPipeline:
             # through as one batch (the reference calls the session once per view; the network is
             # per-image in eval mode, and the convolutions fill the chip better at B = 4)
             with torch.no_grad():
-                # 8-bit quantisation as tensor2pil does (mv.py:46-48: mul 255, add 0.5, clamp)
-                u8 = (col[[1, 2, 4, 5]].permute(0, 3, 1, 2) * 255 + 0.5).clamp(0, 255).to(torch.uint8)
+                u8 = col8[[1, 2, 4, 5]].permute(0, 3, 1, 2)                # the LANCZOS 1024^2 images themselves
                 mattes = (self.isnet(u8.float() / 255.0 - 0.5).clamp(0, 1) * 255).to(torch.uint8)[:, 0]
             self.last_side_mattes = mattes
         if self.time_substages:
@@ -220,7 +231,8 @@ class DrawingPipeline:
         t1 = time.time()
         # export (neus_ortho.py:183-200): smoothed binary volumes, front-mask cutting with the
         # drawing's own alpha (char/mask.png, rotated as ortho.py:155-156), marching cubes, colours
-        front = (F.interpolate(drawing_rgba[3:4][None], size=(size, size), mode="nearest")[0, 0] * 255).to(torch.uint8)
+        front = (F.interpolate(drawing_rgba[3:4][None], size=(size, size), mode="nearest")[0, 0] * 255
+                 + 0.5).to(torch.uint8)                                 # mask_front.resize(res, NEAREST)
         # the switches of configs/neuralangelo-ortho-wmask.yaml:12-20,45-46 as recon.py runs a uid
         # that is not in the thinning list: remeshing to 50 000 faces inside the fine stage
         # (geometry.py:63-64), no texture-network colours when colour back-projection is on
@@ -236,11 +248,11 @@ class DrawingPipeline:
             # predicted front / back views (2048^2, coloring_utils.py:62,100), shear, ortho scale;
             # the OBJ text write itself stays outside (file I/O)
             from .nsr.mesh import post_process_mesh
-            big = lambda t: (F.interpolate(t[None].float(), size=(2048, 2048), mode="bicubic",
-                                           align_corners=False)[0].clamp(0, 1) * 255).to(torch.uint8)
-            cbp = {"color_front": big(colors[0]).permute(1, 2, 0).contiguous(),
-                   "color_back": big(colors[3]).permute(1, 2, 0).contiguous(),
-                   "mask_front": big(drawing_rgba[3:4])[0].contiguous()}
+            # coloring_utils.py:62,100: the 1024^2 PNGs (colour views; the NEAREST-resized front mask)
+            # through Image.resize((2048, 2048), LANCZOS)
+            big = lambda u8: pil_resize_u8(u8, (2048, 2048), "lanczos")
+            cbp = {"color_front": big(col8[0]), "color_back": big(col8[3]),
+                   "mask_front": big(front[:, :, None])[:, :, 0].contiguous()}
             v, f, c = post_process_mesh(mesh["verts"], mesh["faces"], None, ortho_scale=1.35,
                                         smoothing=True, shearing=True, color_back_projection=cbp)
             self.last_mesh_post = {"verts": v, "faces": f, "colors": c}

@@ -31,8 +31,26 @@ def _bicubic(x, a=-0.5):
     return 0.0
 
 
-def _coeff_matrix(in_size, out_size, support=2.0):
+def _sinc(x):
+    if x == 0.0:
+        return 1.0
+    x = x * math.pi
+    return math.sin(x) / x
+
+
+def _lanczos(x):
+    """Resample.c lanczos_filter: truncated sinc, support 3."""
+    if -3.0 <= x < 3.0:
+        return _sinc(x) * _sinc(x / 3)
+    return 0.0
+
+
+_FILTERS = {"bicubic": (_bicubic, 2.0), "lanczos": (_lanczos, 3.0)}
+
+
+def _coeff_matrix(in_size, out_size, filt="bicubic"):
     """(out_size, in_size) int64 matrix of Pillow's normalised 22-bit coefficients."""
+    _bicubic, support = _FILTERS[filt]          # (shadows the module-level name on purpose)
     scale = in_size / out_size
     filterscale = max(scale, 1.0)
     sup = support * filterscale
@@ -55,10 +73,10 @@ def _coeff_matrix(in_size, out_size, support=2.0):
 _COEFF_CACHE = {}
 
 
-def _coeffs(in_size, out_size, device):
-    key = (in_size, out_size, str(device))
+def _coeffs(in_size, out_size, device, filt="bicubic"):
+    key = (in_size, out_size, str(device), filt)
     if key not in _COEFF_CACHE:
-        _COEFF_CACHE[key] = torch.from_numpy(_coeff_matrix(in_size, out_size)).to(device)
+        _COEFF_CACHE[key] = torch.from_numpy(_coeff_matrix(in_size, out_size, filt)).to(device)
     return _COEFF_CACHE[key]
 
 
@@ -69,17 +87,45 @@ def _pass(img, m):
     return (acc >> PRECISION_BITS).clamp_(0, 255).to(torch.uint8)
 
 
-def pil_resize_bicubic_u8(img, out_hw):
-    """img (H, W, C) uint8 tensor -> (out_h, out_w, C) uint8, = PIL.Image.resize((w, h), BICUBIC)."""
+def pil_resize_u8(img, out_hw, filt="bicubic"):
+    """img (H, W, C) uint8 tensor (host or device) -> (out_h, out_w, C) uint8, = PIL.Image.resize((w,
+    h), BICUBIC | LANCZOS) of an "RGB" / "L" image, bit for bit (tests/test_mv_preprocess.py)."""
     assert img.dtype == torch.uint8 and img.dim() == 3
     H, W, _ = img.shape
     oh, ow = out_hw
     x = img
     if ow != W:                                                       # horizontal pass first
-        x = _pass(x.permute(0, 1, 2), _coeffs(W, ow, img.device))
+        x = _pass(x.permute(0, 1, 2), _coeffs(W, ow, img.device, filt))
     if oh != H:
-        x = _pass(x.permute(1, 0, 2), _coeffs(H, oh, img.device)).permute(1, 0, 2)
+        x = _pass(x.permute(1, 0, 2), _coeffs(H, oh, img.device, filt)).permute(1, 0, 2)
     return x.contiguous()
+
+
+def pil_resize_bicubic_u8(img, out_hw):
+    return pil_resize_u8(img, out_hw, "bicubic")
+
+
+def _muldiv255(a, b):
+    """ImagingUtils.h MULDIV255 on int32 tensors: (a b + 128 + ((a b + 128) >> 8)) >> 8."""
+    t = a * b + 128
+    return (t + (t >> 8)) >> 8
+
+
+def pil_resize_rgba_u8(img, out_hw, filt="bicubic"):
+    """PIL.Image.resize of an "RGBA" image (Image.py: for RGBA / LA and any filter but NEAREST the
+    image is converted to premultiplied "RGBa", resampled, and converted back):
+    Convert.c rgbA2rgba = MULDIV255(c, a) per colour channel; the four channels through the
+    resampler; rgba2rgbA = CLIP8(255 c / a) (integer division), colour untouched where a is 0.
+    img (H, W, 4) uint8 -> (out_h, out_w, 4) uint8."""
+    assert img.dtype == torch.uint8 and img.dim() == 3 and img.shape[2] == 4
+    x = img.to(torch.int32)
+    a = x[..., 3:4]
+    pre = torch.cat([_muldiv255(x[..., :3], a), a], -1).to(torch.uint8)
+    r = pil_resize_u8(pre, out_hw, filt).to(torch.int32)
+    ra = r[..., 3:4]
+    col = torch.where(ra > 0, torch.div(255 * r[..., :3], ra.clamp(min=1), rounding_mode="floor")
+                      .clamp(max=255), r[..., :3])
+    return torch.cat([col, ra], -1).to(torch.uint8)
 
 
 def to_pil_u8(images):
@@ -106,4 +152,4 @@ def vae_input(img_u8, dtype):
     return x * 2.0 - 1.0
 
 
-__all__ = ["pil_resize_bicubic_u8", "to_pil_u8", "clip_pixel_values", "vae_input", "math"]
+__all__ = ["pil_resize_u8", "pil_resize_rgba_u8", "pil_resize_bicubic_u8", "to_pil_u8", "clip_pixel_values", "vae_input", "math"]

@@ -5,6 +5,8 @@ with injected initial latents and per-step noise.  SURVEY.md 8(d): "after 75 ste
 noise: report, expect <= 2e-2".
 
     python tests/golden/make_ddim75_golden.py        # CPU only, no /root/reference needed; ~1-2 h
+    python tests/golden/make_ddim75_golden.py 3 32   # first 3 steps at 32x32 latents (BASELINE
+                                                     # configs[1]'s size) -> ddim3_lat32_reference.npz
 
 The weights are not stored: they come from the seeded recipe `_init(UNetMV2DConditionModel(**FULL),
 11).half()` of tests/test_gpu_unet.py, which the test repeats on the GPU box (CPU generator =
@@ -31,6 +33,7 @@ if __name__ == "__main__":
     from drawingspinup_amd.mv.unet import UNetMV2DConditionModel
     from drawingspinup_amd.mv.pipeline import DEFAULT_CAMERA_EMBEDDING, MVDiffusionImagePipeline
     steps = int(sys.argv[1]) if len(sys.argv) > 1 else 75
+    S = int(sys.argv[2]) if len(sys.argv) > 2 else 16           # latent height = width
     torch.manual_seed(0)
     model = T._init(UNetMV2DConditionModel(**T.FULL), 11).half()
     sd = {k: v.clone() for k, v in model.state_dict().items()}
@@ -38,9 +41,9 @@ if __name__ == "__main__":
     g = torch.Generator().manual_seed(31)
     B = 12
     emb = (torch.randn(B, 1, 768, generator=g) * 0.5).half()
-    img_lat = torch.randn(B, 4, 16, 16, generator=g).half()
-    lat0 = torch.randn(B, 4, 16, 16, generator=g).half()
-    noise = torch.randn(75, B, 4, 16, 16, generator=g).half()
+    img_lat = torch.randn(B, 4, S, S, generator=g).half()
+    lat0 = torch.randn(B, 4, S, S, generator=g).half()
+    noise = torch.randn(75, B, 4, S, S, generator=g).half()
     cam = MVDiffusionImagePipeline.prepare_camera_embedding(None, DEFAULT_CAMERA_EMBEDDING) \
         if False else None
     pipe = MVDiffusionImagePipeline(model, None, None)
@@ -63,6 +66,8 @@ if __name__ == "__main__":
     for k in KEEP:
         if k <= steps:
             out["lat_%d" % k] = lats[k - 1].float().numpy()
-    np.savez_compressed(os.path.join(HERE, "ddim75_reference.npz" if steps == 75
-                                     else "ddim%d_probe.npz" % steps), **out)
+    name = "ddim75_reference.npz" if (steps, S) == (75, 16) else \
+        ("ddim%d_lat%d_reference.npz" % (steps, S) if S != 16 else "ddim%d_probe.npz" % steps)
+    out["latent_size"] = np.int64(S)
+    np.savez_compressed(os.path.join(HERE, name), **out)
     print("wrote", list(out))

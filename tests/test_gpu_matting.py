@@ -33,6 +33,30 @@ def test_isnet_forward_on_the_hip_convolution_matches_torch_cpu(dev, x3, monkeyp
     torch.testing.assert_close(got, ref, rtol=0, atol=2e-4)
 
 
+def test_isnet_forward_batch_of_four_at_1024_matches_torch_cpu(dev, monkeypatch):
+    """The shape the drawing pipeline runs (drawing.py: the four 1024^2 side views as one batch),
+    both arithmetics, against torch on the host CPU."""
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(32, threads))          # torch's CPU convolutions crawl at 256 threads
+    try:
+        net = matting.load_isnet(None, "cpu", seed=8)
+        _randomise_bn(net, 9)
+        x = torch.rand(4, 3, 1024, 1024, generator=torch.Generator().manual_seed(10)) - 0.5
+        with torch.no_grad():
+            ref = net(x)
+    finally:
+        torch.set_num_threads(threads)
+    assert ref.shape == (4, 1, 1024, 1024) and float(ref.std()) > 1e-4
+    net = net.to(dev)
+    for x3 in (False, True):
+        monkeypatch.setattr(matting, "EVAL_X3", x3)
+        with torch.no_grad():
+            got = net(x.to(dev)).cpu()
+            one = net(x[2:3].to(dev)).cpu()          # the per-image call of the reference's session
+        torch.testing.assert_close(got, ref, rtol=0, atol=2e-4)
+        torch.testing.assert_close(got[2:3], one, rtol=0, atol=2e-6)     # batch-independent
+
+
 def test_remove_background_through_the_device_session(dev):
     net = matting.load_isnet(None, dev, seed=6)
     sess = matting.IsnetSession(net, dev)

@@ -60,6 +60,20 @@ def test_isnet_parameter_names_and_shapes_follow_the_dis_checkpoint():
     assert 43e6 < n < 45e6                                                  # IS-Net: ~44 M parameters
 
 
+def test_isnet_full_key_and_shape_list():
+    """The whole state_dict against the committed list (tests/golden/isnet_dis_state_dict_keys.json:
+    generated from this restatement — the DIS checkpoint itself is not available here; the list is
+    what tools/isnet_keys_check.py diffs against a real isnet-general-use.pth)."""
+    import json
+    import os
+    want = json.load(open(os.path.join(os.path.dirname(__file__), "golden",
+                                       "isnet_dis_state_dict_keys.json")))["entries"]
+    sd = matting.ISNetDIS().state_dict()
+    assert {k: list(v.shape) for k, v in sd.items()} == want
+    convs = [k for k in want if k.endswith("conv_s1.weight")]
+    assert len(convs) == 112 and len(want) > 700     # 112 REBNCONV blocks (tools/matting_time.py)
+
+
 def test_isnet_session_contract_on_cpu():
     torch.manual_seed(0)
     net = matting.load_isnet(None, "cpu")
