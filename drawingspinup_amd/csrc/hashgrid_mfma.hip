@@ -22,6 +22,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 using namespace dsu_hg;
 
 // Timing ablations (DSU_BWD_ABLATE=<bits>, tools/sdf_bwd_ablation.py) switch phases of the backward
@@ -1110,6 +1112,591 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
     part[v] = (red[v] + red[PART_STRIDE + v]) + (red[2 * PART_STRIDE + v] + red[3 * PART_STRIDE + v]);
 }
 
+// ------------------------------------------------------------ K1, lean / software-pipelined form
+// The MLP part of the split backward again, for the case the optimisation runs (NL = 10 levels,
+// features from the forward's cache, ACT active levels known at compile time), restructured around
+// what the counters of the general kernel above say (profiles/round5_pmc.json): ONE wave per SIMD
+// whose instruction stream alternates VALU phases (48 % of the wave cycles: Softplus, sigmoid, bf16
+// splits, register shuffles — 22 % of the VALU instructions were v_accvgpr moves of values parked
+// in AGPRs) and MFMA phases during which the wave only waits to issue the next MFMA (27 %).
+//   * The six OFFSET evaluations (e = 1..6) carry one upstream gradient (on the SDF output) instead
+//     of the centre's 13: their own straight-line body without the 13-wide output arrays, the
+//     feature-gradient rows, the dOut staging and the gW1 GEMM; the centre evaluation keeps a body
+//     of its own.  The live state of the loop that does 6/7 of the work shrinks by ~50 registers.
+//   * ACT is a template parameter: layer 0 walks ACT + 2 k-pairs without a branch per level (every
+//     MFMA sat in its own basic block), the cache rows are ACT wide.
+//   * Inside an offset evaluation the two point halves are software-pipelined: the matrix pipe's
+//     long phases run beside the OTHER half's VALU work —
+//         L0(half 1) MFMAs            ||  Softplus(half 0)
+//         gW0(half 0) MFMAs (32 x 64) ||  Softplus, dPre, sigmoid, bf16 split of half 1
+//         gW0(half 1) MFMAs           ||  dIn stores, column-0 sums of gW1
+//     The interleave is written out in the source — a piece of VALU work behind every MFMA (pair),
+//     fenced with __builtin_amdgcn_sched_barrier(0): left to itself the scheduler issues a phase's
+//     MFMAs back to back and the VALU work after them (sched_group_barrier patterns did not change
+//     that here), which at one wave per SIMD is the serial form again.  The next evaluation's
+//     inputs (cache row hand-over, positions, upstream gradient) are prepared beside the last phase.
+// Every value is produced by the same operations in the same order as in sdf_fd_bwd_mfma_kernel
+// <NL, true, true>, the tail sharing included.  tests/test_gpu_hashgrid.py compares it with the general
+// kernel's cache-less form (no tail sharing there): MLP gradients bit-identical where the ranges are
+// whole iterations, equal to float summation order elsewhere.
+template <int NL, int ACT>
+__global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
+    dsu_sdf_mlp mlp, const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
+    const float* __restrict__ d_sdf, const float* __restrict__ d_grad,
+    const float* __restrict__ d_feature, const float* __restrict__ d_laplace,
+    float* __restrict__ partials, const __half2* __restrict__ enc, float2* __restrict__ dinbuf,
+    const int32_t* __restrict__ perm) {
+  static_assert(ACT >= 1 && ACT <= NL && 2 * NL + 4 <= 32, "layout");
+  constexpr int KPA = ACT + 2;             // k-pairs walked by layer 0: ACT levels, xyz, (z, 1)
+  constexpr int FG = (2 * ACT + 3) / 4;    // float4 groups of feature columns staged per point
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* w1perm = lds;
+  float* b1s = lds + 2 * NOUT * 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l31 = lane & 31, h = lane >> 5;
+  float* sd = lds + W1P_F + wave * STAGE_F;
+  float* sin_ = sd + 32 * SD_ROW;
+  float* sdo = sin_ + 32 * SIN_ROW;
+
+  // the scatter kernel's work counter (behind the dIn buffer) starts every launch at zero
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    *reinterpret_cast<int*>(dinbuf + (size_t)7 * (size_t)n * NL) = 0;
+
+  // ---- weights.  k-pair tt of layer 0 is the permuted input pair t = tt (level tt) or NL + tt - ACT
+  float w0a[2][KPA];
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int tt = 0; tt < KPA; ++tt) {
+      const int t = tt < ACT ? tt : NL + (tt - ACT);
+      w0a[T][tt] = w0p<NL>(mlp, 32 * T + l31, 2 * t + h);
+    }
+  float w1o0[2][16];
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) w1o0[T][r] = mlp.w1[feat_of(T, r, h)];
+  bf16x8 w0t_hi[2][2], w0t_mid[2][2];
+  {
+    float w0t[2][16];
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        w0t[T][r] = l31 < MC<NL>::KIN ? w0p<NL>(mlp, feat_of(T, r, h), l31) : 0.0f;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) bf16_split8(&w0t[T][8 * g], w0t_hi[T][g], w0t_mid[T][g]);
+  }
+  load_w1perm(w1perm, b1s, mlp);
+  // In' and dOut rows: the columns nobody writes (masked levels, padding) stay zero for the launch
+  for (int t = lane; t < 2 * 32 * SIN_ROW; t += 64) sin_[t] = 0.0f;
+  __syncthreads();
+
+  f32x16 gw0[2], gw1[2];
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gw0[T][r] = gw1[T][r] = 0.0f;
+  float gb1[NOUT];
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) gb1[o] = 0.0f;
+  float gw1c0[2][16];
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) gw1c0[T][r] = 0.0f;
+
+  // ---- pieces shared by the two evaluation bodies
+  // B operands of layer 0 for both point halves from the lane's own inputs
+  auto l0_half = [&](const float (&b)[KPA], f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[T][r] = 0.0f;
+#pragma unroll
+      for (int tt = 0; tt < KPA; ++tt)
+        acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0a[T][tt], b[tt], acc[T], 0, 0, 0);
+    }
+  };
+  auto softplus2 = [&](f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[T][r] = softplus100(acc[T][r]);
+  };
+  // dPre -> sigmoid factor -> dIn MFMAs of one hidden tile (bf16 x 3, as in the general kernel)
+  auto din_tile = [&](int T, float (&dpre)[16], const f32x16& H, f32x16& din) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      dpre[r] *= 1.0f - __builtin_amdgcn_exp2f(H[r] * -144.26950408889634f);
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+      bf16x8 bh, bm;
+      bf16_split8(&dpre[8 * g], bh, bm);
+      din = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_hi[T][g], bh, din, 0, 0, 0);
+      din = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_hi[T][g], bm, din, 0, 0, 0);
+      din = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_mid[T][g], bh, din, 0, 0, 0);
+    }
+  };
+  auto stage_rows = [&](float* dst, int T, const float* v /*16*/) {   // [point][hidden] rows
+#pragma unroll
+    for (int qd = 0; qd < 4; ++qd)
+      *reinterpret_cast<float4*>(&dst[l31 * SD_ROW + 32 * T + 8 * qd + 4 * h]) =
+          make_float4(v[4 * qd], v[4 * qd + 1], v[4 * qd + 2], v[4 * qd + 3]);
+  };
+  auto stage_in = [&](const float (&in)[2 * KPA]) {                   // own-half lanes: In' row
+#pragma unroll
+    for (int g = 0; g < FG; ++g) {
+      float4 v;
+      v.x = in[4 * g];
+      v.y = in[4 * g + 1];
+      v.z = 4 * g + 2 < 2 * ACT ? in[(4 * g + 2) < 2 * ACT ? 4 * g + 2 : 0] : 0.0f;
+      v.w = 4 * g + 3 < 2 * ACT ? in[(4 * g + 3) < 2 * ACT ? 4 * g + 3 : 0] : 0.0f;
+      *reinterpret_cast<float4*>(&sin_[l31 * SIN_ROW + 4 * g]) = v;
+    }
+    *reinterpret_cast<float4*>(&sin_[l31 * SIN_ROW + 2 * NL]) =
+        make_float4(in[2 * ACT], in[2 * ACT + 1], in[2 * ACT + 2], in[2 * ACT + 3]);
+  };
+  // contraction over the 32 staged points: acc[T][feat][col] += rowsA[point][feat] * rowsB[point][col]
+  auto gemm_points = [&](f32x16 (&acc)[2], const float* rowsB) {
+    float q[2][12];
+    auto ld = [&](int tb, float* d) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pr = 2 * (4 * tb + u) + h;
+        d[3 * u + 0] = sd[pr * SD_ROW + l31];
+        d[3 * u + 1] = sd[pr * SD_ROW + 32 + l31];
+        d[3 * u + 2] = rowsB[pr * SIN_ROW + l31];
+      }
+    };
+    ld(0, q[0]);
+#pragma unroll
+    for (int tb = 0; tb < 4; ++tb) {
+      if (tb + 1 < 4) ld(tb + 1, q[(tb + 1) & 1]);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float* d = q[tb & 1] + 3 * u;
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[0], d[2], acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[1], d[2], acc[1], 0, 0, 0);
+      }
+    }
+  };
+  // the same contraction with a piece of other work behind the two MFMAs of every point pair
+  // (filler(integral_constant<k>), k = 0..15), fenced so that the interleave stays as written: at
+  // one wave per SIMD an MFMA phase issued back to back is time the wave only waits for the pipe
+  auto gemm_points_with = [&](f32x16 (&acc)[2], const float* rowsB, auto&& filler) {
+    float q[2][12];
+    auto ld = [&](int tb, float* d) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int pr = 2 * (4 * tb + u) + h;
+        d[3 * u + 0] = sd[pr * SD_ROW + l31];
+        d[3 * u + 1] = sd[pr * SD_ROW + 32 + l31];
+        d[3 * u + 2] = rowsB[pr * SIN_ROW + l31];
+      }
+    };
+    ld(0, q[0]);
+    auto step = [&](auto kc) {
+      constexpr int K = decltype(kc)::value;
+      constexpr int tb = K / 4, u = K % 4;
+      if (u == 0 && tb + 1 < 4) ld(tb + 1, q[(tb + 1) & 1]);
+      const float* d = q[tb & 1] + 3 * u;
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[0], d[2], acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[1], d[2], acc[1], 0, 0, 0);
+      filler(kc);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    step(std::integral_constant<int, 0>{});  step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{});  step(std::integral_constant<int, 3>{});
+    step(std::integral_constant<int, 4>{});  step(std::integral_constant<int, 5>{});
+    step(std::integral_constant<int, 6>{});  step(std::integral_constant<int, 7>{});
+    step(std::integral_constant<int, 8>{});  step(std::integral_constant<int, 9>{});
+    step(std::integral_constant<int, 10>{}); step(std::integral_constant<int, 11>{});
+    step(std::integral_constant<int, 12>{}); step(std::integral_constant<int, 13>{});
+    step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
+  };
+  auto store_din = [&](int e, const f32x16& din, int64_t pi, int64_t r1) {
+    if (pi < r1) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const int la = ((r & 3) + 8 * (r >> 2)) / 2;      // this register pair's level for h = 0
+        const int lev = la + 2 * h;
+        if (la < ACT) {                                   // (else: no lane holds an active level here)
+          if (lev < ACT) dinbuf[((size_t)e * ACT + lev) * n + pi] = make_float2(din[r], din[r + 1]);
+        }
+      }
+    }
+  };
+
+  const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 31) / 32 * 32;
+  const int64_t r0 = blockIdx.x * per;
+  const int64_t r1 = r0 + per < n ? r0 + per : n;
+  for (int64_t bbase = r0; bbase < r1; bbase += blockDim.x) {
+    // (the last, partial iteration of a range is shared by the waves as in the general kernel)
+    int blk = wave, e_start = 0, e_step = 1;
+    {
+      const int64_t left = r1 - bbase;
+      if (left <= 64) { blk = 0; e_start = wave; e_step = 4; }
+      else if (left <= 128) { blk = wave & 1; e_start = wave >> 1; e_step = 2; }
+    }
+    const int64_t wave_first = bbase + blk * 64;
+    if (wave_first >= r1) continue;                          // nothing for this wave (no barriers inside)
+    const int64_t i = wave_first + lane;
+    const bool valid = i < r1;
+    const int64_t ii = valid ? i : r1 - 1;
+    const bool live1 = wave_first + 32 < r1;                 // the second point half holds points
+    const float p[3] = {pts[ii * 3], pts[ii * 3 + 1], pts[ii * 3 + 2]};
+    const int64_t gi = perm ? (int64_t)perm[ii] : ii;
+    float ds = 0.f, dl = 0.f, dg[3] = {0.f, 0.f, 0.f};
+    if (valid) {
+      if (d_sdf) ds = d_sdf[gi];
+      if (d_laplace) dl = d_laplace[gi];
+      if (d_grad) { dg[0] = d_grad[gi * 3]; dg[1] = d_grad[gi * 3 + 1]; dg[2] = d_grad[gi * 3 + 2]; }
+    }
+    __half2 rw[ACT], rwn[ACT];
+    {
+      const __half2* row = enc + ((size_t)e_start * n + ii) * ACT;
+#pragma unroll
+      for (int l = 0; l < ACT; ++l) rw[l] = row[l];
+#pragma unroll
+      for (int l = 0; l < ACT; ++l) rwn[l] = rw[l];
+    }
+    // inputs of evaluation e from the row in `rw`; requests the row of evaluation e + e_step
+    auto prologue = [&](int e, float (&in)[2 * KPA]) {
+      float q[3];
+      fd_point(p, e, eps, radius, q);
+      const float cx = contract(q[0], radius), cy = contract(q[1], radius), cz = contract(q[2], radius);
+#pragma unroll
+      for (int l = 0; l < ACT; ++l) {
+        vm_take(rw[l]);
+        const float2 f = __half22float2(rw[l]);
+        in[2 * l] = f.x;
+        in[2 * l + 1] = f.y;
+      }
+      if (e + e_step < 7) {
+        const __half2* row = enc + ((size_t)(e + e_step) * n + ii) * ACT;
+#pragma unroll
+        for (int l = 0; l < ACT; ++l) rwn[l] = row[l];
+      }
+      in[2 * ACT + 0] = cx * 2.0f + -1.0f;
+      in[2 * ACT + 1] = cy * 2.0f + -1.0f;
+      in[2 * ACT + 2] = cz * 2.0f + -1.0f;
+      in[2 * ACT + 3] = 1.0f;
+    };
+    auto handover = [&]() {
+#pragma unroll
+      for (int l = 0; l < ACT; ++l) {
+        vm_take(rwn[l]);
+        rw[l] = rwn[l];
+      }
+    };
+
+    int e = e_start;
+    if (e == 0) {
+      // ------------------------------------------------ centre evaluation: 13 upstream gradients
+      float in[2 * KPA];
+      prologue(0, in);
+      float dout[NOUT];
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) dout[o] = 0.0f;
+      if (valid) {
+        if (d_feature) {
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o) dout[o] = d_feature[gi * NOUT + o];
+        }
+        dout[0] += ds - 6.0f * dl / eps2;
+      }
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) gb1[o] += dout[o];
+      float b0[KPA], b1[KPA];
+#pragma unroll
+      for (int tt = 0; tt < KPA; ++tt) swap_halves(in[2 * tt], in[2 * tt + 1], b0[tt], b1[tt]);
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (half == 1 && !live1) break;
+        float d[NOUT];
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+          const float other = partner32(dout[o], h);
+          d[o] = (h == half) ? dout[o] : other;
+        }
+        f32x16 Hh[2];
+        l0_half(half ? b1 : b0, Hh);
+        softplus2(Hh);
+        f32x16 din;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) din[r] = 0.0f;
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+          float dpre[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) dpre[r] = w1o0[T][r] * d[0];
+          const float* wp = w1perm + h * NOUT * 32 + T * 16;
+#pragma unroll 1
+          for (int o = 1; o < NOUT; ++o) {
+            const float4* w4 = reinterpret_cast<const float4*>(wp + o * 32);
+            const float dv = d[o];
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+              const float4 w = w4[qd];
+              dpre[4 * qd + 0] = fmaf(w.x, dv, dpre[4 * qd + 0]);
+              dpre[4 * qd + 1] = fmaf(w.y, dv, dpre[4 * qd + 1]);
+              dpre[4 * qd + 2] = fmaf(w.z, dv, dpre[4 * qd + 2]);
+              dpre[4 * qd + 3] = fmaf(w.w, dv, dpre[4 * qd + 3]);
+            }
+          }
+          din_tile(T, dpre, Hh[T], din);
+          stage_rows(sd, T, dpre);
+        }
+        if (h == half) {
+          stage_in(in);
+#pragma unroll
+          for (int o4 = 0; o4 < 4; ++o4) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (4 * o4 + 0 < NOUT) v.x = dout[(4 * o4 + 0) < NOUT ? 4 * o4 + 0 : 0];
+            if (4 * o4 + 1 < NOUT) v.y = dout[(4 * o4 + 1) < NOUT ? 4 * o4 + 1 : 0];
+            if (4 * o4 + 2 < NOUT) v.z = dout[(4 * o4 + 2) < NOUT ? 4 * o4 + 2 : 0];
+            if (4 * o4 + 3 < NOUT) v.w = dout[(4 * o4 + 3) < NOUT ? 4 * o4 + 3 : 0];
+            *reinterpret_cast<float4*>(&sdo[l31 * SIN_ROW + 4 * o4]) = v;
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        gemm_points(gw0, sin_);
+        __builtin_amdgcn_wave_barrier();
+        // hidden activations of this half's points -> LDS, then gW1[feat][o'] += H^T . dOut
+#pragma unroll
+        for (int T = 0; T < 2; ++T) {
+          float hv[16];
+#pragma unroll
+          for (int r = 0; r < 16; ++r) hv[r] = Hh[T][r];
+          stage_rows(sd, T, hv);
+        }
+        __builtin_amdgcn_wave_barrier();
+        gemm_points(gw1, sdo);
+        __builtin_amdgcn_wave_barrier();
+        store_din(0, din, wave_first + half * 32 + l31, r1);
+      }
+      if (e + e_step < 7) handover();
+      e += e_step;
+    }
+    // ------------------------------------------------ offset evaluations: one upstream gradient
+    // loop-carried: the inputs and the upstream gradient of the evaluation about to run, prepared
+    // beside the previous evaluation's last MFMA phase
+    float in[2 * KPA];
+    float dout0 = 0.0f;
+    float q3[3] = {0.f, 0.f, 0.f};
+    auto prep_unpack = [&]() {                              // rw (already handed over) -> feature inputs
+#pragma unroll
+      for (int l = 0; l < ACT; ++l) {
+        const float2 f = __half22float2(rw[l]);
+        in[2 * l] = f.x;
+        in[2 * l + 1] = f.y;
+      }
+    };
+    auto prep_point = [&](int en) {                         // position of evaluation en -> xyz inputs
+      fd_point(p, en, eps, radius, q3);
+      in[2 * ACT + 0] = contract(q3[0], radius) * 2.0f + -1.0f;
+      in[2 * ACT + 1] = contract(q3[1], radius) * 2.0f + -1.0f;
+      in[2 * ACT + 2] = contract(q3[2], radius) * 2.0f + -1.0f;
+      in[2 * ACT + 3] = 1.0f;
+    };
+    auto prep_request = [&](int en) {                       // row of the evaluation after en (clamped)
+      const int e2 = en + e_step < 7 ? en + e_step : 6;
+      const __half2* row = enc + ((size_t)e2 * n + ii) * ACT;
+#pragma unroll
+      for (int l = 0; l < ACT; ++l) rwn[l] = row[l];
+    };
+    auto prep_dout = [&](int en) {
+      const int ax = (en - 1) >> 1;
+      const float sgn = ((en - 1) & 1) ? -1.0f : 1.0f;
+      const float dga = ax == 0 ? dg[0] : (ax == 1 ? dg[1] : dg[2]);
+      dout0 = valid ? sgn * 0.5f * dga / eps + dl / eps2 : 0.0f;
+    };
+    if (e < 7) {
+#pragma unroll
+      for (int l = 0; l < ACT; ++l) vm_take(rw[l]);
+      prep_unpack();
+      prep_point(e);
+      prep_request(e);
+      prep_dout(e);
+    }
+#pragma unroll 1
+    for (; e < 7; e += e_step) {
+      gb1[0] += dout0;
+      const float other0 = partner32(dout0, h);
+      const float d0h0 = h == 0 ? dout0 : other0;       // gradient of the point this lane column holds
+      const float d0h1 = h == 1 ? dout0 : other0;       //   in half 0 / half 1
+      float b0[KPA], b1[KPA];
+#pragma unroll
+      for (int tt = 0; tt < KPA; ++tt) swap_halves(in[2 * tt], in[2 * tt + 1], b0[tt], b1[tt]);
+      f32x16 H0[2], H1[2], din0, din1;
+      float dp0[2][16], dp1[2][16];
+      // P1: layer 0 of half 0
+      l0_half(b0, H0);
+      __builtin_amdgcn_sched_barrier(0);
+      // P2: layer 0 of half 1  ||  Softplus of half 0 (+ its column-0 sums of gW1), a few hidden units
+      // behind every MFMA; the fences keep the interleave the source spells out
+#pragma unroll
+      for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) H1[T][r] = 0.0f;
+#pragma unroll
+      for (int mi = 0; mi < 2 * KPA; ++mi) {
+        constexpr int NM = 2 * KPA;
+        const int T = mi / KPA, tt = mi % KPA;
+        H1[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0a[T][tt], b1[tt], H1[T], 0, 0, 0);
+#pragma unroll
+        for (int v = 0; v < 32; ++v)
+          if (v * NM / 32 == mi) {
+            H0[v >> 4][v & 15] = softplus100(H0[v >> 4][v & 15]);
+            gw1c0[v >> 4][v & 15] = fmaf(H0[v >> 4][v & 15], d0h0, gw1c0[v >> 4][v & 15]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // P3: dPre / sigmoid / dIn of half 0, rows to LDS
+#pragma unroll
+      for (int r = 0; r < 16; ++r) din0[r] = 0.0f;
+#pragma unroll
+      for (int T = 0; T < 2; ++T) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dp0[T][r] = w1o0[T][r] * d0h0;
+        din_tile(T, dp0[T], H0[T], din0);
+        stage_rows(sd, T, dp0[T]);
+      }
+      if (h == 0) stage_in(in);
+      __builtin_amdgcn_sched_barrier(0);
+      // P4: gW0 over half 0's points  ||  Softplus, column-0 sums, dPre x sigmoid of half 1: two
+      // hidden units behind the two MFMAs of every point pair
+      gemm_points_with(gw0, sin_, [&](auto kc) {
+        constexpr int K = decltype(kc)::value;
+#pragma unroll
+        for (int v = 2 * K; v < 2 * K + 2; ++v) {
+          const int T = v >> 4, r = v & 15;
+          H1[T][r] = softplus100(H1[T][r]);
+          gw1c0[T][r] = fmaf(H1[T][r], d0h1, gw1c0[T][r]);
+          dp1[T][r] = (w1o0[T][r] * d0h1) *
+                      (1.0f - __builtin_amdgcn_exp2f(H1[T][r] * -144.26950408889634f));
+        }
+      });
+      // P5: dIn of half 1; half 0's dIn out; half 1's rows to LDS (behind the reads of P4)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) din1[r] = 0.0f;
+#pragma unroll
+      for (int T = 0; T < 2; ++T)
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          bf16x8 bh, bm;
+          bf16_split8(&dp1[T][8 * g], bh, bm);
+          din1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_hi[T][g], bh, din1, 0, 0, 0);
+          din1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_hi[T][g], bm, din1, 0, 0, 0);
+          din1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_mid[T][g], bh, din1, 0, 0, 0);
+        }
+      store_din(e, din0, wave_first + l31, r1);
+      const int en = e + e_step < 7 ? e + e_step : 6;    // next evaluation (clamped: unused at the end)
+      if (live1) {
+#pragma unroll
+        for (int T = 0; T < 2; ++T) stage_rows(sd, T, dp1[T]);
+        if (h == 1) stage_in(in);
+        __builtin_amdgcn_sched_barrier(0);
+        // P6: gW0 over half 1's points  ||  half 1's dIn out, the next evaluation's inputs
+        gemm_points_with(gw0, sin_, [&](auto kc) {
+          constexpr int K = decltype(kc)::value;
+          if (K == 1) store_din(e, din1, wave_first + 32 + l31, r1);
+          if (K == 3) {
+#pragma unroll
+            for (int l = 0; l < ACT; ++l) {
+              vm_take(rwn[l]);
+              rw[l] = rwn[l];
+            }
+          }
+          if (K == 5) prep_unpack();
+          if (K == 7) prep_point(en);
+          if (K == 9) prep_request(en);
+          if (K == 11) prep_dout(en);
+        });
+      } else {
+#pragma unroll
+        for (int l = 0; l < ACT; ++l) {
+          vm_take(rwn[l]);
+          rw[l] = rwn[l];
+        }
+        prep_unpack();
+        prep_point(en);
+        prep_request(en);
+        prep_dout(en);
+      }
+    }
+  }
+
+  // ---- workgroup reduction of the parameter-gradient tiles -> one partial vector per workgroup
+  __syncthreads();
+  float* red = lds + W1P_F;                     // [4 waves][PART_STRIDE] (fits: 4*4160 floats)
+  {
+    float* rr = red + wave * PART_STRIDE;
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int feat = feat_of(T, r, h);
+        float c0 = gw1c0[T][r];                      // sum over the 32 point columns of this half
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) c0 += __shfl_xor(c0, off);
+        rr[PART_GW0 + feat * 32 + l31] = gw0[T][r];
+        rr[PART_GW1 + feat * 32 + l31] = gw1[T][r] + (l31 == 0 ? c0 : 0.0f);
+      }
+#pragma unroll
+    for (int o = 0; o < NOUT; ++o) gb1[o] += __shfl_xor(gb1[o], 32);
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1)
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) gb1[o] += __shfl_xor(gb1[o], off);
+    if (lane == 0) {
+#pragma unroll
+      for (int o = 0; o < NOUT; ++o) rr[PART_GB1 + o] = gb1[o];
+    }
+  }
+  __syncthreads();
+  float* part = partials + (size_t)blockIdx.x * PART_STRIDE;
+  for (int v = threadIdx.x; v < PART_GB1 + NOUT; v += blockDim.x)
+    part[v] = (red[v] + red[PART_STRIDE + v]) + (red[2 * PART_STRIDE + v] + red[3 * PART_STRIDE + v]);
+}
+
+template <int NL, int ACT>
+bool launch_bwd_pipe_one(uint32_t active, int blocks, size_t shm, hipStream_t s, const dsu_sdf_mlp& mlp,
+                         const float* pts, int64_t n, float radius, float eps, float eps2,
+                         const float* d_sdf, const float* d_grad, const float* d_feature,
+                         const float* d_laplace, float* partials, const __half2* enc, float2* dinbuf,
+                         const int32_t* perm) {
+  if ((int)active != ACT) return false;
+  static bool lds_ok = false;
+  if (!lds_ok) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(sdf_fd_bwd_pipe_kernel<NL, ACT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+      return false;
+    lds_ok = true;
+  }
+  sdf_fd_bwd_pipe_kernel<NL, ACT><<<dim3(blocks), dim3(256), shm, s>>>(
+      mlp, pts, n, radius, eps, eps2, d_sdf, d_grad, d_feature, d_laplace, partials, enc, dinbuf, perm);
+  return true;
+}
+
+template <int NL>
+bool launch_bwd_pipe(uint32_t active, int blocks, size_t shm, hipStream_t s, const dsu_sdf_mlp& mlp,
+                     const float* pts, int64_t n, float radius, float eps, float eps2,
+                     const float* d_sdf, const float* d_grad, const float* d_feature,
+                     const float* d_laplace, float* partials, const __half2* enc, float2* dinbuf,
+                     const int32_t* perm) {
+#define DSU_PIPE_TRY(A)                                                                          \
+  if (launch_bwd_pipe_one<NL, A>(active, blocks, shm, s, mlp, pts, n, radius, eps, eps2, d_sdf,   \
+                                 d_grad, d_feature, d_laplace, partials, enc, dinbuf, perm))      \
+    return true;
+  DSU_PIPE_TRY(4) DSU_PIPE_TRY(5) DSU_PIPE_TRY(6) DSU_PIPE_TRY(7)
+#undef DSU_PIPE_TRY
+  return false;
+}
+
 // ---------------------------------------------------------------------------- K2: scatter
 // Table gradients from dinbuf (SPLIT path).  One point per thread, 512 threads (8 waves) per
 // workgroup, one LEVEL at a time for the workgroup's 512 points (so the 4096-slot cache only ever
@@ -1814,10 +2401,23 @@ int dsu_sdf_fd_bwd_sorted_fold(const dsu_hashgrid_cfg* cfg, const void* table_f1
       DSU_ENSURE_DYN_LDS((sdf_fd_bwd_mfma_kernel<NL, true, true>), shm1);
       DSU_ENSURE_DYN_LDS((sdf_fd_bwd_mfma_kernel<NL, true, false>), shm1);
       DSU_ENSURE_DYN_LDS(k2, shm2);
-      k1<<<dim3(blocks), dim3(256), shm1, s>>>(
-          (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
-          d_grad, d_feature, d_laplace, grad_table, (float*)workspace, (const __half2*)enc_cache,
-          dinbuf, perm, ablate);
+      // the lean / pipelined form of the MLP part (NL = 10, features from the cache, 4..7 active
+      // levels: the optimisation's schedule); anything else, and DSU_BWD_PIPE=0 in variant builds,
+      // takes the general kernel
+      bool piped = false;
+      if constexpr (NL == 10) {
+        static int use_pipe = -1;
+        if (use_pipe < 0) use_pipe = dsu_ab_int("DSU_BWD_PIPE", 1) != 0;
+        if (use_pipe && enc_cache && ablate == 0)
+          piped = launch_bwd_pipe<NL>(active_levels, blocks, shm1, s, *mlp, pts, n, radius, eps, eps2,
+                                      d_sdf, d_grad, d_feature, d_laplace, (float*)workspace,
+                                      (const __half2*)enc_cache, dinbuf, perm);
+      }
+      if (!piped)
+        k1<<<dim3(blocks), dim3(256), shm1, s>>>(
+            (const __half2*)table_f16, m, *mlp, pts, n, radius, eps, eps2, active_levels, d_sdf,
+            d_grad, d_feature, d_laplace, grad_table, (float*)workspace, (const __half2*)enc_cache,
+            dinbuf, perm, ablate);
       // the MLP part holds every SIMD with one 458-register wave; what a caller wants to run
       // beside the rest of the backward (two 96-register waves per SIMD) waits for this event
       if (mid_event && hipEventRecord((hipEvent_t)mid_event, s) != hipSuccess) return DSU_ELAUNCH;

@@ -153,6 +153,69 @@ def test_sdf_fd_bwd(dev):
                                    atol=1e-5 * max(np.abs(r).max(), 1.0))
 
 
+def test_sdf_fd_bwd_from_the_feature_cache_vs_float64_autograd(dev):
+    """The path the optimisation runs — forward with the feature cache, backward from it (for 4..7
+    active levels the lean / pipelined kernel sdf_fd_bwd_pipe_kernel) — against float64 autograd."""
+    tab = _table(15, 0.5)
+    mlp = _mlp(16)
+    n = 1000 + 37
+    pts = _pts(n, 17, -1.0, 1.0)
+    eps, active, radius = 0.031, 5, 1.0
+    g = torch.Generator().manual_seed(18)
+    d = [torch.randn(n, generator=g), torch.randn(n, 3, generator=g) * 0.1,
+         torch.randn(n, 13, generator=g), torch.randn(n, generator=g) * 1e-3]
+    tab64 = tab.double().requires_grad_(True)
+    mlp64 = [m.double().requires_grad_(True) for m in mlp]
+    _torch_fd_loss(tab64, mlp64, pts.numpy(), eps, active, radius, [x.double() for x in d]).backward()
+    tabd, mlpd, ptsd = tab.to(dev), [m.to(dev) for m in mlp], pts.to(dev)
+    fwd = ops.sdf_fd_fwd(CFG, tabd, mlpd, ptsd, radius, eps, active, enc_cache=True)
+    gt, gm = ops.sdf_fd_bwd(CFG, tabd, mlpd, ptsd, radius, eps, active, *[x.to(dev) for x in d],
+                            enc_cache=fwd[4])
+    gt = gt.cpu().numpy().reshape(-1, 2)
+    ref_t = tab64.grad.numpy()
+    assert np.array_equal(ref_t != 0, gt != 0)
+    np.testing.assert_allclose(gt, ref_t, rtol=1e-4, atol=1e-5 * np.abs(ref_t).max())
+    for got, ref in zip(gm, mlp64):
+        r = ref.grad.numpy()
+        np.testing.assert_allclose(got.cpu().numpy(), r, rtol=1e-4,
+                                   atol=1e-5 * max(np.abs(r).max(), 1.0))
+
+
+@pytest.mark.parametrize("active", [4, 5, 6, 7])
+@pytest.mark.parametrize("n", [1, 33, 256, 256 * 9, 64 * 256 + 5, 256 * 96 + 40, 256 * 256 * 2,
+                               256 * 288 + 17, 70001])
+def test_sdf_fd_bwd_pipelined_kernel_equals_the_general_kernel(dev, active, n):
+    """sdf_fd_bwd_pipe_kernel (backward from the feature cache, 4..7 active levels) performs the
+    general kernel's operations in the general kernel's order per value.  The general kernel is
+    reached by the call WITHOUT a cache, which re-gathers the same f16 features; in that form it
+    does not share the last partial iteration of a workgroup's range between the waves, so:
+      * where every range is whole 256-point iterations (n = 256 k up to 256 workgroups, or a
+        multiple of 256 * 256) the MLP gradients of the two are bit-identical;
+      * otherwise (fewer points than workgroups, a last partial iteration of <= 64 / <= 128 points
+        whose evaluations the waves share, a lone second half) the same per-point terms are summed
+        by different waves: equal to float summation order (measured <= 1.1e-5 of the largest
+        entry, tools/bwd_pipe_diff.py).
+    The table gradients differ by the order of the float atomics of the scatter only."""
+    tab = _table(61, 0.5).to(dev)
+    mlp = [m.to(dev) for m in _mlp(62)]
+    pts = _pts(n, 63 + n % 7, -1.0, 1.0).to(dev)
+    eps, radius = 1.0 / 128, 1.0
+    g = torch.Generator().manual_seed(64)
+    d = [torch.randn(n, generator=g).to(dev), (torch.randn(n, 3, generator=g) * 0.1).to(dev),
+         (torch.randn(n, 13, generator=g) * 0.1).to(dev), (torch.randn(n, generator=g) * 1e-4).to(dev)]
+    fwd = ops.sdf_fd_fwd(CFG, tab, mlp, pts, radius, eps, active, enc_cache=True)
+    gt0, gm0 = ops.sdf_fd_bwd(CFG, tab, mlp, pts, radius, eps, active, *d)
+    gt1, gm1 = ops.sdf_fd_bwd(CFG, tab, mlp, pts, radius, eps, active, *d, enc_cache=fwd[4])
+    whole = n % 256 == 0 and (n <= 256 * 256 or n % (256 * 256) == 0)
+    for a_, b_ in zip(gm0, gm1):
+        if whole:
+            assert torch.equal(a_, b_)
+        else:
+            assert float((a_ - b_).abs().max()) <= 3e-5 * float(a_.abs().max())
+    assert torch.equal(gt0 != 0, gt1 != 0)
+    assert float((gt0 - gt1).abs().max()) <= 2e-6 * float(gt0.abs().max())
+
+
 def test_sdf_fd_bwd_points_outside_the_box(dev):
     """Points beyond [-radius, radius] (the perturbed random points of the sparsity / smoothness
     terms can be): fd_point clamps every coordinate of the six offset evaluations but not the
