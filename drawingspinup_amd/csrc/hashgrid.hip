@@ -275,21 +275,38 @@ __device__ __forceinline__ void mlp_stream_sgpr(const dsu_sdf_mlp& mlp, const fl
 #define DSU_FWD_JB 2
 #endif
 
-template <int NL, int NO>
+// points of the export's lattice formed in the kernel (dsu_sdf_fwd_lattice): x-slabs from x0
+struct SdfLattice {
+  const float* lin;
+  int32_t res, x0;
+  float lo[3], span[3];
+};
+
+template <int NL, int NO, bool LAT = false>
 __global__ __launch_bounds__(256) void sdf_fwd_kernel(const __half2* __restrict__ table,
                                                       GridMeta m, dsu_sdf_mlp mlp,
                                                       const float* __restrict__ pts, int64_t n,
                                                       float radius, uint32_t active,
-                                                      float* __restrict__ out) {
+                                                      float* __restrict__ out, SdfLattice lat) {
   using L = MlpLds<NL>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   DSU_FWD_LOAD_MLP(NL, lds, mlp);
   const int kmax = 3 + 2 * (int)active;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n;
        i += (int64_t)gridDim.x * blockDim.x) {
-    float x = contract(pts[i * 3 + 0], radius);
-    float y = contract(pts[i * 3 + 1], radius);
-    float z = contract(pts[i * 3 + 2], radius);
+    float px, py, pz;
+    if (LAT) {
+      const int64_t r2 = (int64_t)lat.res * lat.res;
+      const int ix = lat.x0 + (int)(i / r2), iy = (int)((i / lat.res) % lat.res), iz = (int)(i % lat.res);
+      px = lat.lin[ix] * lat.span[0] + lat.lo[0];          // (-ffp-contract=off: two rounded operations)
+      py = lat.lin[iy] * lat.span[1] + lat.lo[1];
+      pz = lat.lin[iz] * lat.span[2] + lat.lo[2];
+    } else {
+      px = pts[i * 3 + 0]; py = pts[i * 3 + 1]; pz = pts[i * 3 + 2];
+    }
+    float x = contract(px, radius);
+    float y = contract(py, radius);
+    float z = contract(pz, radius);
     float in[L::DIN];
     encode_input<NL>(table, m, active, x, y, z, in);
     float o_[NO];
@@ -1251,10 +1268,36 @@ int dsu_sdf_fwd_valu(const dsu_hashgrid_cfg* cfg, const void* table_f16, const d
     const size_t shm = DSU_FWD_LDS_BYTES(NL);
     if (n_out == 1)
       sdf_fwd_kernel<NL, 1><<<dim3(blocks), dim3(DSU_FWD_THREADS), shm, s>>>(
-          (const __half2*)table_f16, m, *mlp, pts, n, radius, active_levels, out);
+          (const __half2*)table_f16, m, *mlp, pts, n, radius, active_levels, out, SdfLattice{});
     else
       sdf_fwd_kernel<NL, NOUT><<<dim3(blocks), dim3(DSU_FWD_THREADS), shm, s>>>(
-          (const __half2*)table_f16, m, *mlp, pts, n, radius, active_levels, out);
+          (const __half2*)table_f16, m, *mlp, pts, n, radius, active_levels, out, SdfLattice{});
+  });
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_sdf_fwd_lattice(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                        const float* lin, int32_t res, int32_t x0, int32_t nx, const float* lo3,
+                        const float* span3, float radius, uint32_t active_levels, float* out,
+                        void* stream) {
+  if (!cfg || !table_f16 || !mlp || !lin || !lo3 || !span3 || !out || res < 1 || x0 < 0 || nx < 0 ||
+      x0 + nx > res)
+    return DSU_EINVAL;
+  if (!mlp->w0 || !mlp->b0 || !mlp->w1 || !mlp->b1) return DSU_EINVAL;
+  if (active_levels > cfg->n_levels) return DSU_EINVAL;
+  GridMeta m;
+  int rc = make_meta(cfg, &m);
+  if (rc) return rc;
+  const int64_t n = (int64_t)nx * res * res;
+  if (n == 0) return DSU_OK;
+  SdfLattice lat{lin, res, x0, {lo3[0], lo3[1], lo3[2]}, {span3[0], span3[1], span3[2]}};
+  hipStream_t s = (hipStream_t)stream;
+  const int blocks = dsu_capped_blocks(n, DSU_FWD_THREADS, 8192 * (256 / DSU_FWD_THREADS));
+  DSU_DISPATCH_NL(cfg->n_levels, {
+    const size_t shm = DSU_FWD_LDS_BYTES(NL);
+    sdf_fwd_kernel<NL, 1, true><<<dim3(blocks), dim3(DSU_FWD_THREADS), shm, s>>>(
+        (const __half2*)table_f16, m, *mlp, nullptr, n, radius, active_levels, out, lat);
   });
   DSU_CHECK_LAUNCH();
   return DSU_OK;

@@ -194,17 +194,21 @@ def marching_cubes(volume, isovalue=0.0):
     et, tt = tables()
     edge_table = torch.from_numpy(et).to(dev)
     tri_table = torch.from_numpy(tt.astype(np.int64)).to(dev)
-    below = v <= isovalue                                          # marchingcubes.h: `<=`
-    cube = torch.zeros((X - 1, Y - 1, Z - 1), dtype=torch.int64, device=dev)
-    for m, (dx, dy, dz) in enumerate(CORNERS):
-        cube += below[dx:X - 1 + dx, dy:Y - 1 + dy, dz:Z - 1 + dz].to(torch.int64) << m
+    if v.is_cuda:
+        from .. import ops
+        cube = ops.mc_cube_index(v.contiguous(), isovalue)         # one configuration byte per cube
+    else:
+        below = v <= isovalue                                      # marchingcubes.h: `<=`
+        cube = torch.zeros((X - 1, Y - 1, Z - 1), dtype=torch.int64, device=dev)
+        for m, (dx, dy, dz) in enumerate(CORNERS):
+            cube += below[dx:X - 1 + dx, dy:Y - 1 + dy, dz:Z - 1 + dz].to(torch.int64) << m
     active = torch.nonzero((cube != 0) & (cube != 255))           # lexicographic = sweep order
     na = active.shape[0]
     if na == 0:
         return (torch.zeros((0, 3), dtype=torch.float64, device=dev),
                 torch.zeros((0, 3), dtype=torch.int64, device=dev))
     ci, cj, ck = active[:, 0], active[:, 1], active[:, 2]
-    cidx = cube[ci, cj, ck]
+    cidx = cube[ci, cj, ck].to(torch.int64)
     emask = edge_table[cidx].to(torch.int64)
     # which of its 12 edges does each active cube CREATE (first cube of the sweep on that edge)?
     own = {6: None, 5: None, 10: None,
@@ -238,14 +242,14 @@ def marching_cubes(volume, isovalue=0.0):
         p = torch.where((fa == fb)[:, None], (pa + pb) / 2, p)
         verts[vid_o[sel, slot]] = p
     # per grid edge: the id of its vertex (three dense id volumes, one per axis)
-    eid = [torch.full((X, Y, Z), -1, dtype=torch.int64, device=dev) for _ in range(3)]
+    eid = [torch.full((X, Y, Z), -1, dtype=torch.int32, device=dev) for _ in range(3)]
     for slot, e in enumerate(CREATE_ORDER):
         sel = created_o[:, slot]
         if not bool(sel.any()):
             continue
         axis, off = EDGE_AXIS_OFF[e]
         b = active[sel] + torch.tensor(off, device=dev)
-        eid[axis][b[:, 0], b[:, 1], b[:, 2]] = vid_o[sel, slot]
+        eid[axis][b[:, 0], b[:, 1], b[:, 2]] = vid_o[sel, slot].to(torch.int32)
     # triangles: cube by cube, table order
     tri = tri_table[cidx]                                          # (na, 3T), -1 padded
     ntri = (tri >= 0).sum(1) // 3
@@ -257,7 +261,7 @@ def marching_cubes(volume, isovalue=0.0):
     for e in range(12):
         axis, off = EDGE_AXIS_OFF[e]
         b = active + torch.tensor(off, device=dev)
-        cube_vid[:, e] = eid[axis][b[:, 0], b[:, 1], b[:, 2]]
+        cube_vid[:, e] = eid[axis][b[:, 0], b[:, 1], b[:, 2]].to(torch.int64)
     for t in range(T):
         sel = ntri > t
         if not bool(sel.any()):
@@ -308,6 +312,33 @@ def _min_plus_pass(d2, axis, radius):
     return out
 
 
+def _band_tables(radius, band_radius):
+    """Host tables over d2 = min(squared distance to the nearest voxel of the other class, (R+1)^2)
+    for csrc/mesh_volume.hip: the float64 values signed_distance_band's last lines produce (sqrt,
+    far-field value, half-voxel shift, sign; row 0 = inside voxels) and |value| <= band_radius."""
+    R = int(math.ceil(radius))
+    k = np.arange((R + 1) * (R + 1) + 1, dtype=np.float64)
+    d = np.sqrt(k)
+    d = np.where(d > radius, float(radius) + 1.0, d)
+    inside = d - 0.5
+    table = np.stack([inside, -(d - 0.5)])
+    band = (np.abs(inside) <= band_radius).astype(np.uint8) if band_radius is not None else np.zeros(k.shape, np.uint8)
+    return R, table, band
+
+
+@torch.no_grad()
+def signed_distance_band_device(binary, radius=5.0, band_radius=None):
+    """signed_distance_band on the library's kernels (dsu_volume_band_distance): the same integers
+    through three passes over two bytes per voxel, then the values through the host's table.
+    Returns (dist f64, band bool = |dist| <= band_radius, or None)."""
+    from .. import ops
+    R, table, band = _band_tables(radius, band_radius)
+    dev = binary.device
+    dist, bm = ops.volume_band_distance(binary.bool(), R, torch.from_numpy(table).to(dev),
+                                        torch.from_numpy(band).to(dev))
+    return dist, (bm if band_radius is not None else None)
+
+
 @torch.no_grad()
 def signed_distance_band(binary, radius=5.0):
     """scipy.ndimage.distance_transform_edt on both classes, exact wherever the other class is
@@ -315,7 +346,15 @@ def signed_distance_band(binary, radius=5.0):
     -(distance to the nearest True voxel) + 0.5 outside; farther voxels get +-(radius + 0.5).
     Separable squared-distance transform in integers: nearest other-class voxel along z, then
     min-plus sweeps over |dy| <= R and |dx| <= R (a nearest voxel within R has every coordinate
-    offset within R)."""
+    offset within R).  Device volumes: csrc/mesh_volume.hip (bit-identical values); this tensor
+    program is the host form and the tests' comparison (`signed_distance_band_tensor_program`)."""
+    if binary.is_cuda and math.ceil(radius) <= 8 and binary.shape[2] <= 4096:
+        return signed_distance_band_device(binary, radius)[0]
+    return signed_distance_band_tensor_program(binary, radius)
+
+
+@torch.no_grad()
+def signed_distance_band_tensor_program(binary, radius=5.0):
     b = binary.bool()
     R = int(math.ceil(radius))
     cap2 = (R + 1) * (R + 1)
@@ -346,14 +385,19 @@ def smooth_constrained(binary, max_iters=250, rel_tol=1e-6, band_radius=4.0, wei
     order with six neighbour-slot arrays; F and F^T are gathers over them."""
     b = binary.bool()
     dev = b.device
-    dist = signed_distance_band(b, band_radius + 1.0)
-    band = dist.abs() <= band_radius
+    if b.is_cuda and math.ceil(band_radius + 1.0) <= 8 and b.shape[2] <= 4096:
+        dist, band = signed_distance_band_device(b, band_radius + 1.0, band_radius)
+    else:
+        dist = signed_distance_band(b, band_radius + 1.0)
+        band = dist.abs() <= band_radius
     pos = torch.nonzero(band)
     nv = pos.shape[0]
     if nv == 0:
         return dist
+    # x-major linear index of the band voxels (the order nonzero / mask indexing walk them in)
+    flat = (pos[:, 0] * b.shape[1] + pos[:, 1]) * b.shape[2] + pos[:, 2]
     slot = torch.full(b.shape, -1, dtype=torch.int32, device=dev)
-    slot[band] = torch.arange(nv, device=dev, dtype=torch.int32)
+    slot.view(-1)[flat] = torch.arange(nv, device=dev, dtype=torch.int32)
     shape = torch.tensor(b.shape, device=dev)
     nbr_slots = []                          # -x, +x, -y, +y, -z, +z : slot or -1
     for a in range(3):
@@ -365,7 +409,7 @@ def smooth_constrained(binary, max_iters=250, rel_tol=1e-6, band_radius=4.0, wei
             n = slot[q[:, 0], q[:, 1], q[:, 2]]
             nbr_slots.append(torch.where(ok, n, torch.full_like(n, -1)))
     del slot
-    x = dist[band]
+    x = dist.reshape(-1)[flat]
     # PyMCubes' bounds: own-side bound = the initial distance, 0 next to the surface
     ninf, pinf = float("-inf"), float("inf")
     lower = torch.where(x > 0, x, torch.full_like(x, ninf))
@@ -392,9 +436,8 @@ def smooth_constrained(binary, max_iters=250, rel_tol=1e-6, band_radius=4.0, wei
                 energy_now = float(ops.smooth_energy(nbr_t, x, ybuf))
                 if energy_before <= 0 or (energy_before - energy_now) / energy_before < cum_rel_tol:
                     break
-        out = dist.clone()
-        out[band] = x
-        return out
+        dist.view(-1)[flat] = x             # (dist is this call's own volume: written in place)
+        return dist
     # host tensors (CPU tests of the restatement): the same iteration as tensor programs
     nbr = [[nbr_slots[2 * a + k].clamp(min=0).long() for k in range(2)] for a in range(3)]
     has = [[(nbr_slots[2 * a + k] >= 0).to(torch.float64) for k in range(2)] for a in range(3)]

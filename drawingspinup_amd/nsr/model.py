@@ -552,12 +552,14 @@ class NeuSModel(nn.Module):
         return {}
 
     @torch.no_grad()
-    def isosurface_levels(self, vmin, vmax, resolution=None, chunk=None):
+    def isosurface_levels(self, vmin, vmax, resolution=None, chunk=None, lattice_kernel=None):
         """BaseImplicitGeometry.isosurface_ grid evaluation (geometry.py:83-106): SDF on the
         res^3 lattice, x-major / y / z-minor ('ij' meshgrid order, geometry.py:44-46),
         evaluated chunk by chunk on the device.  Returns (res,res,res) f32 on the device."""
         iso = self.config.geometry.isosurface
         res = resolution or iso.resolution
+        if lattice_kernel is None:
+            lattice_kernel = chunk is None       # an explicit chunk size asks for the chunked tensor expression
         chunk = chunk or iso.chunk
         dev = self.scene_aabb.device
         lin = torch.linspace(0, 1, res, device=dev)
@@ -565,6 +567,16 @@ class NeuSModel(nn.Module):
         vmin = [float(v) for v in vmin]
         vmax = [float(v) for v in vmax]
         # a chunk = `chunk // res^2` x-slabs (chunk is a multiple of res^2 for 512/2097152)
+        if dev.type == "cuda" and lattice_kernel:
+            # the lattice points are formed in the kernel (dsu_sdf_fwd_lattice: lin[i] * span + lo per
+            # axis, the two rounded float32 operations of the tensor expression below)
+            lo = torch.tensor(vmin, dtype=torch.float64).float()
+            span = (torch.tensor(vmax, dtype=torch.float64) - torch.tensor(vmin, dtype=torch.float64)).float()
+            g = self.geometry
+            w = [t.detach().contiguous() for t in g._mlp()]
+            ops.sdf_fwd_lattice(g.hashgrid.cfg, g.hashgrid.table_f16(), w, lin.contiguous(), 0, res,
+                                lo.tolist(), span.tolist(), g.radius, g.active_levels, level)
+            return level.view(res, res, res)
         slab = max(1, chunk // (res * res))
         yz = torch.stack(torch.meshgrid(lin, lin, indexing="ij"), -1).reshape(-1, 2)
         for x0 in range(0, res, slab):

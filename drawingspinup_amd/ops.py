@@ -89,6 +89,23 @@ def sdf_fwd(cfg, table_f16, mlp, pts, radius, active_levels, n_out=1):
     return out
 
 
+def sdf_fwd_lattice(cfg, table_f16, mlp, lin, x0, nx, lo, span, radius, active_levels, out):
+    """SDF on x-slabs [x0, x0 + nx) of the res^3 export lattice, points formed in the kernel
+    (p = lin[i] * span + lo per axis); lin (res) f32 device, lo / span three host floats (f32 values);
+    out: f32 view of nx * res * res elements, written in place."""
+    res = lin.shape[0]
+    c, m = cfg.c(), _mlp_struct(*mlp)
+    lo3 = (C.c_float * 3)(*[float(v) for v in lo])
+    sp3 = (C.c_float * 3)(*[float(v) for v in span])
+    if out.numel() != nx * res * res:
+        raise DsuError("sdf_fwd_lattice: output size")
+    check(lib().dsu_sdf_fwd_lattice(C.byref(c), ptr(table_f16, torch.float16), C.byref(m),
+                                    ptr(lin, torch.float32), res, int(x0), int(nx), lo3, sp3,
+                                    float(radius), int(active_levels), ptr(out, torch.float32), stream()),
+          "dsu_sdf_fwd_lattice")
+    return out
+
+
 def spatial_sort(pts, radius, bits=6):
     """Morton-bin the points of one step (csrc/spatial_sort.hip): returns (pts_sorted, perm) with
     pts_sorted[i] = pts[perm[i]].  Pass both to sdf_fd_fwd / sdf_fd_bwd (perm=...)."""
@@ -229,6 +246,37 @@ def smooth_energy(nbr, x, y):
                                   ptr(y, torch.float64), ptr(part), stream()),
           "dsu_smooth_energy")
     return part.sum() / 2
+
+
+def volume_band_distance(binary, R, value_table, band_table):
+    """binary (X,Y,Z) bool/uint8 device volume -> (dist f64 (X,Y,Z), band bool (X,Y,Z)) through the
+    caller's tables over d2 = min(squared distance to the nearest voxel of the other class, (R+1)^2):
+    value_table (2, (R+1)^2 + 1) f64 (row 0: inside voxels), band_table ((R+1)^2 + 1) uint8."""
+    b = binary.contiguous()
+    if b.dtype == torch.bool:
+        b = b.view(torch.uint8)
+    X, Y, Z = b.shape
+    dev = b.device
+    dist = torch.empty((X, Y, Z), dtype=torch.float64, device=dev)
+    band = torch.empty((X, Y, Z), dtype=torch.uint8, device=dev)
+    wbytes = int(lib().dsu_volume_band_distance_workspace_bytes(X, Y, Z))
+    if wbytes < 0:
+        check(wbytes, "dsu_volume_band_distance_workspace_bytes")
+    ws = torch.empty(wbytes, dtype=torch.uint8, device=dev)
+    check(lib().dsu_volume_band_distance(ptr(b, torch.uint8), X, Y, Z, int(R),
+                                         ptr(value_table, torch.float64), ptr(band_table, torch.uint8),
+                                         ptr(dist), ptr(band), ptr(ws), wbytes, stream()),
+          "dsu_volume_band_distance")
+    return dist, band.view(torch.bool)
+
+
+def mc_cube_index(volume, isovalue):
+    """(X,Y,Z) f64 device volume -> (X-1,Y-1,Z-1) uint8 marching-cubes configuration bytes."""
+    X, Y, Z = volume.shape
+    cube = torch.empty((X - 1, Y - 1, Z - 1), dtype=torch.uint8, device=volume.device)
+    check(lib().dsu_mc_cube_index(ptr(volume, torch.float64), X, Y, Z, float(isovalue), ptr(cube),
+                                  stream()), "dsu_mc_cube_index")
+    return cube
 
 
 # ------------------------------------------------------------------ nerfacc replacements

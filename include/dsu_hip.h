@@ -97,6 +97,16 @@ typedef struct {
 int dsu_sdf_fwd(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
                 const float* pts, int64_t n, float radius, uint32_t active_levels,
                 uint32_t n_out, float* out, void* stream);
+/* The same network on the export's lattice (BaseImplicitGeometry.isosurface_, geometry.py:83-106:
+ * `scale_anything(meshgrid(linspace(0,1,res)), (0,1), (vmin,vmax))` -> forward_level, chunk by
+ * chunk): the points are formed in the kernel, x-slabs [x0, x0 + nx) of the res^3 lattice,
+ * p = lin[i] * span + lo per axis (two rounded f32 operations, as the reference's tensor
+ * expression).  lin: (res) f32 on the device (the caller's linspace); out: (nx * res * res) f32,
+ * x-major / y / z-minor. */
+int dsu_sdf_fwd_lattice(const dsu_hashgrid_cfg* cfg, const void* table_f16, const dsu_sdf_mlp* mlp,
+                        const float* lin, int32_t res, int32_t x0, int32_t nx, const float* lo3,
+                        const float* span3, float radius, uint32_t active_levels, float* out,
+                        void* stream);
 
 /* VolumeSDF.forward(points, with_grad, with_feature, with_laplace) with
  * grad_type=finite_difference (geometry.py:158-176): 7 network evaluations per point
@@ -911,6 +921,23 @@ int dsu_smooth_iterate(const int32_t* nbr, int64_t nv, const double* lower, cons
                        double weight, int32_t iters, double* x, double* y, void* stream);
 int dsu_smooth_energy(const int32_t* nbr, int64_t nv, const double* x, double* y,
                       double* partials, void* stream);
+
+/* The signed distance transform mcubes.smooth starts from (PyMCubes: scipy's
+ * distance_transform_edt on both classes, +-0.5 at the boundary voxels; geometry.py:57-58), in the
+ * band that matters: exact wherever the other class is within R voxels (1 <= R <= 8).
+ * binary (X,Y,Z) bytes (non-zero = inside), z minor.  Per voxel d2 = min(squared distance to the
+ * nearest voxel of the OTHER class, (R+1)^2) as an integer; the outputs go through two caller-built
+ * tables: dist[v] = value_table[(inside ? 0 : (R+1)^2 + 1) + d2] (f64: the caller applies sqrt,
+ * the far-field value, the half-voxel shift and the sign on the host), band[v] = band_table[d2].
+ * workspace: dsu_volume_band_distance_workspace_bytes(X, Y, Z) bytes of device scratch. */
+int64_t dsu_volume_band_distance_workspace_bytes(int32_t X, int32_t Y, int32_t Z);
+int dsu_volume_band_distance(const uint8_t* binary, int32_t X, int32_t Y, int32_t Z, int32_t R,
+                             const double* value_table, const uint8_t* band_table, double* dist,
+                             uint8_t* band, void* workspace, int64_t workspace_bytes, void* stream);
+/* mcubes.marching_cubes' configuration byte per cube (PyMCubes marchingcubes.h: `if (v[m] <=
+ * isovalue) cubeindex |= 1 << m`, geometry.py:59): volume (X,Y,Z) f64 -> cube (X-1,Y-1,Z-1) bytes. */
+int dsu_mc_cube_index(const double* volume, int32_t X, int32_t Y, int32_t Z, double isovalue,
+                      uint8_t* cube, void* stream);
 
 /* ------------------------------------------------------------------------------------
  * Mesh post-processing of the export (save_mesh, instant_nsr/utils/mesh_utils.py:25-73): the

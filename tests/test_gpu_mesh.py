@@ -120,3 +120,71 @@ def test_isosurface_lattice_points_match_reference_grid(dev):
     np.testing.assert_allclose(coarse[idx], z["coarse_pts"], rtol=0, atol=1.2e-7)
     np.testing.assert_allclose(fine[idx], z["fine_pts"], rtol=0, atol=2.4e-7)
     assert lo.shape == hi.shape == (3,)
+
+
+# ------------------------------------------------------------------ csrc/mesh_volume.hip
+def _volumes():
+    g = torch.Generator().manual_seed(3)
+    blob = _shape(44)[:, :37, :]                                   # non-cubic, touches no face
+    noise = torch.rand(23, 40, 70, generator=g) > 0.5              # every voxel next to the other class
+    sparse = torch.rand(30, 30, 66, generator=g) > 0.985           # isolated voxels, long empty runs
+    full = torch.ones(9, 10, 11, dtype=torch.bool)
+    empty = torch.zeros(9, 10, 11, dtype=torch.bool)
+    slab = torch.zeros(20, 18, 16, dtype=torch.bool)
+    slab[:, :, :7] = True                                          # a class boundary through the faces
+    one = torch.zeros(15, 15, 15, dtype=torch.bool)
+    one[7, 7, 7] = True
+    return {"blob": blob, "noise": noise, "sparse": sparse, "full": full, "empty": empty, "slab": slab,
+            "one": one}
+
+
+@pytest.mark.parametrize("radius,band_radius", [(5.0, 4.0), (3.0, 2.0), (2.5, 2.0), (8.0, 7.5)])
+def test_band_distance_kernel_equals_the_tensor_program(dev, radius, band_radius):
+    """dsu_volume_band_distance (integer squared distances through three byte passes, values through
+    the host's table) == signed_distance_band_tensor_program ON THE DEVICE (the export's form until
+    round 5) bit for bit, and its band byte == |dist| <= band_radius: blobs, noise, isolated voxels,
+    one-class volumes, boundaries on faces.  (The tensor program on HOST tensors is compared to
+    2 ulp only: torch's vectorised CPU sqrt is not correctly rounded for every integer — 2, 8, 19,
+    32 differ from numpy's here — while the table holds numpy's, as scipy's C sqrt in the
+    reference does.)"""
+    for name, b in _volumes().items():
+        ref = M.signed_distance_band_tensor_program(b.to(dev), radius).cpu()
+        got, band = M.signed_distance_band_device(b.to(dev), radius, band_radius)
+        assert got.dtype == torch.float64 and band.dtype == torch.bool, name
+        assert torch.equal(got.cpu(), ref), name
+        assert torch.equal(band.cpu(), ref.abs() <= band_radius), name
+        assert torch.equal(M.signed_distance_band(b.to(dev), radius).cpu(), ref), name
+        host = M.signed_distance_band_tensor_program(b, radius)
+        np.testing.assert_allclose(got.cpu().numpy(), host.numpy(), rtol=0, atol=2e-15)
+
+
+def test_cube_index_kernel_equals_the_tensor_program(dev):
+    """dsu_mc_cube_index == the eight shifted comparisons of the host form, exact zeros included
+    (the `<=` corner rule), on a non-cubic volume."""
+    vol = _field(64, 5)[:, :50, :41].contiguous()
+    assert int((vol == 0).sum()) > 50
+    from drawingspinup_amd import ops
+    got = ops.mc_cube_index(vol.to(dev), 0.0).cpu()
+    X, Y, Z = vol.shape
+    below = vol <= 0.0
+    ref = torch.zeros((X - 1, Y - 1, Z - 1), dtype=torch.int64)
+    for m, (dx, dy, dz) in enumerate(M.CORNERS):
+        ref += below[dx:X - 1 + dx, dy:Y - 1 + dy, dz:Z - 1 + dz].to(torch.int64) << m
+    assert torch.equal(got.to(torch.int64), ref)
+    hv, hf = M.marching_cubes(vol, 0.0)                            # host form end to end
+    dv, df = M.marching_cubes(vol.to(dev), 0.0)
+    assert torch.equal(df.cpu(), hf) and torch.equal(dv.cpu(), hv)
+
+
+def test_lattice_forward_equals_the_chunked_tensor_expression(dev):
+    """dsu_sdf_fwd_lattice forms the export's lattice points in the kernel: the level volume is
+    bit-identical to the chunked tensor expression + forward_level (same rounded float32
+    coordinates, same network kernel), for the whole box and for an off-centre fine box."""
+    from drawingspinup_amd.nsr.model import NeuSModel
+    torch.manual_seed(11)
+    model = NeuSModel().to(dev)
+    res = 40
+    for vmin, vmax in (([-1.0] * 3, [1.0] * 3), ([-0.4123456789, -0.61, -0.2000000001], [0.35, 0.58, 0.77])):
+        a = model.isosurface_levels(vmin, vmax, res)
+        b = model.isosurface_levels(vmin, vmax, res, chunk=5 * res * res)
+        assert a.shape == (res, res, res) and torch.equal(a, b)

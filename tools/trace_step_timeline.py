@@ -1,13 +1,13 @@
 """Timeline of the NSR optimisation step from a rocprofv3 kernel trace (csv): per queue the busy
 time and the idle gaps between consecutive kernels, and one steady-state step printed kernel by
 kernel (start offset, duration, queue).  usage: trace_step_timeline.py <kernel_trace.csv> [anchor]
-`anchor` = substring of the kernel that starts a step (default sdf_fd_fwd_kernel)."""
+`anchor` = substring of the kernel that starts a step (default sdf_fd_fwd: any form of the geometry forward)."""
 import csv
 import sys
 from collections import defaultdict
 
 path = sys.argv[1]
-anchor = sys.argv[2] if len(sys.argv) > 2 else "sdf_fd_fwd_kernel"
+anchor = sys.argv[2] if len(sys.argv) > 2 else "sdf_fd_fwd"
 rows = []
 for r in csv.DictReader(open(path)):
     rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Queue_Id"],
