@@ -286,14 +286,36 @@ __global__ __launch_bounds__(256) void conv_f16_kernel(CArgs a) {
     // runs the epilogue.  The UNet forward issued ~180 reduce launches (7 us + a launch gap each,
     // 1.2 ms of 13) for its split-K layers.
     __shared__ int s_ticket;
+    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
+#ifdef DSU_CONV_THREADFENCE
+    // (rounds 3-5, A/B variant: a device-scope fence by every thread on both sides)
     __threadfence();
     __syncthreads();
-    const int tile = blockIdx.y * gridDim.x + blockIdx.x;
     if (tid == 0) s_ticket = atomicAdd(&a.counters[tile], 1);
     __syncthreads();
     if (s_ticket != a.split_k - 1) return;
     __threadfence();
     if (tid == 0) a.counters[tile] = 0;             // ready for the next launch on this stream
+#else
+    // publish: every wave's slab stores have left the wave (vmcnt), ONE agent-scope release (the
+    // write-back of this XCD's L2 is not per wave), then the relaxed ticket; the last arriver does
+    // ONE agent-scope acquire for the workgroup.  A __threadfence() per thread on both sides is the
+    // same ordering at several times the cost (a write-back + invalidate per wave).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      s_ticket = __hip_atomic_fetch_add(&a.counters[tile], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();
+    if (s_ticket != a.split_k - 1) return;
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      a.counters[tile] = 0;                         // ready for the next launch on this stream
+    }
+    __syncthreads();
+#endif
     const int hw = a.OH * a.OW;
     for (int idx = tid; idx < TN * (TM / 4); idx += 256) {
       const int64_t p = p0 + idx / (TM / 4);
