@@ -54,6 +54,14 @@ def parse(argv=None):
     ap.add_argument("--nsr-steps", type=int, default=3000)
     ap.add_argument("--frames", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=3,
+                    help="--config drawing: drawings in flight per GPU (one Python thread + one stream + "
+                         "one DrawingPipeline each); 1 = one drawing at a time, as in rounds 1-5")
+    ap.add_argument("--inflight-skew", type=float, default=None,
+                    help="seconds between the starts of the workers' first drawings of a region (stage skew; "
+                         "default: 4.2 s / inflight)")
+    ap.add_argument("--nsr-slots", type=int, default=0,
+                    help="at most this many drawings inside the NSR optimisation at a time (0 = no limit)")
     a = ap.parse_args(argv)
     if a.steps is None:
         a.steps = {"drawing": 1, "unet": 50, "nsr50k": 50, "frames": 3}[a.config]
@@ -305,6 +313,123 @@ def _timed_loop(args, ddist, dev, timer, body):
     return elapsed, last
 
 
+def _inflight_loop(args, ddist, rank, dev, timer, pipes, inputs, stage_t, sub_t, gathered):
+    """K = len(pipes) drawings in flight on this rank's GPU: K worker threads, each with its own
+    stream and pipeline, take the drawings of the region in turn (drawing j -> worker j % K) and run
+    them back to back; the main thread keeps the collectives (the per-drawing gather of the outputs
+    to rank 0) in one order on every rank.  Warm-up region, barrier + synchronize, timed region of
+    args.steps * K drawings, synchronize + barrier, max over ranks — the contract's brackets around
+    the whole region.  Returns (elapsed, {"latency": ..., "alone": ...})."""
+    import queue
+    import threading
+    from drawingspinup_amd.drawing import DrawingPipeline  # noqa: F401  (import check before threads start)
+    K = len(pipes)
+    on_gpu = torch.device(dev).type == "cuda"
+
+    class _HostStream:                      # the gloo tests drive this loop with CPU stubs
+        def synchronize(self):
+            pass
+
+        def __enter__(self):
+            return self
+
+        def __exit__(self, *a):
+            return False
+    streams = [torch.cuda.Stream(dev) if on_gpu else _HostStream() for _ in range(K)]
+    lat = []
+
+    def one(pipe, stream, j, timed):
+        seed = (rank * 100 + j) if timed else (1000 + rank * 100 + j)
+        drawing, frames_in, edges_in = inputs[(timed, j)]
+        sync = stream.synchronize
+        with (torch.cuda.stream(stream) if on_gpu else stream):
+            t0 = time.time()
+            cleaned = pipe.remove_contour(drawing)
+            sync(); t1 = time.time()
+            normals, colors = pipe.multiview(cleaned, 123456 + seed)
+            sync(); t2 = time.time()
+            system, inside = pipe.reconstruct(normals, colors, cleaned, 123456 + seed)
+            sync(); t3 = time.time()
+            frames = pipe.stylize(frames_in, edges_in)
+            views = torch.cat([normals, colors]).to(torch.float16)
+            sync(); t4 = time.time()
+        return (t0, t1, t2, t3, t4), views, frames, dict(pipe.substage_seconds)
+
+    skew = getattr(args, "inflight_skew", None)
+    skew = (4.2 / K if skew is None else float(skew)) if on_gpu else 0.0
+    slots = int(getattr(args, "nsr_slots", 0) or 0)
+    gate = threading.BoundedSemaphore(slots) if slots > 0 else None
+    for p_ in pipes:
+        if hasattr(p_, "fit_gate"):
+            p_.fit_gate = gate
+
+    def region(n_drawings, timed):
+        done = queue.Queue()
+
+        def worker(k):
+            try:
+                if on_gpu:
+                    torch.cuda.set_device(dev)
+                if k and skew > 0:
+                    time.sleep(skew * k)              # the workers start a fraction of a drawing apart
+                for j in range(k, n_drawings, K):
+                    done.put((j, one(pipes[k], streams[k], j, timed)))
+            except BaseException as e:          # surfaces in the main thread
+                done.put((-1, e))
+        th = [threading.Thread(target=worker, args=(k,), daemon=True) for k in range(K)]
+        for t in th:
+            t.start()
+        for _ in range(n_drawings):
+            j, res = done.get()
+            if j < 0:
+                raise res
+            (t0, t1, t2, t3, t4), views, frames, sub = res
+            tg = time.time()
+            gv = ddist.gather_tensor(views)           # main thread only: one order of collectives per rank
+            gf = ddist.gather_tensor(frames)
+            if timed:
+                for k_, v in zip(stage_t, (t1 - t0, t2 - t1, t3 - t2, t4 - t3, time.time() - tg)):
+                    stage_t[k_] += v
+                for k_ in sub_t:
+                    sub_t[k_] += sub.get(k_, 0.0)
+                lat.append(t4 - t0)
+                if gv is not None:
+                    gathered["views"], gathered["frames"] = gv, gf
+        for t in th:
+            t.join()
+
+    region(args.warmup * K, False)
+    ddist.barrier(); _sync(dev)
+    timer.enabled = True
+    t0 = time.time()
+    region(args.steps * K, True)
+    _sync(dev); ddist.barrier()
+    elapsed = ddist.max_over_ranks(time.time() - t0, dev)
+    timer.enabled = False
+    info = {"latency": {"mean": sum(lat) / max(len(lat), 1), "max": max(lat) if lat else None,
+                        "drawings": len(lat)},
+            "schedule": {"start_skew_s": skew, "nsr_slots": slots}}
+    # one drawing alone, beside the clock: the kernel families without co-running drawings
+    if rank == 0 and hasattr(timer, "fam"):
+        concurrent = timer.summary()
+        saved = (timer.fam, dict(timer._calls))
+        from drawingspinup_amd.nsr import system as nsr_system
+        saved_tot = nsr_system.native_timing["totals"]
+        timer.fam, timer._calls, nsr_system.native_timing["totals"] = {}, {}, {}
+        timer.enabled = True
+        one(pipes[0], streams[0], 0, True)
+        _sync(dev)
+        timer.enabled = False
+        rows = timer.summary()
+        info["alone"] = [{k: r[k] for k in ("kernel", "launches", "avg_launch_ms", "achieved", "peak", "unit", "frac")
+                          if k in r} | ({"bound_actual_frac": r["bound_actual"]["frac"]} if "bound_actual" in r else {})
+                         for r in rows[:3]]
+        timer.fam, timer._calls = saved
+        nsr_system.native_timing["totals"] = saved_tot
+        del concurrent
+    return elapsed, info
+
+
 _PMC_CACHE = []
 
 
@@ -397,10 +522,30 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
     with a stub); None builds the real one."""
     from drawingspinup_amd.drawing import (DrawingPipeline, synthetic_drawing, synthetic_edges,
                                            synthetic_frames)
+    stub = pipe is not None
+    stub_list = list(pipe) if isinstance(pipe, (list, tuple)) else None      # tests: one stub per drawing in flight
+    if stub_list:
+        pipe = stub_list[0]
     if pipe is None:
         pipe = DrawingPipeline(dev, seed=0, mv_steps=args.mv_steps, nsr_steps=args.nsr_steps,
                                n_frames=args.frames)
     bcast_bytes = sum(ddist.broadcast_module(m, 0) for m in pipe.shared_modules())
+    # drawings in flight: one pipeline (own module instances: the per-module caches are not shared
+    # between threads; same seed = same random weights) per concurrent drawing
+    pipes = [pipe]
+    if stub_list:
+        for p2 in stub_list[1:]:
+            for m in p2.shared_modules():
+                ddist.broadcast_module(m, 0)
+            pipes.append(p2)
+    if not stub:
+        for _ in range(max(1, int(getattr(args, "inflight", 1))) - 1):
+            p2 = DrawingPipeline(dev, seed=0, mv_steps=args.mv_steps, nsr_steps=args.nsr_steps,
+                                 n_frames=args.frames)
+            for m in p2.shared_modules():
+                ddist.broadcast_module(m, 0)
+            p2.time_substages = True
+            pipes.append(p2)
     stage_t = {"contour": 0.0, "mv": 0.0, "nsr": 0.0, "style": 0.0, "gather": 0.0}
     sub_t = {"nsr_matting": 0.0, "nsr_fit": 0.0, "nsr_export": 0.0, "nsr_post": 0.0}
     pipe.time_substages = True               # one extra synchronize between fit and export
@@ -410,8 +555,9 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
     def make_inputs(seed):
         fr = synthetic_frames(seed, args.frames, device=dev)
         return (synthetic_drawing(seed, device=dev), fr, synthetic_edges(fr))
-    inputs = {(False, w): make_inputs(1000 + rank * 100 + w) for w in range(args.warmup)}
-    inputs.update({(True, s): make_inputs(rank * 100 + s) for s in range(args.steps)})
+    n_in = len(pipes)
+    inputs = {(False, w): make_inputs(1000 + rank * 100 + w) for w in range(args.warmup * n_in)}
+    inputs.update({(True, s): make_inputs(rank * 100 + s) for s in range(args.steps * n_in)})
     _sync(dev)
     gathered = {}
 
@@ -442,12 +588,19 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
                 gathered["views"], gathered["frames"] = views, out_frames
         return colors, inside.sum(), frames
 
-    elapsed, last = _timed_loop(args, ddist, dev, timer, one_drawing)
+    inflight = len(pipes)
+    flight = None
+    if inflight == 1:
+        elapsed, last = _timed_loop(args, ddist, dev, timer, one_drawing)
+    else:
+        elapsed, flight = _inflight_loop(args, ddist, rank, dev, timer, pipes, inputs, stage_t, sub_t, gathered)
     if rank != 0:
         return None
     assert len(gathered["views"]) == world and len(gathered["frames"]) == world
-    per = {k: v / args.steps for k, v in stage_t.items()}
-    per.update({k: v / args.steps for k, v in sub_t.items()})
+    # seconds per DRAWING and stage (with drawings in flight: wall time of the stage on its stream,
+    # beside the other drawings' kernels — the stages of one drawing then add up to its latency)
+    per = {k: v / (args.steps * inflight) for k, v in stage_t.items()}
+    per.update({k: v / (args.steps * inflight) for k, v in sub_t.items()})
     # The clock runs the reference's arithmetic per operator: stage 1's deform_conv2d layers in exact
     # f32 (torchvision im2col + f32 addmm, TF32 off by default), stage 2's nn.Conv2d layers on bf16 x 3
     # products (finer than the cuDNN TF32 the reference gets by default), IS-Net in exact f32 (f32
@@ -487,16 +640,29 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
                                              "(roofline.traffic_source, tools/pmc_round5.sh) relative to "
                                              "that workload's algorithmic bytes, applied to this run's "
                                              "mean algorithmic bytes per launch"})
+    if flight and roof is not None:
+        # kernel timing of ONE drawing alone beside the clock (the timed region's event pairs see the
+        # kernels of the other drawings in flight inside their intervals)
+        roof["in_flight"] = inflight
+        roof["note_in_flight"] = ("avg_launch_ms / achieved / frac are HIP-event intervals inside the timed region, "
+                                  "where %d drawings share the GPU: an interval contains the co-running kernels' "
+                                  "share of the machine; roofline.alone = the same families with one drawing alone "
+                                  "on the GPU (one more drawing after the clock)" % inflight)
+        roof["alone"] = flight.get("alone")
     out = {
         "metric": "drawings/sec end-to-end (512x512, 6 views, 24 frames)",
-        "value": world * args.steps / elapsed, "unit": "drawings/s", "n_gpus": world,
+        "value": world * inflight * args.steps / elapsed, "unit": "drawings/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f16 (diffusion) / f16 table + f32 MLP (NSR) / f32 (stage-1 deformable convolutions, "
                  "IS-Net, contour) / f32 with bf16 x 3 products (stage-2 convolutions; the reference: "
                  "cuDNN TF32)",
         "data": "synthetic",
-        "config": {"workload": "one drawing per GPU: contour removal (FFC-ResNet generator, masks, host "
+        "config": {"workload": ("%d drawings in flight per GPU (a step = %d drawings per GPU: one thread + one "
+                                "stream + one pipeline instance each, every drawing the full chain below; "
+                                "latency per drawing in config.latency_s), each drawing: " % (inflight, inflight)
+                                if inflight > 1 else "one drawing per GPU: ") +
+                               "contour removal (FFC-ResNet generator, masks, host "
                                "TELEA inpainting, 512^2) -> 6-view diffusion (%d DDIM steps, B=12) -> "
                                "IS-Net matting forward on the four 1024^2 side views (mv.py:113-150; random "
                                "weights: the filled-silhouette stand-in supplies the masks) -> NSR "
@@ -509,7 +675,10 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
                                "and 1024 -> 2048 LANCZOS) is Pillow's arithmetic restated on the device, "
                                "bit for bit (tests/test_mv_preprocess.py), on the 8-bit images the "
                                "reference's PNG hand-offs hold" % (args.mv_steps, args.nsr_steps, args.frames),
-                   "drawings_per_step": world, "parallelism": f"replica-per-drawing x{world}",
+                   "drawings_per_step": world * inflight,
+                   "parallelism": f"replica-per-drawing x{world}" + (f", {inflight} in flight per GPU" if inflight > 1 else ""),
+                   "latency_s": flight.get("latency") if flight else None,
+                   "inflight_schedule": flight.get("schedule") if flight else None,
                    # arithmetic per stage next to the reference's own (file:line in DESIGN.md 4)
                    "stage_dtype": {
                        "contour": "f32 (exact f32 MFMA; reference: cuDNN / cuFFT f32)",

@@ -322,6 +322,15 @@ def ptr(t, dtype=None):
     return C.c_void_p(t.data_ptr())
 
 
+def publish_sync(device=None):
+    """Before a lazily built device tensor goes into a process-wide cache: wait for the stream that
+    produced it.  Several drawings may be in flight on one GPU (one Python thread + one stream each,
+    bench.py --inflight): another thread's stream must not read a cached table ahead of the copies /
+    kernels that fill it."""
+    if torch.cuda.is_available() and torch.cuda.is_initialized() and (device is None or torch.device(device).type == "cuda"):
+        torch.cuda.current_stream(device).synchronize()
+
+
 def stream():
     """Raw handle of torch's current stream on the current device.  (The public
     torch.cuda.current_stream() wrapper costs ~9 us per call: 0.17 ms of a 2 ms optimisation

@@ -45,6 +45,8 @@ def _dft_mats(n, half, device, dtype):
         s = 1.0 / math.sqrt(n)
         m = ((torch.cos(ang) * s).to(device=device, dtype=dtype),
              (torch.sin(ang) * s).to(device=device, dtype=dtype))
+        from .._lib import publish_sync
+        publish_sync(device)
         _DFT_CACHE[key] = m
     return m
 

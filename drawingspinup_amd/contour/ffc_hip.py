@@ -67,6 +67,8 @@ def _mats(h, w, device):
         inv_w = torch.cat([torch.cat([cm, -sm], 1), torch.cat([sm, cm], 1)], 0)   # (2w, 2k)
         inv_h = torch.cat([ch, -sh], 1)                              # (h, 2h): cos Re U - sin Im U
         m = tuple(t.contiguous() for t in (fwd_h, fwd_w, inv_w, inv_h))
+        from .._lib import publish_sync
+        publish_sync(device)
         M._DFT_CACHE[key] = m
     return m
 

@@ -86,8 +86,12 @@ class DrawingPipeline:
         self.device = torch.device(device)
         self.mv_steps, self.nsr_steps, self.n_frames = mv_steps, nsr_steps, n_frames
         self.style_batch = 4                 # frames per generator call
-        self.time_substages = False          # bench.py: split the NSR stage into fit / export
+        self.time_substages = False          # bench.py: split the NSR stage into fit / export (the
+        #                                      synchronisations are the CURRENT STREAM's: several drawings
+        #                                      may be in flight on one GPU, one stream + one pipeline each)
         self.substage_seconds = {}
+        self.fit_gate = None                 # a semaphore shared by the pipelines of one GPU: how many
+        #                                      drawings may be inside the NSR optimisation at a time
         self.export_resolution = export_resolution
         self.mesh_post = mesh_post           # the reference's export switches (remesh, smooth, cbp, shear)
         self.mv = build_random_pipeline(self.device, seed, with_clip=with_clip) if with_mv else None
@@ -195,7 +199,7 @@ class DrawingPipeline:
         # side_mask_from_prediction — the reference runs a CPU ONNX matting model there)
         mattes = None
         if self.time_substages:
-            torch.cuda.synchronize(dev)
+            torch.cuda.current_stream(dev).synchronize()
         t_m = time.time()
         if self.isnet is not None:
             # remove_background (mv.py:134-150) on the 8-bit side-view images, in memory: (x / 255 -
@@ -207,7 +211,7 @@ class DrawingPipeline:
                 mattes = (self.isnet(u8.float() / 255.0 - 0.5).clamp(0, 1) * 255).to(torch.uint8)[:, 0]
             self.last_side_mattes = mattes
         if self.time_substages:
-            torch.cuda.synchronize(dev)
+            torch.cuda.current_stream(dev).synchronize()
             self.substage_seconds["nsr_matting"] = time.time() - t_m
         if mattes is not None and self.isnet_trained:
             side = torch.zeros(col.shape[:3], dtype=torch.bool, device=dev)
@@ -224,10 +228,16 @@ class DrawingPipeline:
                              for v in VIEWS])
         data = OrthoData(col, masks, n_world, poses, dev)
         system = OrthoNeuSSystem(device=dev, seed=seed)
-        t0 = time.time()
-        system.fit(data, max_steps=self.nsr_steps)
-        if self.time_substages:
-            torch.cuda.synchronize(dev)
+        if self.fit_gate is not None:
+            self.fit_gate.acquire()
+        try:
+            t0 = time.time()
+            system.fit(data, max_steps=self.nsr_steps)
+            if self.time_substages or self.fit_gate is not None:
+                torch.cuda.current_stream(dev).synchronize()
+        finally:
+            if self.fit_gate is not None:
+                self.fit_gate.release()
         t1 = time.time()
         # export (neus_ortho.py:183-200): smoothed binary volumes, front-mask cutting with the
         # drawing's own alpha (char/mask.png, rotated as ortho.py:155-156), marching cubes, colours
@@ -241,7 +251,7 @@ class DrawingPipeline:
                                   with_colors=not self.mesh_post, face_count=50000 if self.mesh_post else None)
         self.last_mesh = mesh
         if self.time_substages:
-            torch.cuda.synchronize(dev)
+            torch.cuda.current_stream(dev).synchronize()
         t2 = time.time()
         if self.mesh_post and mesh["faces"].shape[0]:
             # save_mesh (mesh_utils.py:25-73): Laplacian smoothing, colour back-projection from the
@@ -257,7 +267,7 @@ class DrawingPipeline:
                                         smoothing=True, shearing=True, color_back_projection=cbp)
             self.last_mesh_post = {"verts": v, "faces": f, "colors": c}
         if self.time_substages:
-            torch.cuda.synchronize(dev)
+            torch.cuda.current_stream(dev).synchronize()
             self.substage_seconds.update({"nsr_fit": t1 - t0, "nsr_export": t2 - t1,
                                           "nsr_post": time.time() - t2})
         return system, mesh["binary"]

@@ -76,7 +76,10 @@ _COEFF_CACHE = {}
 def _coeffs(in_size, out_size, device, filt="bicubic"):
     key = (in_size, out_size, str(device), filt)
     if key not in _COEFF_CACHE:
-        _COEFF_CACHE[key] = torch.from_numpy(_coeff_matrix(in_size, out_size, filt)).to(device)
+        t = torch.from_numpy(_coeff_matrix(in_size, out_size, filt)).to(device)
+        from .._lib import publish_sync
+        publish_sync(device)
+        _COEFF_CACHE[key] = t
     return _COEFF_CACHE[key]
 
 

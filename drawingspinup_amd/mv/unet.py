@@ -159,8 +159,8 @@ class FeedForward(nn.Module):
         return ops.linear_f16(h, self.net[2].weight, self.net[2].bias, residual=residual)
 
 
-# lazily built, process-wide, NOT locked: the package drives one GPU from one Python thread per process
-# (one process per GPU); guard with a mutex before calling these paths from several threads
+# lazily built, process-wide; an entry is published only once the stream that filled it has finished
+# (several drawings may be in flight on one GPU, each on its own thread + stream)
 _SEG_CACHE = {}
 
 
@@ -172,7 +172,10 @@ def _seg_table(kind, B, num_views, device):
         else:                 # joint, transformer_mv2d.py:878-883: chunk(2) / cat seq / cat batch
             half = B // 2
             rows = [[b % half, b % half + half] for b in range(B)]
-        _SEG_CACHE[key] = torch.tensor(rows, dtype=torch.int32, device=device)
+        t = torch.tensor(rows, dtype=torch.int32, device=device)
+        from .._lib import publish_sync
+        publish_sync(device)
+        _SEG_CACHE[key] = t
     return _SEG_CACHE[key]
 
 

@@ -317,8 +317,7 @@ def ray_march(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step):
     return ray_indices, t_starts, t_ends, offsets, counts
 
 
-# lazily built, process-wide, NOT locked: the package drives one GPU from one Python thread per process
-# (one process per GPU); guard with a mutex before calling these paths from several threads
+# lazily built, process-wide; keyed by stream: drawings in flight on one GPU run on their own streams
 _MARCH_SCRATCH = {}
 
 
@@ -333,7 +332,7 @@ def ray_march_single_pass(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, 
     a = (C.c_float * 6)(*[float(v) for v in aabb6])
     diag = math.sqrt(sum((aabb6[3 + d] - aabb6[d]) ** 2 for d in range(3)))
     cap = int(diag / step) + 8
-    key = (str(dev), cap)
+    key = (str(dev), cap, stream().value)          # scratch rows belong to ONE stream's launches
     sc = _MARCH_SCRATCH.get(key)
     if sc is None or sc[0].shape[0] < n * cap:
         rows = max(n, 8192)
@@ -378,7 +377,7 @@ def ray_march_begin(rays_o, rays_d, t_min, t_max, aabb6, occ_binary, res, step):
     a = (C.c_float * 6)(*[float(v) for v in aabb6])
     diag = math.sqrt(sum((aabb6[3 + d] - aabb6[d]) ** 2 for d in range(3)))
     cap = int(diag / step) + 8
-    key = (str(dev), cap)
+    key = (str(dev), cap, stream().value)
     sc = _MARCH_SCRATCH.get(key)
     if sc is None or sc[0].shape[0] < n * cap:
         rows = max(n, 8192)
@@ -872,7 +871,9 @@ def deform_plan(offset):
     key = (offset.data_ptr(), tuple(offset.shape), str(offset.device))
     plan = _DEFORM_PLANS.get(key)
     if plan is None:
-        plan = _DEFORM_PLANS[key] = DeformPlan(offset)
+        plan = DeformPlan(offset)
+        _lib.publish_sync(offset.device)
+        _DEFORM_PLANS[key] = plan
     return plan
 
 
@@ -1070,7 +1071,8 @@ def conv_weight_okc(weight):
 
 _TILE_COUNTERS = {}
 _N_TILE_COUNTERS = 1 << 16
-SPLITK_FIXUP = False          # in-kernel split-K fix-up instead of the separate reduce launch (A/B)
+import os as _os
+SPLITK_FIXUP = _os.environ.get("DSU_SPLITK_FIXUP", "0") == "1"   # in-kernel split-K fix-up instead of the separate reduce launch (A/B)
 
 
 def _tile_counters(device):

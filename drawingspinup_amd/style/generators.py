@@ -68,7 +68,10 @@ def generate_coordinates(batch_size, input_height, input_width, device="cuda"):
             ang = torch.add(theta, torch.mul(torch.div(PI[0], 8.0), m))
             coords[:, :, 2 * k] = torch.add(torch.cos(ang), shift[k][0])
             coords[:, :, 2 * k + 1] = torch.add(torch.sin(ang), shift[k][1])
-        _COORD_CACHE[key] = coords.permute(2, 0, 1).contiguous().to(device)
+        t = coords.permute(2, 0, 1).contiguous().to(device)
+        from .._lib import publish_sync
+        publish_sync(device)
+        _COORD_CACHE[key] = t
     c = _COORD_CACHE[key]
     return c.unsqueeze(0).expand(batch_size, -1, -1, -1)
 

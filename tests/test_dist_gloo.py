@@ -125,8 +125,13 @@ def _bench_worker(rank, world, port, q):
     args = bench.parse(["--gpus", str(world), "--config", "drawing", "--frames", "3", "--steps", "2",
                         "--warmup", "1", "--no-cpu-baseline"])
     out_d = bench.bench_drawing(args, ddist, r, w, dev, _StubTimer(), pipe=pipe)
+    # the same with two drawings in flight per rank (bench._inflight_loop: worker threads, the
+    # collectives kept in one order by the main thread)
+    args = bench.parse(["--gpus", str(world), "--config", "drawing", "--frames", "3", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline", "--inflight", "2"])
+    out_i = bench.bench_drawing(args, ddist, r, w, dev, _StubTimer(), pipe=[pipe, _StubPipe(rank + 7)])
     ddist.barrier()
-    q.put((rank, threads, out_f, want, out_d))
+    q.put((rank, threads, out_f, want, out_d, out_i))
     torch.distributed.destroy_process_group()
 
 
@@ -141,7 +146,13 @@ def test_bench_frames_and_drawing_paths_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, th0, f0, want, d0), (_, th1, f1, _, d1) = res
+    (_, th0, f0, want, d0, i0), (_, th1, f1, _, d1, i1) = res
+    # two in flight: a step is 2 drawings per rank, the value counts all of them, every drawing's
+    # outputs were gathered (the last gather holds both ranks' tensors), latency is reported
+    assert i1 is None and i0["config"]["drawings_per_step"] == 4 and i0["steps"] == 2
+    assert abs(i0["value"] - 2 * 2 * 2 / (i0["ms_per_step"] * 2e-3)) < 1e-6 * i0["value"]
+    assert i0["config"]["latency_s"]["drawings"] == 4 and "2 drawings in flight" in i0["config"]["workload"]
+    assert i0["config"]["gathered_bytes_per_step"] == 2 * (12 * 3 * 16 * 16 * 2 + 3 * 4 * 512 * 512)
     cores = len(os.sched_getaffinity(0))
     assert th0 == th1 == max(1, cores // 2)                # the ranks split the host cores
     assert f1 is None and d1 is None                       # only rank 0 reports
