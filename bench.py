@@ -64,7 +64,7 @@ def parse(argv=None):
                     help="at most this many drawings inside the NSR optimisation at a time (0 = no limit)")
     a = ap.parse_args(argv)
     if a.steps is None:
-        a.steps = {"drawing": 1, "unet": 50, "nsr50k": 50, "frames": 3}[a.config]
+        a.steps = {"drawing": 2, "unet": 50, "nsr50k": 50, "frames": 3}[a.config]
     if a.warmup is None:
         a.warmup = {"drawing": 1, "unet": 5, "nsr50k": 10, "frames": 1}[a.config]
     return a
@@ -434,9 +434,9 @@ _PMC_CACHE = []
 
 
 def _pmc():
-    """profiles/round5_pmc.json (tools/pmc_round5.sh; round 4's file when it is absent) or None."""
+    """profiles/round6_pmc.json (tools/pmc_round6.sh; the previous rounds. files when it is absent) or None."""
     if not _PMC_CACHE:
-        for name in ("round5_pmc.json", "round4_pmc.json"):
+        for name in ("round6_pmc.json", "round5_pmc.json", "round4_pmc.json"):
             try:
                 with open(os.path.join(ROOT, "profiles", name)) as f:
                     _PMC_CACHE.append(dict(json.load(f), source="profiles/" + name))
@@ -473,13 +473,13 @@ def _roofline(timer, extra=None):
     top["timed_launch_stride"] = timer.stride
     # HBM-side bytes per launch of the dominant family: not collectable inside this process (PMC
     # counters need their own rocprofv3 --pmc passes, FETCH_SIZE and WRITE_SIZE one pass each, as
-    # MI355X_MICROARCH.md prescribes).  profiles/round5_pmc.json holds this round's passes over
+    # MI355X_MICROARCH.md prescribes).  profiles/round6_pmc.json holds this round's passes over
     # tools/pmc_sdf_kernels.py (N = 262 144 Morton-ordered samples, 5 levels): per kernel
     # (2 x FETCH_SIZE + WRITE_SIZE) — the guide's gfx950 correction for coalesced reads — and the
     # workload's algorithmic bytes; the measured ratio is applied to this run's mean algorithmic
     # bytes per launch.
     pmc = _pmc()
-    fam = {"sdf_fd_bwd": ("sdf_fd_bwd_mfma_kernel", "sdf_fd_scatter_kernel"),
+    fam = {"sdf_fd_bwd": ("sdf_fd_bwd_pipe_kernel", "sdf_fd_bwd_mfma_kernel", "sdf_fd_scatter_kernel"),
            "sdf_fd_fwd": ("sdf_fd_fwd_kernel", "sdf_fd_fwd_shared_kernel")}
     top["traffic"] = None
     if pmc and top["kernel"] in fam:
@@ -637,7 +637,7 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
                              "traffic_note": "HBM-side bytes per launch of the dominant family "
                                              "(MLP part + scatter): (2 x FETCH_SIZE + "
                                              "WRITE_SIZE) of separate rocprofv3 --pmc passes "
-                                             "(roofline.traffic_source, tools/pmc_round5.sh) relative to "
+                                             "(roofline.traffic_source, tools/pmc_round6.sh) relative to "
                                              "that workload's algorithmic bytes, applied to this run's "
                                              "mean algorithmic bytes per launch"})
     if flight and roof is not None:
