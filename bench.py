@@ -539,11 +539,17 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
                 ddist.broadcast_module(m, 0)
             pipes.append(p2)
     if not stub:
+        import copy
         for _ in range(max(1, int(getattr(args, "inflight", 1))) - 1):
-            p2 = DrawingPipeline(dev, seed=0, mv_steps=args.mv_steps, nsr_steps=args.nsr_steps,
-                                 n_frames=args.frames)
-            for m in p2.shared_modules():
-                ddist.broadcast_module(m, 0)
+            try:
+                # a device-side copy of the (already broadcast) first instance: no second random
+                # initialisation of 910 M parameters on the host, no second broadcast
+                p2 = copy.deepcopy(pipe)
+            except Exception:                                          # noqa: BLE001
+                p2 = DrawingPipeline(dev, seed=0, mv_steps=args.mv_steps, nsr_steps=args.nsr_steps,
+                                     n_frames=args.frames)
+                for m in p2.shared_modules():
+                    ddist.broadcast_module(m, 0)
             p2.time_substages = True
             pipes.append(p2)
     stage_t = {"contour": 0.0, "mv": 0.0, "nsr": 0.0, "style": 0.0, "gather": 0.0}

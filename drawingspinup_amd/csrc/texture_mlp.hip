@@ -15,6 +15,19 @@
 // go through LDS, 32 samples at a time.  Exact f32 throughout.
 #include "common.h"
 
+// -DDSU_TEX_PROF (variant build only): per-phase shader-clock totals of the backward kernel, summed
+// over the waves into dsu_tex_prof[] and read back with dsu_debug_tex_prof() (tools/texture_phase_clocks.py)
+#ifdef DSU_TEX_PROF
+__device__ unsigned long long dsu_tex_prof[16];
+#define TEX_PROF_DECL unsigned long long pt__[16] = {0}; unsigned long long pc__ = __builtin_readcyclecounter();
+#define TEX_PROF(i) { const unsigned long long n__ = __builtin_readcyclecounter(); pt__[i] += n__ - pc__; pc__ = n__; }
+#define TEX_PROF_END if ((threadIdx.x & 63) == 0) { for (int i__ = 0; i__ < 16; ++i__) atomicAdd(&dsu_tex_prof[i__], pt__[i__]); }
+#else
+#define TEX_PROF_DECL
+#define TEX_PROF(i)
+#define TEX_PROF_END
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -273,6 +286,7 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
     const float* __restrict__ rgb, const float* __restrict__ d_rgb, int64_t n,
     float* __restrict__ d_x, float* __restrict__ partials) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
+  TEX_PROF_DECL
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
   float* st = lds + L_WEND + wave * STAGE_F;
   float* sP = st + S_P;
@@ -328,6 +342,7 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
     const int64_t ii = valid ? i : r1 - 1;
     const int64_t wave_first = base + wave * 64;
     if (wave_first >= r1) continue;                    // wave-uniform, no workgroup barrier in the loop
+    TEX_PROF(9)   // (first block: kernel prologue; later: loop overhead)
     float in[TIN];
     if (SHADE) {
       float inv_len;
@@ -350,9 +365,11 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
 #pragma unroll 1
     for (int a = 0; a < 2; ++a) {
       if (wave_first + a * 32 >= r1) continue;
+      TEX_PROF(0)   // rows of the block / previous half's tail
       f32x16 H0[2], H1[2];
       forward_half(lds, in, a, l31, h, H0, H1);
       // dz of the samples of half a, in every lane of the pair
+      TEX_PROF(1)   // forward recompute
       float dza[TOUT];
 #pragma unroll
       for (int o = 0; o < TOUT; ++o) {
@@ -372,6 +389,7 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
           D1[T][r] = H1[T][r] > 0.0f ? v : 0.0f;
           gb1[T][r] += D1[T][r];
         }
+      TEX_PROF(2)   // dPre1
       // ---- gW2^T[unit][o] += sum_samples H1[sample][unit] * dz[sample][o]
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
@@ -409,6 +427,7 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
         }
       }
       // ---- gW1[i][j] += sum_samples dPre1[sample][i] * H0[sample][j]
+      TEX_PROF(3)   // gW2
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int T = 0; T < 2; ++T)
@@ -447,6 +466,7 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
         }
       }
       // ---- dH0^T = W1^T . dPre1^T, then dPre0 = dH0 * relu'(H0)
+      TEX_PROF(4)   // gW1
       f32x16 D0[2];
 #pragma unroll
       for (int T = 0; T < 2; ++T)
@@ -511,6 +531,7 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
 #pragma unroll
         for (int r = 0; r < 16; ++r) D0[T][r] = H0[T][r] > 0.0f ? D0[T][r] : 0.0f;
       // ---- gW0[i][k] += sum_samples dPre0[sample][i] * In[sample][k]  (k = 16: ones -> gb0)
+      TEX_PROF(5)   // dH0 + relu'
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int T = 0; T < 2; ++T)
@@ -552,6 +573,7 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
         }
       }
       // ---- dIn^T = W0^T . dPre0^T : row k = (r&3) + 8(r>>2) + 4h of the sample in column l31
+      TEX_PROF(6)   // gW0
       f32x16 din;
 #pragma unroll
       for (int r = 0; r < 16; ++r) din[r] = 0.0f;
@@ -622,6 +644,7 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
       }
 #endif
       const int64_t si = wave_first + a * 32 + l31;              // the sample of column l31
+      TEX_PROF(7)   // dIn
       if (si < r1) {
         if (SHADE) {
           // lane h holds components 8q + 4h + {0..3}: h = 0 -> 0-3, 8-11; h = 1 -> 4-7, 12-15
@@ -654,38 +677,78 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
                 make_float4(din[4 * q], din[4 * q + 1], din[4 * q + 2], din[4 * q + 3]);
         }
       }
+      TEX_PROF(11)  // write-out of the half (sdf gradient / d_normal loads + stores)
     }
   }
 
-  // ---- workgroup reduction of the parameter-gradient tiles -> one partial vector per workgroup
+  // ---- workgroup reduction of the parameter-gradient tiles -> one partial vector per workgroup.
+  // Plain stores into per-wave images and a two-step tree (waves 2, 3 -> 0, 1; wave 1 -> 0), wave 0
+  // writes the sums out.  The first form added all four waves' tiles into ONE image with LDS float
+  // atomics (160 per lane, every address hit by all four waves): 112 k of the kernel's 332 k clocks
+  // per wave (phase clocks, profiles/round6_texture_phase_clocks.txt).  The whole LDS is free here.
   __syncthreads();
-  float* red = lds + L_WEND;                       // staging area reused: PART_N <= 4 * STAGE_F
-  for (int v = threadIdx.x; v < PART_N; v += blockDim.x) red[v] = 0.0f;
-  __syncthreads();
+  TEX_PROF(8)   // last epilogue stores + wait for the other waves
+  static_assert(3 * PART_STRIDE <= BWD_LDS_F, "three partial images fit the kernel's LDS");
+  float gb1s[2][16], gb2s[TOUT];
 #pragma unroll
   for (int T = 0; T < 2; ++T)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = feat_of(T, r, h);
-      atomicAdd(&red[P_GW1 + row * 64 + l31], gw1[T][0][r]);
-      atomicAdd(&red[P_GW1 + row * 64 + 32 + l31], gw1[T][1][r]);
-      atomicAdd(&red[P_GW0 + row * 32 + l31], gw0[T][r]);
-      atomicAdd(&red[P_GW2 + row * 32 + l31], gw2[T][r]);
-      float s = gb1[T][r];                          // sum over the 32 sample columns of this half
+      float s_ = gb1[T][r];                         // sum over the 32 sample columns of this half
 #pragma unroll
-      for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
-      if (l31 == 0) atomicAdd(&red[P_GB1 + row], s);
+      for (int o = 16; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
+      gb1s[T][r] = s_;
     }
 #pragma unroll
   for (int o = 0; o < TOUT; ++o) {
-    float s = gb2[o];
+    float s_ = gb2[o];
 #pragma unroll
-    for (int k = 32; k > 0; k >>= 1) s += __shfl_xor(s, k);
-    if (lane == 0) atomicAdd(&red[P_GB2 + o], s);
+    for (int k = 32; k > 0; k >>= 1) s_ += __shfl_xor(s_, k);
+    gb2s[o] = s_;
   }
+  auto store_own = [&](float* dst) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = feat_of(T, r, h);
+        dst[P_GW1 + row * 64 + l31] = gw1[T][0][r];
+        dst[P_GW1 + row * 64 + 32 + l31] = gw1[T][1][r];
+        dst[P_GW0 + row * 32 + l31] = gw0[T][r];
+        dst[P_GW2 + row * 32 + l31] = gw2[T][r];
+        if (l31 == 0) dst[P_GB1 + row] = gb1s[T][r];
+      }
+    if (lane == 0) {
+#pragma unroll
+      for (int o = 0; o < TOUT; ++o) dst[P_GB2 + o] = gb2s[o];
+    }
+  };
+  auto add_from = [&](const float* src) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = feat_of(T, r, h);
+        gw1[T][0][r] += src[P_GW1 + row * 64 + l31];
+        gw1[T][1][r] += src[P_GW1 + row * 64 + 32 + l31];
+        gw0[T][r] += src[P_GW0 + row * 32 + l31];
+        gw2[T][r] += src[P_GW2 + row * 32 + l31];
+        gb1s[T][r] += src[P_GB1 + row];
+      }
+#pragma unroll
+    for (int o = 0; o < TOUT; ++o) gb2s[o] += src[P_GB2 + o];
+  };
+  if (wave >= 2) store_own(lds + (wave - 2) * PART_STRIDE);
   __syncthreads();
-  float* part = partials + (size_t)blockIdx.x * PART_STRIDE;
-  for (int v = threadIdx.x; v < PART_N; v += blockDim.x) part[v] = red[v];
+  if (wave < 2) add_from(lds + wave * PART_STRIDE);
+  if (wave == 1) store_own(lds + 2 * PART_STRIDE);
+  __syncthreads();
+  if (wave == 0) {
+    add_from(lds + 2 * PART_STRIDE);
+    store_own(partials + (size_t)blockIdx.x * PART_STRIDE);
+  }
+  TEX_PROF(10)  // workgroup reduction
+  TEX_PROF_END
 }
 
 __global__ void texture_reduce_kernel(const float* __restrict__ partials, int nblocks,
@@ -857,5 +920,17 @@ int dsu_texture_bwd_shaded_partials(const dsu_tex_mlp* mlp, const float* feature
   red->n = PART_N;
   return DSU_OK;
 }
+
+#ifdef DSU_TEX_PROF
+int dsu_debug_tex_prof(unsigned long long* out16, int reset) {
+  if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(dsu_tex_prof), 16 * sizeof(unsigned long long)) != hipSuccess)
+    return DSU_ELAUNCH;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(dsu_tex_prof), z, sizeof(z)) != hipSuccess) return DSU_ELAUNCH;
+  }
+  return DSU_OK;
+}
+#endif
 
 }  // extern "C"
