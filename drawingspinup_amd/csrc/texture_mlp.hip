@@ -46,6 +46,7 @@ __device__ __forceinline__ void bf16_split8(const float* x, bf16x8& hi, bf16x8& 
 }
 
 constexpr int TIN = 16, THID = 64, TOUT = 3;
+typedef __bf16 bf16x2v __attribute__((ext_vector_type(2)));
 // LDS layout (floats)
 constexpr int W1_ROW = 65;                       // padded row: conflict-free by row AND by column
 constexpr int W0_ROW = 17;
@@ -58,8 +59,23 @@ constexpr int L_B2 = L_B1 + THID;                // 5568
 constexpr int L_WEND = L_B2 + 8;                 // 5576
 // per-wave staging (backward)
 constexpr int SD_ROW = 68, SIN_ROW = 20, SDO_ROW = 4;
+#ifdef DSU_TEX_GEMM_F32
+// (variant build: the contraction-over-samples GEMMs in exact f32, rounds 2-5)
 constexpr int S_P = 0, S_H = 32 * SD_ROW, S_IN = 2 * 32 * SD_ROW, S_DO = S_IN + 32 * SIN_ROW;
 constexpr int STAGE_F = S_DO + 32 * SDO_ROW;     // 5120
+#else
+// Transposed bf16 images of the contraction-over-samples GEMMs (gW2, gW1, gW0 as bf16 x 3):
+// [part hi | mid][row = unit (or output / input column)][TROW] bf16, element (row, s) = the value of
+// sample s of the 32-sample half.  TROW = 40 (80-byte rows): the 16-byte fragments of 16 lanes
+// (rows l31, l31 + 1, ...) fall on 16 different bank quads.  Two 64-row images (X, Y) and one
+// 20-row image (S: dz^T, then In^T) per wave.
+constexpr int TROW = 40;
+constexpr int TIMG_B = 2 * 64 * TROW;            // bf16 elements of a 64-row image (hi + mid) = 10 240 B
+constexpr int TSML_B = 2 * 20 * TROW;            // 20-row image
+constexpr int S_X = 0, S_Y = TIMG_B / 2, S_S = TIMG_B;          // float offsets
+constexpr int STAGE_F = TIMG_B + TSML_B / 2;     // 5120 + 800 = 5920 floats
+constexpr int S_P = 0, S_H = 0, S_IN = 0, S_DO = 0;              // (f32 staging areas: unused)
+#endif
 // bf16 images of the backward GEMMs' weight operands, one 16-byte fragment per lane and MFMA:
 //   W1 image [hi|mid][To][Tin][g][lane] : 8 values t -> w1[feat_of(Tin, 8 g + t, h)][32 To + l31]
 //   W0 image [hi|mid][T][g][lane]       : 8 values t -> w0[feat_of(T, 8 g + t, h)][l31] (0 for l31 >= 16)
@@ -273,6 +289,64 @@ __global__ __launch_bounds__(256) void texture_fwd_kernel(dsu_tex_mlp m,
 // SHADE (backward): the gradient of the input row is not stored as (n,16) but pulled back through
 // cat / normalize right here (what shade_prep_bwd_kernel did in a separate launch):
 //   d_feature[s] = d_x[0:13];  dn = d_x[13:16] + d_normal[s];  d_grad[s] = (dn - n (n.dn)) / |grad|
+#ifndef DSU_TEX_GEMM_F32
+// rows = hidden units: the lane's 32 values X[T][r] (unit 32 T + (r & 3) + 8 (r >> 2) + 4 h of the
+// sample in column l31) -> bf16 hi / mid at [unit][l31] of a transposed image
+__device__ __forceinline__ void stage_units_T(__bf16* img, const f32x16 (&X)[2], int l31, int h) {
+  __bf16* base = img + 4 * h * TROW + l31;
+#pragma unroll
+  for (int T = 0; T < 2; ++T)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int u = 32 * T + (r & 3) + 8 * (r >> 2);
+      const float x = X[T][r];
+      const __bf16 hi = (__bf16)x;
+      base[u * TROW] = hi;
+      base[(64 + u) * TROW] = (__bf16)(x - (float)hi);
+    }
+}
+// 16-byte fragment of a transposed image: 8 consecutive samples (k = 16 ks + 8 h ..) of row `row`
+__device__ __forceinline__ bf16x8 frag_T(const __bf16* img, int row, int ks, int h) {
+  return *reinterpret_cast<const bf16x8*>(img + row * TROW + 16 * ks + 8 * h);
+}
+// acc[Ti][Tj] += A^T B over the 32 samples of the half, bf16 x 3: A / B images with 64 / (32 NJ) rows
+// (`rows_b` rows of B are real: lanes beyond them feed zeros)
+template <int NJ>
+__device__ __forceinline__ void gemm_samples_T(f32x16 (&acc0)[NJ], f32x16 (&acc1)[NJ], const __bf16* A,
+                                               int a_mid, const __bf16* B, int b_mid, int rows_b,
+                                               int l31, int h) {
+  bf16x8 z;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.0f;
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    bf16x8 ah[2], am[2], bh[NJ], bm[NJ];
+#pragma unroll
+    for (int Ti = 0; Ti < 2; ++Ti) {
+      ah[Ti] = frag_T(A, 32 * Ti + l31, ks, h);
+      am[Ti] = frag_T(A + a_mid, 32 * Ti + l31, ks, h);
+    }
+#pragma unroll
+    for (int Tj = 0; Tj < NJ; ++Tj) {
+      const int row = 32 * Tj + l31;
+      const bool real = row < rows_b;
+      const bf16x8 vh = frag_T(B, real ? row : 0, ks, h), vm = frag_T(B + b_mid, real ? row : 0, ks, h);
+      bh[Tj] = real ? vh : z;
+      bm[Tj] = real ? vm : z;
+    }
+#pragma unroll
+    for (int Tj = 0; Tj < NJ; ++Tj) {
+      acc0[Tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bh[Tj], acc0[Tj], 0, 0, 0);
+      acc1[Tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bh[Tj], acc1[Tj], 0, 0, 0);
+      acc0[Tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bm[Tj], acc0[Tj], 0, 0, 0);
+      acc1[Tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bm[Tj], acc1[Tj], 0, 0, 0);
+      acc0[Tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[0], bh[Tj], acc0[Tj], 0, 0, 0);
+      acc1[Tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am[1], bh[Tj], acc1[Tj], 0, 0, 0);
+    }
+  }
+}
+#endif
+
 struct ShadeOut {
   const float* d_normal;  // (n,3) from the compositing backward
   float* d_grad;          // (n,3)
@@ -293,6 +367,11 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
   float* sH = st + S_H;
   float* sIn = st + S_IN;
   float* sDo = st + S_DO;
+#ifndef DSU_TEX_GEMM_F32
+  __bf16* tX = reinterpret_cast<__bf16*>(st + S_X);
+  __bf16* tY = reinterpret_cast<__bf16*>(st + S_Y);
+  __bf16* tS = reinterpret_cast<__bf16*>(st + S_S);
+#endif
   load_weights(lds, m);
   __syncthreads();
   {   // bf16 hi / mid fragments of W1 and W0 in the order the backward MFMAs consume them
@@ -391,6 +470,7 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
         }
       TEX_PROF(2)   // dPre1
       // ---- gW2^T[unit][o] += sum_samples H1[sample][unit] * dz[sample][o]
+#ifdef DSU_TEX_GEMM_F32
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int T = 0; T < 2; ++T)
@@ -426,8 +506,31 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
           }
         }
       }
+#else
+      // bf16 x 3 on v_mfma_f32_32x32x16_bf16 (K = 16 samples per MFMA): H1 and dz go to LDS
+      // TRANSPOSED ([unit][sample], bf16 hi / mid, two-byte stores at compile-time offsets), so that
+      // a lane's operand fragment — 8 consecutive samples of one row — is one 16-byte read.
+      // 12 MFMAs of 32 clocks instead of 32 of 64.
+      __builtin_amdgcn_wave_barrier();
+      stage_units_T(tX, H1, l31, h);
+      if (h == a) {
+#pragma unroll
+        for (int o = 0; o < TOUT; ++o) {
+          const __bf16 hi = (__bf16)dz[o];
+          tS[o * TROW + l31] = hi;
+          tS[(20 + o) * TROW + l31] = (__bf16)(dz[o] - (float)hi);
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+      {
+        f32x16 (&g0)[1] = *reinterpret_cast<f32x16 (*)[1]>(&gw2[0]);
+        f32x16 (&g1)[1] = *reinterpret_cast<f32x16 (*)[1]>(&gw2[1]);
+        gemm_samples_T<1>(g0, g1, tX, 64 * TROW, tS, 20 * TROW, TOUT, l31, h);
+      }
+#endif
       // ---- gW1[i][j] += sum_samples dPre1[sample][i] * H0[sample][j]
       TEX_PROF(3)   // gW2
+#ifdef DSU_TEX_GEMM_F32
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int T = 0; T < 2; ++T)
@@ -465,6 +568,13 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
           }
         }
       }
+#else
+      __builtin_amdgcn_wave_barrier();           // (the gW2 reads of X are done: in-order LDS queue of the wave)
+      stage_units_T(tY, D1, l31, h);
+      stage_units_T(tX, H0, l31, h);
+      __builtin_amdgcn_wave_barrier();
+      gemm_samples_T<2>(gw1[0], gw1[1], tY, 64 * TROW, tX, 64 * TROW, 64, l31, h);   // 24 MFMAs instead of 64
+#endif
       // ---- dH0^T = W1^T . dPre1^T, then dPre0 = dH0 * relu'(H0)
       TEX_PROF(4)   // gW1
       f32x16 D0[2];
@@ -532,6 +642,7 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
         for (int r = 0; r < 16; ++r) D0[T][r] = H0[T][r] > 0.0f ? D0[T][r] : 0.0f;
       // ---- gW0[i][k] += sum_samples dPre0[sample][i] * In[sample][k]  (k = 16: ones -> gb0)
       TEX_PROF(5)   // dH0 + relu'
+#ifdef DSU_TEX_GEMM_F32
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
       for (int T = 0; T < 2; ++T)
@@ -572,6 +683,26 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
           }
         }
       }
+#else
+      __builtin_amdgcn_wave_barrier();
+      stage_units_T(tY, D0, l31, h);
+      if (h == a) {
+#pragma unroll
+        for (int k = 0; k < TIN; ++k) {
+          const __bf16 hi = (__bf16)in[k];
+          tS[k * TROW + l31] = hi;
+          tS[(20 + k) * TROW + l31] = (__bf16)(in[k] - (float)hi);
+        }
+        tS[TIN * TROW + l31] = (__bf16)1.0f;               // the ones column -> gb0
+        tS[(20 + TIN) * TROW + l31] = (__bf16)0.0f;
+      }
+      __builtin_amdgcn_wave_barrier();
+      {
+        f32x16 (&g0)[1] = *reinterpret_cast<f32x16 (*)[1]>(&gw0[0]);
+        f32x16 (&g1)[1] = *reinterpret_cast<f32x16 (*)[1]>(&gw0[1]);
+        gemm_samples_T<1>(g0, g1, tY, 64 * TROW, tS, 20 * TROW, TIN + 1, l31, h);   // 12 MFMAs instead of 32
+      }
+#endif
       // ---- dIn^T = W0^T . dPre0^T : row k = (r&3) + 8(r>>2) + 4h of the sample in column l31
       TEX_PROF(6)   // gW0
       f32x16 din;

@@ -16,4 +16,3 @@ for rep in 1 2; do
     else DSU_HIP_LIB=$lib timeout 300 python tools/nsr_stage_ab.py 3000 2>/dev/null | tail -1 | tee -a $O/texture_ab.txt; fi
   done
 done
-DSU_HIP_LIB=$V/libdsu_hip_texprof.so timeout 300 python tools/texture_phase_clocks.py 2>&1 | grep -v Warn | tee $O/phase_clocks_after.txt
