@@ -813,12 +813,17 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
   }
 
   // ---- workgroup reduction of the parameter-gradient tiles -> one partial vector per workgroup.
-  // Plain stores into per-wave images and a two-step tree (waves 2, 3 -> 0, 1; wave 1 -> 0), wave 0
-  // writes the sums out.  The first form added all four waves' tiles into ONE image with LDS float
+  // Plain stores into per-wave images, one barrier, element-wise sums by all threads.  The first form added all four waves' tiles into ONE image with LDS float
   // atomics (160 per lane, every address hit by all four waves): 112 k of the kernel's 332 k clocks
   // per wave (phase clocks, profiles/round6_texture_phase_clocks.txt).  The whole LDS is free here.
   __syncthreads();
   TEX_PROF(8)   // last epilogue stores + wait for the other waves
+#if defined(DSU_TEX_ABL_RED) && DSU_TEX_ABL_RED == 1
+  // (timing ablation, variant build: no reduction at all — one value per lane keeps the accumulators alive)
+  partials[(size_t)blockIdx.x * PART_STRIDE + threadIdx.x] =
+      gw1[0][0][0] + gw1[0][1][1] + gw1[1][0][2] + gw1[1][1][3] + gw0[0][4] + gw0[1][5] + gw2[0][6] + gw2[1][7] + gb1[0][0] + gb2[0];
+  return;
+#endif
   static_assert(3 * PART_STRIDE <= BWD_LDS_F, "three partial images fit the kernel's LDS");
   float gb1s[2][16], gb2s[TOUT];
 #pragma unroll
@@ -826,8 +831,10 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float s_ = gb1[T][r];                         // sum over the 32 sample columns of this half
+#if !(defined(DSU_TEX_ABL_RED) && DSU_TEX_ABL_RED == 2)
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
+#endif
       gb1s[T][r] = s_;
     }
 #pragma unroll
@@ -869,14 +876,25 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
 #pragma unroll
     for (int o = 0; o < TOUT; ++o) gb2s[o] += src[P_GB2 + o];
   };
-  if (wave >= 2) store_own(lds + (wave - 2) * PART_STRIDE);
-  __syncthreads();
-  if (wave < 2) add_from(lds + wave * PART_STRIDE);
-  if (wave == 1) store_own(lds + 2 * PART_STRIDE);
-  __syncthreads();
-  if (wave == 0) {
-    add_from(lds + 2 * PART_STRIDE);
-    store_own(partials + (size_t)blockIdx.x * PART_STRIDE);
+  if constexpr (4 * PART_STRIDE <= BWD_LDS_F) {
+    // every wave's image, one barrier, then all 256 threads sum the four images element by element
+    // (fixed order) and write the partial vector
+    store_own(lds + wave * PART_STRIDE);
+    __syncthreads();
+    float* part = partials + (size_t)blockIdx.x * PART_STRIDE;
+    for (int v = threadIdx.x; v < PART_N; v += blockDim.x)
+      part[v] = (lds[v] + lds[PART_STRIDE + v]) + (lds[2 * PART_STRIDE + v] + lds[3 * PART_STRIDE + v]);
+  } else {
+    // (exact-f32 GEMM variant: three images fit) waves 2, 3 -> 0, 1; wave 1 -> 0; wave 0 writes
+    if (wave >= 2) store_own(lds + (wave - 2) * PART_STRIDE);
+    __syncthreads();
+    if (wave < 2) add_from(lds + wave * PART_STRIDE);
+    if (wave == 1) store_own(lds + 2 * PART_STRIDE);
+    __syncthreads();
+    if (wave == 0) {
+      add_from(lds + 2 * PART_STRIDE);
+      store_own(partials + (size_t)blockIdx.x * PART_STRIDE);
+    }
   }
   TEX_PROF(10)  // workgroup reduction
   TEX_PROF_END
