@@ -1333,7 +1333,11 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
   const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 31) / 32 * 32;
   const int64_t r0 = blockIdx.x * per;
   const int64_t r1 = r0 + per < n ? r0 + per : n;
+#ifdef DSU_PIPE_ABL   // (timing ablation, variant build: prologue + epilogue only)
+  for (int64_t bbase = r1; bbase < r1; bbase += blockDim.x) {
+#else
   for (int64_t bbase = r0; bbase < r1; bbase += blockDim.x) {
+#endif
     // (the last, partial iteration of a range is shared by the waves as in the general kernel)
     int blk = wave, e_start = 0, e_step = 1;
     {
