@@ -60,6 +60,9 @@ def parse(argv=None):
     ap.add_argument("--inflight-skew", type=float, default=None,
                     help="seconds between the starts of the workers' first drawings of a region (stage skew; "
                          "default: 4.2 s / inflight)")
+    ap.add_argument("--onewave-grid", type=int, default=None,
+                    help="workgroups of the NSR step's two one-wave-per-SIMD kernels (dsu_set_onewave_grid_cap); "
+                         "default: 256 with one drawing at a time, 128 with several in flight")
     ap.add_argument("--nsr-slots", type=int, default=0,
                     help="at most this many drawings inside the NSR optimisation at a time (0 = no limit)")
     a = ap.parse_args(argv)
@@ -355,6 +358,11 @@ def _inflight_loop(args, ddist, rank, dev, timer, pipes, inputs, stage_t, sub_t,
             sync(); t4 = time.time()
         return (t0, t1, t2, t3, t4), views, frames, dict(pipe.substage_seconds)
 
+    grid_cap = getattr(args, "onewave_grid", None)
+    grid_cap = 128 if grid_cap is None else int(grid_cap)
+    if on_gpu:
+        from drawingspinup_amd import _lib as dsu_lib
+        dsu_lib.check(dsu_lib.lib().dsu_set_onewave_grid_cap(grid_cap), "dsu_set_onewave_grid_cap")
     skew = getattr(args, "inflight_skew", None)
     skew = (4.2 / K if skew is None else float(skew)) if on_gpu else 0.0
     slots = int(getattr(args, "nsr_slots", 0) or 0)
@@ -408,7 +416,7 @@ def _inflight_loop(args, ddist, rank, dev, timer, pipes, inputs, stage_t, sub_t,
     timer.enabled = False
     info = {"latency": {"mean": sum(lat) / max(len(lat), 1), "max": max(lat) if lat else None,
                         "drawings": len(lat)},
-            "schedule": {"start_skew_s": skew, "nsr_slots": slots}}
+            "schedule": {"start_skew_s": skew, "nsr_slots": slots, "onewave_grid": grid_cap}}
     # one drawing alone, beside the clock: the kernel families without co-running drawings
     if rank == 0 and hasattr(timer, "fam"):
         concurrent = timer.summary()
@@ -417,6 +425,8 @@ def _inflight_loop(args, ddist, rank, dev, timer, pipes, inputs, stage_t, sub_t,
         saved_tot = nsr_system.native_timing["totals"]
         timer.fam, timer._calls, nsr_system.native_timing["totals"] = {}, {}, {}
         timer.enabled = True
+        if on_gpu:
+            dsu_lib.lib().dsu_set_onewave_grid_cap(0)          # alone: one workgroup per CU
         one(pipes[0], streams[0], 0, True)
         _sync(dev)
         timer.enabled = False

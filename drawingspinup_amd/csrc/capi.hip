@@ -15,6 +15,13 @@ const char* dsu_strerror(int code) {
 
 int dsu_abi_version(void) { return 1; }
 
+int32_t dsu_onewave_grid_cap_value = 0;     // 0 = one workgroup per CU (256)
+int dsu_set_onewave_grid_cap(int32_t workgroups) {
+  if (workgroups < 0 || workgroups > 256) return DSU_EINVAL;
+  dsu_onewave_grid_cap_value = workgroups;
+  return DSU_OK;
+}
+
 // 1 in a variant build with the A/B environment switches compiled in (-DDSU_AB_SWITCHES), 0 in the
 // product library
 int dsu_ab_switches(void) {

@@ -33,6 +33,16 @@ static inline int dsu_ab_int(const char*, int dflt) { return dflt; }
 static inline bool dsu_ab_is(const char*, const char*) { return false; }
 #endif
 
+// Workgroups of the two one-wave-per-SIMD kernels of the NSR step (dsu_set_onewave_grid_cap, capi.hip)
+extern "C" int32_t dsu_onewave_grid_cap_value;
+static inline int dsu_onewave_blocks(int64_t n, int threads, int max_blocks) {
+  int cap = dsu_onewave_grid_cap_value;
+  if (cap < 1 || cap > max_blocks) cap = max_blocks;
+  int64_t b = (n + threads - 1) / threads;
+  if (b < 1) b = 1;
+  return (int)(b > cap ? cap : b);
+}
+
 static inline int dsu_blocks_for(int64_t n, int threads) {
   return (int)((n + threads - 1) / threads);
 }

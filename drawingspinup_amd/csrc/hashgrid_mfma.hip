@@ -2188,7 +2188,10 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
 #endif
 }
 
-constexpr int BWD_MFMA_MAX_BLOCKS = 256;   // one workgroup per CU (458 registers: one wave per SIMD)
+#ifndef DSU_BWD_MFMA_MAX_BLOCKS
+#define DSU_BWD_MFMA_MAX_BLOCKS 256
+#endif
+constexpr int BWD_MFMA_MAX_BLOCKS = DSU_BWD_MFMA_MAX_BLOCKS;   // one workgroup per CU (458 registers: one wave per SIMD)
 
 }  // namespace
 
@@ -2390,7 +2393,8 @@ int dsu_sdf_fd_bwd_sorted_fold(const dsu_hashgrid_cfg* cfg, const void* table_f1
   if (!workspace || workspace_bytes < need) return DSU_EINVAL;
   hipStream_t s = (hipStream_t)stream;
   const float eps2 = (float)((double)eps * (double)eps);
-  const int blocks = dsu_capped_blocks(n, 256, BWD_MFMA_MAX_BLOCKS);
+  // (the workspace is sized for one workgroup per CU; dsu_set_onewave_grid_cap may launch fewer)
+  const int blocks = dsu_onewave_blocks(n, 256, BWD_MFMA_MAX_BLOCKS);
   const int ablate = dsu_ab_int("DSU_BWD_ABLATE", 0);
   if (bwd_split()) {
     const size_t shm1 = (size_t)BWD_CACHE_OFF * sizeof(float);         // no gradient cache

@@ -86,7 +86,10 @@ constexpr int BWD_LDS_F = L_IMG0 + IMG0_F;       // 26056 + 6144 floats = 126 KB
 // per-workgroup partial vector
 constexpr int P_GW1 = 0, P_GW0 = 64 * 64, P_GW2 = P_GW0 + 64 * 32, P_GB1 = P_GW2 + 64 * 32,
               P_GB2 = P_GB1 + 64, PART_N = P_GB2 + 3, PART_STRIDE = 8320;
-constexpr int TEX_MAX_BLOCKS = 256;
+#ifndef DSU_TEX_MAX_BLOCKS
+#define DSU_TEX_MAX_BLOCKS 256
+#endif
+constexpr int TEX_MAX_BLOCKS = DSU_TEX_MAX_BLOCKS;
 
 __device__ __forceinline__ int feat_of(int T, int r, int h) {
   return 32 * T + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -978,7 +981,7 @@ int dsu_texture_bwd(const dsu_tex_mlp* mlp, const float* tex_in, const float* rg
   const int64_t need = dsu_texture_bwd_workspace_bytes(n);
   if (!workspace || workspace_bytes < need) return DSU_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const int blocks = dsu_capped_blocks(n, 256, TEX_MAX_BLOCKS);
+  const int blocks = dsu_onewave_blocks(n, 256, TEX_MAX_BLOCKS);
   const size_t shm = (size_t)BWD_LDS_F * sizeof(float);
   static_assert(PART_N <= 4 * STAGE_F, "reduction buffer must fit the staging area");
   DSU_ENSURE_DYN_LDS(texture_bwd_kernel<false>, shm);
@@ -1005,7 +1008,7 @@ int dsu_texture_bwd_shaded(const dsu_tex_mlp* mlp, const float* feature, const f
   const int64_t need = dsu_texture_bwd_workspace_bytes(n);
   if (!workspace || workspace_bytes < need) return DSU_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const int blocks = dsu_capped_blocks(n, 256, TEX_MAX_BLOCKS);
+  const int blocks = dsu_onewave_blocks(n, 256, TEX_MAX_BLOCKS);
   const size_t shm = (size_t)BWD_LDS_F * sizeof(float);
   DSU_ENSURE_DYN_LDS(texture_bwd_kernel<true>, shm);
   texture_bwd_kernel<true><<<blocks, 256, shm, s>>>(*mlp, nullptr, ShadeIn{feature, grad},
@@ -1056,7 +1059,7 @@ int dsu_texture_bwd_shaded_partials(const dsu_tex_mlp* mlp, const float* feature
   const int64_t need = dsu_texture_bwd_workspace_bytes(n);
   if (!workspace || workspace_bytes < need) return DSU_EINVAL;
   hipStream_t s = (hipStream_t)stream;
-  const int blocks = dsu_capped_blocks(n, 256, TEX_MAX_BLOCKS);
+  const int blocks = dsu_onewave_blocks(n, 256, TEX_MAX_BLOCKS);
   const size_t shm = (size_t)BWD_LDS_F * sizeof(float);
   DSU_ENSURE_DYN_LDS(texture_bwd_kernel<true>, shm);
   texture_bwd_kernel<true><<<blocks, 256, shm, s>>>(*mlp, nullptr, ShadeIn{feature, grad},

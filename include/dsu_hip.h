@@ -35,6 +35,12 @@ const char* dsu_strerror(int code);
 int dsu_ab_switches(void);
 /* ABI version of this header; bumped on any signature change. */
 int dsu_abi_version(void);
+/* Workgroups of the two one-wave-per-SIMD kernels of the NSR step (the MLP part of the geometry
+ * backward, the texture backward: 450-510 registers per lane, nothing else fits beside them on a
+ * SIMD).  0 / 256 = one workgroup per CU (a single optimisation alone on the GPU); with several
+ * drawings in flight on one GPU fewer workgroups leave CUs to the other drawings' kernels while such
+ * a kernel runs (bench.py --inflight: 128).  Process-wide; workspaces stay sized for 256. */
+int dsu_set_onewave_grid_cap(int32_t workgroups);
 
 /* ------------------------------------------------------------------------------------
  * Multi-resolution hash grid (replaces tiny-cuda-nn `tcnn.Encoding(3, {otype:HashGrid})`
