@@ -63,6 +63,9 @@ def parse(argv=None):
     ap.add_argument("--onewave-grid", type=int, default=None,
                     help="workgroups of the NSR step's two one-wave-per-SIMD kernels (dsu_set_onewave_grid_cap); "
                          "default: 256 with one drawing at a time, 128 with several in flight")
+    ap.add_argument("--fit-priority", type=int, default=0,
+                    help="1: with drawings in flight, the NSR optimisation runs on a low-priority stream of its own "
+                         "and the other stages on a high-priority stream")
     ap.add_argument("--nsr-slots", type=int, default=0,
                     help="at most this many drawings inside the NSR optimisation at a time (0 = no limit)")
     a = ap.parse_args(argv)
@@ -338,7 +341,11 @@ def _inflight_loop(args, ddist, rank, dev, timer, pipes, inputs, stage_t, sub_t,
 
         def __exit__(self, *a):
             return False
-    streams = [torch.cuda.Stream(dev) if on_gpu else _HostStream() for _ in range(K)]
+    fitprio = bool(getattr(args, "fit_priority", 0)) and on_gpu
+    streams = [torch.cuda.Stream(dev, priority=-1 if fitprio else 0) if on_gpu else _HostStream() for _ in range(K)]
+    if fitprio:
+        for p_ in pipes:
+            p_.fit_stream = torch.cuda.Stream(dev, priority=0)
     lat = []
 
     def one(pipe, stream, j, timed):

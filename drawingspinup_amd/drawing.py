@@ -90,6 +90,7 @@ class DrawingPipeline:
         #                                      synchronisations are the CURRENT STREAM's: several drawings
         #                                      may be in flight on one GPU, one stream + one pipeline each)
         self.substage_seconds = {}
+        self.fit_stream = None               # a stream for the NSR optimisation alone (see reconstruct)
         self.fit_gate = None                 # a semaphore shared by the pipelines of one GPU: how many
         #                                      drawings may be inside the NSR optimisation at a time
         self.export_resolution = export_resolution
@@ -232,7 +233,17 @@ class DrawingPipeline:
             self.fit_gate.acquire()
         try:
             t0 = time.time()
-            system.fit(data, max_steps=self.nsr_steps)
+            if self.fit_stream is not None:
+                # the optimisation on a stream of its own (bench.py --fit-priority: a lower priority
+                # than the stream of the latency-bound stages of the other drawings in flight)
+                outer = torch.cuda.current_stream(dev)
+                self.fit_stream.wait_stream(outer)
+                with torch.cuda.stream(self.fit_stream):
+                    system.fit(data, max_steps=self.nsr_steps)
+                outer.wait_stream(self.fit_stream)
+                self._fit_on_own_stream = True
+            else:
+                system.fit(data, max_steps=self.nsr_steps)
             if self.time_substages or self.fit_gate is not None:
                 torch.cuda.current_stream(dev).synchronize()
         finally:
@@ -270,6 +281,10 @@ class DrawingPipeline:
             torch.cuda.current_stream(dev).synchronize()
             self.substage_seconds.update({"nsr_fit": t1 - t0, "nsr_export": t2 - t1,
                                           "nsr_post": time.time() - t2})
+        if getattr(self, "_fit_on_own_stream", False):
+            # tensors of the fit's stream were read by this stream's export: they go back to the fit
+            # stream's pool only once this stream is done with them
+            torch.cuda.current_stream(dev).synchronize()
         return system, mesh["binary"]
 
     # ---------------------------------------------------------------- stage 3: test_stage1/2.py
