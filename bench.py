@@ -672,6 +672,9 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
                                   "share of the machine; roofline.alone = the same families with one drawing alone "
                                   "on the GPU (one more drawing after the clock)" % inflight)
         roof["alone"] = flight.get("alone")
+        lead = next((r for r in (roof["alone"] or []) if r.get("kernel") == roof.get("kernel")), None)
+        if lead:                                  # the leading family alone, next to the shared-machine figures
+            roof["frac_alone"], roof["avg_launch_ms_alone"] = lead["frac"], lead["avg_launch_ms"]
     out = {
         "metric": "drawings/sec end-to-end (512x512, 6 views, 24 frames)",
         "value": world * inflight * args.steps / elapsed, "unit": "drawings/s", "n_gpus": world,
