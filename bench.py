@@ -63,6 +63,8 @@ def parse(argv=None):
     ap.add_argument("--onewave-grid", type=int, default=None,
                     help="workgroups of the NSR step's two one-wave-per-SIMD kernels (dsu_set_onewave_grid_cap); "
                          "default: 256 with one drawing at a time, 128 with several in flight")
+    ap.add_argument("--scatter-grid", type=int, default=None,
+                    help="workgroups of the geometry backward's scatter kernel (dsu_set_scatter_grid_cap); default 256")
     ap.add_argument("--fit-priority", type=int, default=0,
                     help="1: with drawings in flight, the NSR optimisation runs on a low-priority stream of its own "
                          "and the other stages on a high-priority stream")
@@ -370,6 +372,9 @@ def _inflight_loop(args, ddist, rank, dev, timer, pipes, inputs, stage_t, sub_t,
     if on_gpu:
         from drawingspinup_amd import _lib as dsu_lib
         dsu_lib.check(dsu_lib.lib().dsu_set_onewave_grid_cap(grid_cap), "dsu_set_onewave_grid_cap")
+        sc_cap = getattr(args, "scatter_grid", None)
+        dsu_lib.check(dsu_lib.lib().dsu_set_scatter_grid_cap(0 if sc_cap is None else int(sc_cap)),
+                      "dsu_set_scatter_grid_cap")
     skew = getattr(args, "inflight_skew", None)
     skew = (4.2 / K if skew is None else float(skew)) if on_gpu else 0.0
     slots = int(getattr(args, "nsr_slots", 0) or 0)
@@ -434,6 +439,7 @@ def _inflight_loop(args, ddist, rank, dev, timer, pipes, inputs, stage_t, sub_t,
         timer.enabled = True
         if on_gpu:
             dsu_lib.lib().dsu_set_onewave_grid_cap(0)          # alone: one workgroup per CU
+            dsu_lib.lib().dsu_set_scatter_grid_cap(0)
         one(pipes[0], streams[0], 0, True)
         _sync(dev)
         timer.enabled = False

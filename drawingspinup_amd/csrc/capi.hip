@@ -16,6 +16,12 @@ const char* dsu_strerror(int code) {
 int dsu_abi_version(void) { return 1; }
 
 int32_t dsu_onewave_grid_cap_value = 0;     // 0 = one workgroup per CU (256)
+int32_t dsu_scatter_grid_cap_value = 0;     // 0 = one scatter workgroup per CU (256)
+int dsu_set_scatter_grid_cap(int32_t workgroups) {
+  if (workgroups < 0 || workgroups > 256) return DSU_EINVAL;
+  dsu_scatter_grid_cap_value = workgroups;
+  return DSU_OK;
+}
 int dsu_set_onewave_grid_cap(int32_t workgroups) {
   if (workgroups < 0 || workgroups > 256) return DSU_EINVAL;
   dsu_onewave_grid_cap_value = workgroups;

@@ -35,6 +35,7 @@ static inline bool dsu_ab_is(const char*, const char*) { return false; }
 
 // Workgroups of the two one-wave-per-SIMD kernels of the NSR step (dsu_set_onewave_grid_cap, capi.hip)
 extern "C" int32_t dsu_onewave_grid_cap_value;
+extern "C" int32_t dsu_scatter_grid_cap_value;
 static inline int dsu_onewave_blocks(int64_t n, int threads, int max_blocks) {
   int cap = dsu_onewave_grid_cap_value;
   if (cap < 1 || cap > max_blocks) cap = max_blocks;

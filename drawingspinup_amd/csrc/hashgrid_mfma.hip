@@ -2401,7 +2401,11 @@ int dsu_sdf_fd_bwd_sorted_fold(const dsu_hashgrid_cfg* cfg, const void* table_f1
     const size_t shm2 = (size_t)SC_LDS_TOTAL * sizeof(float);
     float2* dinbuf = reinterpret_cast<float2*>((char*)workspace +
                                                (size_t)blocks * PART_STRIDE * sizeof(float));
-    const int sblocks = dsu_capped_blocks(n, SC_THREADS, SC_MAXBLOCKS);
+    // (150 KB of LDS per workgroup: one per CU, and no other LDS-using kernel beside it on that CU;
+    // dsu_set_scatter_grid_cap launches fewer when other drawings share the GPU — the items are
+    // handed out dynamically, so any count works)
+    int sblocks = dsu_capped_blocks(n, SC_THREADS, SC_MAXBLOCKS);
+    if (dsu_scatter_grid_cap_value > 0 && sblocks > dsu_scatter_grid_cap_value) sblocks = dsu_scatter_grid_cap_value;
     DSU_DISPATCH_NL(cfg->n_levels, {
       auto k1 = enc_cache ? sdf_fd_bwd_mfma_kernel<NL, true, true>
                           : sdf_fd_bwd_mfma_kernel<NL, true, false>;
