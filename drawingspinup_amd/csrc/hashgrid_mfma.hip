@@ -1848,6 +1848,7 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
   __syncthreads();
 #ifdef DSU_AB_SWITCHES
   const unsigned long long clk_start = wall_clock64();
+  if (threadIdx.x < 15 && sc_block < 256) dsu_sc_clk[sc_block * 16 + threadIdx.x] = 0ull;   // per-level item time of this launch
 #endif
   // Work items = (512-point chunk of the Morton-ordered samples, level), handed out dynamically:
   // an item is self-contained (its tile is flushed at its end), items differ a lot in cost (how
@@ -1915,6 +1916,9 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
 #pragma unroll 1
   while (cur < n_items) {              // uniform over the workgroup
     {
+#ifdef DSU_AB_SWITCHES
+      const unsigned long long clk_item = wall_clock64();
+#endif
       const int64_t chunk = cur / (int64_t)active;
       const int lev = (int)(cur - chunk * (int64_t)active);
       const float l_scale = m.scale[lev];
@@ -2179,6 +2183,9 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
       } else {
         flush_cache();                   // cache mode: this item's entries (the next item may be a tile)
       }
+#ifdef DSU_AB_SWITCHES
+      if (threadIdx.x == 0 && sc_block < 256 && lev < 15) dsu_sc_clk[sc_block * 16 + lev] += wall_clock64() - clk_item;
+#endif
       cur = nxt;
       nxt = after_next;
     }

@@ -32,3 +32,8 @@ a = np.array(list(clk), dtype=np.float64).reshape(256, 16) * 0.01      # us
 tot = a[:, 15]
 print("last launch: workgroup total us: mean %.1f  median %.1f  p90 %.1f  max %.1f  min %.1f" %
       (tot.mean(), np.median(tot), np.percentile(tot, 90), tot.max(), tot.min()))
+# per level: time the workgroups spent in items of that level during the last launch (mean over workgroups)
+for lev in range(10):
+    if a[:, lev].sum() > 0:
+        print("   level %d: mean %.1f us per workgroup (%.1f %% of its total)" % (lev, a[:, lev].mean(), 100 * a[:, lev].sum() / tot.sum()))
+
