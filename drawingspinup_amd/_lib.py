@@ -141,6 +141,9 @@ _PROTOS = {
     "dsu_texture_partial_map": [P],
     "dsu_texture_bwd_shaded_partials": [C.POINTER(TexMlp), P, P, P, P, P, c_i64, c_i64, P, P, P, c_i64,
                                         C.POINTER(PartialReduce), P],
+    "dsu_texture_bwd_shaded_partials_m": [C.POINTER(TexMlp), P, P, P, P, P, c_i64, c_i64, P, P, P, P, c_i64,
+                                          C.POINTER(PartialReduce), P],
+    "dsu_texture_fwd_shaded_m": [C.POINTER(TexMlp), P, P, c_i64, P, P, P, P],
     "dsu_occgrid_refresh_workspace_bytes": [c_i32],
     "dsu_occgrid_refresh": [C.POINTER(OccRefreshArgs), P],
     "dsu_nsr_driver_occ_refresh": [P, C.POINTER(OccRefreshArgs), P],

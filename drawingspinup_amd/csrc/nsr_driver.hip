@@ -287,6 +287,7 @@ struct Layout {
   float *d_sdf_all, *d_grad_all, *d_feat_all, *d_normal, *d_rgb;
   void *tex_ws, *sdf_ws;
   int32_t* tex_map;                   // dsu_texture_partial_map, uploaded at creation
+  uint32_t* tex_mask;                 // (cap_points, 2): layer 1's ReLU pattern, texture forward -> backward
   float *g_geo, *g_tex, *d_inv;      // contiguous: zeroed as one block
   float *w0_eff, *w1_eff, *inv_s, *adam_m, *adam_v;
   int64_t tex_ws_bytes, sdf_ws_bytes, sort_ws_bytes, enc_cache_bytes, total;
@@ -333,6 +334,7 @@ int carve(const dsu_nsr_driver_cfg& c, char* base, Layout& L) {
   L.tex_ws = k.take<char>(L.tex_ws_bytes > 4 ? L.tex_ws_bytes : 4);
   L.sdf_ws = k.take<char>(L.sdf_ws_bytes > 4 ? L.sdf_ws_bytes : 4);
   L.tex_map = k.take<int32_t>(dsu_texture_partial_map(nullptr));
+  L.tex_mask = k.take<uint32_t>(N * 2);
   L.g_geo = k.take<float>(N_GEO + N_TEX + 1);
   L.g_tex = L.g_geo ? L.g_geo + N_GEO : nullptr;
   L.d_inv = L.g_geo ? L.g_geo + N_GEO + N_TEX : nullptr;
@@ -361,6 +363,7 @@ struct dsu_nsr_driver {
   hipEvent_t gate = nullptr;                           // main: MLP part of the latest backward done
   hipEvent_t fwd_done = nullptr;                       // main: this step's geometry forward done
   bool fold = true;                 // DSU_NSR_FOLD (variant builds)
+  bool tex_masks = true;            // DSU_NSR_TEX_MASKS (variant builds)
   bool side_high_priority = true;   // DSU_NSR_SIDE_PRIO
   int pack_gate = 0;                // DSU_NSR_PACK_GATE: 0 with the march, 1 behind this step's geometry
                                     // forward (own event), 2 behind the MLP part of this step's backward
@@ -590,6 +593,7 @@ int dsu_nsr_driver_create(const dsu_nsr_driver_cfg* cfg, dsu_nsr_driver** out) {
   // interleaved pairs, same box) — and the main queue loses one event record per step
   d->pack_gate = dsu_ab_int("DSU_NSR_PACK_GATE", 0);
   d->fold = dsu_ab_int("DSU_NSR_FOLD", 1) != 0;
+  d->tex_masks = dsu_ab_int("DSU_NSR_TEX_MASKS", 1) != 0;   // (variant builds: 0 = exact f32 recompute, for A/B)
   bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
             hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking,
                                         d->side_high_priority ? hi : lo) == hipSuccess;
@@ -758,7 +762,9 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
   }
   if (n_s > 0) {
     dsu_tex_mlp tex{c.tex[0], c.tex[1], c.tex[2], c.tex[3], c.tex[4], c.tex[5]};
-    DSU_TRY(dsu_texture_fwd_shaded(&tex, L.a_feat, L.a_grad, n_s, L.normal, L.rgb, s));
+    // (with the ReLU pattern of hidden layer 1 for the backward: its recompute runs as bf16 x 3)
+    DSU_TRY(dsu_texture_fwd_shaded_m(&tex, L.a_feat, L.a_grad, n_s, L.normal, L.rgb,
+                                     d->tex_masks ? L.tex_mask : nullptr, s));
     DSU_TRY(dsu_neus_composite_fwd(L.a_sdf, L.normal, L.rgb, f.rays_d, f.t_starts, f.t_ends,
                                    f.offsets, f.counts, a->n_rays, L.inv_s, a->cos_anneal_ratio,
                                    L.alpha, L.w, L.comp, s));
@@ -785,9 +791,10 @@ int dsu_nsr_driver_step(dsu_nsr_driver* d, dsu_nsr_step_args* a, void* main_stre
                                      L.d_grad_all, L.d_feat_all, gt, gt + 1024, gt + 1088, gt + 5184,
                                      gt + 5248, gt + 5440, L.tex_ws, L.tex_ws_bytes, s));
     } else {
-    DSU_TRY(dsu_texture_bwd_shaded_partials(&tex, L.a_feat, L.a_grad, L.rgb, L.d_rgb, L.d_normal, n_s,
-                                            2 * n_r, L.d_grad_all, L.d_feat_all, L.tex_ws,
-                                            L.tex_ws_bytes, &tex_red, s));
+    DSU_TRY(dsu_texture_bwd_shaded_partials_m(&tex, L.a_feat, L.a_grad, L.rgb, L.d_rgb, L.d_normal, n_s,
+                                              2 * n_r, L.d_grad_all, L.d_feat_all,
+                                              d->tex_masks ? L.tex_mask : nullptr, L.tex_ws,
+                                              L.tex_ws_bytes, &tex_red, s));
     tex_red.map = L.tex_map;
     tex_red.base = L.g_tex;
     have_tex_red = true;

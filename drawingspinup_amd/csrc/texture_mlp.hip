@@ -82,7 +82,10 @@ constexpr int S_P = 0, S_H = 0, S_IN = 0, S_DO = 0;              // (f32 staging
 constexpr int IMG1_F = 2 * 8 * 64 * 4, IMG0_F = 2 * 4 * 64 * 4;       // floats (16 B = 4 floats per fragment)
 constexpr int L_IMG1 = L_WEND + 4 * STAGE_F;
 constexpr int L_IMG0 = L_IMG1 + IMG1_F;
-constexpr int BWD_LDS_F = L_IMG0 + IMG0_F;       // 26056 + 6144 floats = 126 KB
+//   W1 image of the backward's forward RECOMPUTE (L1_MASK kernels) [hi|mid][To][Tin][g][lane] :
+//   8 values t -> w1[32 To + l31][feat_of(Tin, 8 g + t, h)]
+constexpr int L_IMGF = L_IMG0 + IMG0_F;
+constexpr int BWD_LDS_F = L_IMGF + IMG1_F;       // 5576 + 4 x 5920 + 6144 + 4096 floats = 154 KB
 // per-workgroup partial vector
 constexpr int P_GW1 = 0, P_GW0 = 64 * 64, P_GW2 = P_GW0 + 64 * 32, P_GB1 = P_GW2 + 64 * 32,
               P_GB2 = P_GB1 + 64, PART_N = P_GB2 + 3, PART_STRIDE = 8320;
@@ -119,6 +122,11 @@ __device__ __forceinline__ void load_weights(float* lds, const dsu_tex_mlp& m) {
 
 // Hidden activations of ONE sample half `a` (0: samples of lanes 0-31, 1: lanes 32-63).
 // in: the lane's OWN sample (16 inputs).  H0/H1: [hidden tile T] accumulators, post-ReLU.
+// L1_BF16 (the backward's recompute when the forward handed over its ReLU pattern of layer 1): layer 1
+// as bf16 x 3 on v_mfma_f32_32x32x16_bf16 — the post-ReLU accumulators of layer 0 are the B operand
+// as they stand (registers 8 g + t of tile Tin = units feat_of(Tin, 8 g + t, h) of the lane's sample
+// column), the A fragments come from the image at L_IMGF: 24 MFMAs of 32 clocks instead of 64 of 64.
+template <bool L1_BF16 = false>
 __device__ __forceinline__ void forward_half(const float* lds, const float* in, int a, int l31,
                                              int h, f32x16 (&H0)[2], f32x16 (&H1)[2]) {
 #pragma unroll
@@ -154,7 +162,30 @@ __device__ __forceinline__ void forward_half(const float* lds, const float* in, 
   // The weight operands of the NEXT four k-pairs are requested from LDS before the eight MFMAs of
   // the current four are issued (written per k-pair, the compiler put every `ds_read` right in
   // front of its MFMA with `s_waitcnt lgkmcnt(0)` in between: one MFMA per LDS round trip).
-  {
+  if constexpr (L1_BF16) {
+    // (one B fragment pair at a time: the kernel has no registers for all four)
+    const bf16x8* imgf = reinterpret_cast<const bf16x8*>(lds + L_IMGF);
+    const int lane = l31 + 32 * h;
+#pragma unroll
+    for (int Tin = 0; Tin < 2; ++Tin)
+#pragma unroll
+      for (int g = 0; g < 2; ++g) {
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = H0[Tin][8 * g + t];
+        bf16x8 bh, bm;
+        bf16_split8(v, bh, bm);
+#pragma unroll
+        for (int To = 0; To < 2; ++To) {
+          const int f = ((To * 2 + Tin) * 2 + g) * 64 + lane;
+          const bf16x8 ah = imgf[f], am = imgf[8 * 64 + f];
+          H1[To] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, H1[To], 0, 0, 0);
+          H1[To] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, H1[To], 0, 0, 0);
+          H1[To] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, H1[To], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);        // (keeps the next pair's fragments out of this one's registers)
+      }
+  } else {
     float a[2][8];
     auto load = [&](int s_, float* dst) {
       const int T = s_ >> 2, rq = s_ & 3;
@@ -236,7 +267,8 @@ template <bool SHADE>
 __global__ __launch_bounds__(256) void texture_fwd_kernel(dsu_tex_mlp m,
                                                           const float* __restrict__ x, ShadeIn sh,
                                                           float* __restrict__ normal_out, int64_t n,
-                                                          float* __restrict__ rgb) {
+                                                          float* __restrict__ rgb,
+                                                          uint32_t* __restrict__ h1_mask) {
   __shared__ __attribute__((aligned(16))) float lds[L_WEND];
   const int lane = threadIdx.x & 63, l31 = lane & 31, h = lane >> 5;
   load_weights(lds, m);
@@ -274,6 +306,17 @@ __global__ __launch_bounds__(256) void texture_fwd_kernel(dsu_tex_mlp m,
       if (wave_first + a * 32 >= r1) continue;
       f32x16 H0[2], H1[2];
       forward_half(lds, in, a, l31, h, H0, H1);
+      if (h1_mask) {
+        // the ReLU pattern of layer 1 for the backward (bit 16 T + r = unit feat_of(T, r, h) of the
+        // sample in column l31): its recompute may then round differently without moving a mask
+        uint32_t mk = 0u;
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mk |= (H1[T][r] > 0.0f ? 1u : 0u) << (16 * T + r);
+        const int64_t si = wave_first + a * 32 + l31;
+        if (si < r1) h1_mask[si * 2 + h] = mk;
+      }
       float p[TOUT];
       layer2_partial(lds, H1, h, p);
 #pragma unroll
@@ -357,11 +400,12 @@ struct ShadeOut {
   int64_t tail;           // not ray samples: the regulariser points of the same geometry launch)
 };
 
-template <bool SHADE>
+template <bool SHADE, bool L1_MASK = false>
 __global__ __launch_bounds__(256) void texture_bwd_kernel(
     dsu_tex_mlp m, const float* __restrict__ x, ShadeIn sh, ShadeOut so,
     const float* __restrict__ rgb, const float* __restrict__ d_rgb, int64_t n,
-    float* __restrict__ d_x, float* __restrict__ partials) {
+    float* __restrict__ d_x, float* __restrict__ partials,
+    const uint32_t* __restrict__ h1_mask = nullptr) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   TEX_PROF_DECL
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l31 = lane & 31, h = lane >> 5;
@@ -396,6 +440,17 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
         w[t] = (ln & 31) < TIN ? lds[L_W0 + feat_of(T, 8 * g + t, ln >> 5) * W0_ROW + (ln & 31)] : 0.0f;
       bf16_split8(w, img0[f], img0[4 * 64 + f]);
     }
+    if constexpr (L1_MASK) {
+      bf16x8* imgf = reinterpret_cast<bf16x8*>(lds + L_IMGF);
+      for (int f = threadIdx.x; f < 8 * 64; f += blockDim.x) {
+        const int ln = f & 63, c = f >> 6, g = c & 1, Tin = (c >> 1) & 1, To = c >> 2;
+        float w[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+          w[t] = lds[L_W1 + (32 * To + (ln & 31)) * W1_ROW + feat_of(Tin, 8 * g + t, ln >> 5)];
+        bf16_split8(w, imgf[f], imgf[8 * 64 + f]);
+      }
+    }
   }
   __syncthreads();
 
@@ -405,14 +460,21 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
       so.d_feature[n * 13 + t] = 0.0f;
   }
   f32x16 gw1[2][2], gw0[2], gw2[2];     // D[i = row unit][j]: W1[i][j], W0[i][k | bias], W2^T[i][o]
-  float gb1[2][16], gb2[TOUT] = {0.0f, 0.0f, 0.0f};
+#ifdef DSU_TEX_GEMM_F32
+  float gb1[2][16];
+#else
+  float gb1row = 0.0f;                 // gb1[unit = lane]: row sums of the transposed dPre1 image (see gW1)
+#endif
+  float gb2[TOUT] = {0.0f, 0.0f, 0.0f};
 #pragma unroll
   for (int T = 0; T < 2; ++T)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       gw1[T][0][r] = gw1[T][1][r] = 0.0f;
       gw0[T][r] = gw2[T][r] = 0.0f;
+#ifdef DSU_TEX_GEMM_F32
       gb1[T][r] = 0.0f;
+#endif
     }
 
   const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 31) / 32 * 32;   // see texture_fwd_kernel
@@ -444,12 +506,30 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
       dz[o] = valid ? d_rgb[ii * TOUT + o] * s * (1.0f - s) : 0.0f;
       gb2[o] += dz[o];
     }
+    uint32_t mk2[2] = {0u, 0u};         // layer 1's ReLU pattern of the samples in column l31 of both halves
+    if constexpr (L1_MASK) {
+#pragma unroll
+      for (int a_ = 0; a_ < 2; ++a_) {
+        int64_t si = wave_first + a_ * 32 + l31;
+        si = si < r1 ? si : r1 - 1;
+        mk2[a_] = h1_mask[si * 2 + h];
+      }
+    }
 #pragma unroll 1
     for (int a = 0; a < 2; ++a) {
       if (wave_first + a * 32 >= r1) continue;
       TEX_PROF(0)   // rows of the block / previous half's tail
       f32x16 H0[2], H1[2];
-      forward_half(lds, in, a, l31, h, H0, H1);
+      forward_half<L1_MASK>(lds, in, a, l31, h, H0, H1);
+      const uint32_t mk = a ? mk2[1] : mk2[0];
+      if constexpr (L1_MASK) {
+        // the forward's pattern decides which units are live; the bf16 x 3 recompute only supplies
+        // their values (2^-16 relative)
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) H1[T][r] = ((mk >> (16 * T + r)) & 1u) ? H1[T][r] : 0.0f;
+      }
       // dz of the samples of half a, in every lane of the pair
       TEX_PROF(1)   // forward recompute
       float dza[TOUT];
@@ -468,8 +548,10 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
 #pragma unroll
           for (int o = 0; o < TOUT; ++o)
             v = fmaf(lds[L_W2P + (h * TOUT + o) * 32 + T * 16 + r], dza[o], v);
-          D1[T][r] = H1[T][r] > 0.0f ? v : 0.0f;
+          D1[T][r] = (L1_MASK ? ((mk >> (16 * T + r)) & 1u) != 0u : H1[T][r] > 0.0f) ? v : 0.0f;
+#ifdef DSU_TEX_GEMM_F32
           gb1[T][r] += D1[T][r];
+#endif
         }
       TEX_PROF(2)   // dPre1
       // ---- gW2^T[unit][o] += sum_samples H1[sample][unit] * dz[sample][o]
@@ -576,6 +658,19 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
       stage_units_T(tY, D1, l31, h);
       stage_units_T(tX, H0, l31, h);
       __builtin_amdgcn_wave_barrier();
+      {   // gb1[unit] += sum over the half's samples of dPre1: lane u adds up row u of the image it was
+          // just staged into (hi + mid: 2^-16 relative, like the products) — one accumulator per lane
+          // instead of 32 per-column partial sums
+        float srow = 0.0f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bf16x8 vh = *reinterpret_cast<const bf16x8*>(tY + lane * TROW + 8 * q);
+          const bf16x8 vm = *reinterpret_cast<const bf16x8*>(tY + (64 + lane) * TROW + 8 * q);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) srow += (float)vh[e] + (float)vm[e];
+        }
+        gb1row += srow;
+      }
       gemm_samples_T<2>(gw1[0], gw1[1], tY, 64 * TROW, tX, 64 * TROW, 64, l31, h);   // 24 MFMAs instead of 64
 #endif
       // ---- dH0^T = W1^T . dPre1^T, then dPre0 = dH0 * relu'(H0)
@@ -824,22 +919,23 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
 #if defined(DSU_TEX_ABL_RED) && DSU_TEX_ABL_RED == 1
   // (timing ablation, variant build: no reduction at all — one value per lane keeps the accumulators alive)
   partials[(size_t)blockIdx.x * PART_STRIDE + threadIdx.x] =
-      gw1[0][0][0] + gw1[0][1][1] + gw1[1][0][2] + gw1[1][1][3] + gw0[0][4] + gw0[1][5] + gw2[0][6] + gw2[1][7] + gb1[0][0] + gb2[0];
+      gw1[0][0][0] + gw1[0][1][1] + gw1[1][0][2] + gw1[1][1][3] + gw0[0][4] + gw0[1][5] + gw2[0][6] + gw2[1][7] + gb2[0];
   return;
 #endif
   static_assert(3 * PART_STRIDE <= BWD_LDS_F, "three partial images fit the kernel's LDS");
-  float gb1s[2][16], gb2s[TOUT];
+  float gb2s[TOUT];
+#ifdef DSU_TEX_GEMM_F32
+  float gb1s[2][16];
 #pragma unroll
   for (int T = 0; T < 2; ++T)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       float s_ = gb1[T][r];                         // sum over the 32 sample columns of this half
-#if !(defined(DSU_TEX_ABL_RED) && DSU_TEX_ABL_RED == 2)
 #pragma unroll
       for (int o = 16; o > 0; o >>= 1) s_ += __shfl_xor(s_, o);
-#endif
       gb1s[T][r] = s_;
     }
+#endif
 #pragma unroll
   for (int o = 0; o < TOUT; ++o) {
     float s_ = gb2[o];
@@ -857,8 +953,13 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
         dst[P_GW1 + row * 64 + 32 + l31] = gw1[T][1][r];
         dst[P_GW0 + row * 32 + l31] = gw0[T][r];
         dst[P_GW2 + row * 32 + l31] = gw2[T][r];
+#ifdef DSU_TEX_GEMM_F32
         if (l31 == 0) dst[P_GB1 + row] = gb1s[T][r];
+#endif
       }
+#ifndef DSU_TEX_GEMM_F32
+    dst[P_GB1 + lane] = gb1row;
+#endif
     if (lane == 0) {
 #pragma unroll
       for (int o = 0; o < TOUT; ++o) dst[P_GB2 + o] = gb2s[o];
@@ -874,8 +975,13 @@ __global__ __launch_bounds__(256) void texture_bwd_kernel(
         gw1[T][1][r] += src[P_GW1 + row * 64 + 32 + l31];
         gw0[T][r] += src[P_GW0 + row * 32 + l31];
         gw2[T][r] += src[P_GW2 + row * 32 + l31];
+#ifdef DSU_TEX_GEMM_F32
         gb1s[T][r] += src[P_GB1 + row];
+#endif
       }
+#ifndef DSU_TEX_GEMM_F32
+    gb1row += src[P_GB1 + lane];
+#endif
 #pragma unroll
     for (int o = 0; o < TOUT; ++o) gb2s[o] += src[P_GB2 + o];
   };
@@ -950,19 +1056,24 @@ int dsu_texture_fwd(const dsu_tex_mlp* mlp, const float* tex_in, int64_t n, floa
   if (!mlp_ok(mlp) || n < 0 || (n && (!tex_in || !rgb))) return DSU_EINVAL;
   if (n == 0) return DSU_OK;
   texture_fwd_kernel<false><<<dsu_capped_blocks(n, 256, 2048), 256, 0, (hipStream_t)stream>>>(
-      *mlp, tex_in, ShadeIn{nullptr, nullptr}, nullptr, n, rgb);
+      *mlp, tex_in, ShadeIn{nullptr, nullptr}, nullptr, n, rgb, nullptr);
+  DSU_CHECK_LAUNCH();
+  return DSU_OK;
+}
+
+int dsu_texture_fwd_shaded_m(const dsu_tex_mlp* mlp, const float* feature, const float* grad,
+                             int64_t n, float* normal, float* rgb, uint32_t* h1_mask, void* stream) {
+  if (!mlp_ok(mlp) || n < 0 || (n && (!feature || !grad || !normal || !rgb))) return DSU_EINVAL;
+  if (n == 0) return DSU_OK;
+  texture_fwd_kernel<true><<<dsu_capped_blocks(n, 256, 2048), 256, 0, (hipStream_t)stream>>>(
+      *mlp, nullptr, ShadeIn{feature, grad}, normal, n, rgb, h1_mask);
   DSU_CHECK_LAUNCH();
   return DSU_OK;
 }
 
 int dsu_texture_fwd_shaded(const dsu_tex_mlp* mlp, const float* feature, const float* grad,
                            int64_t n, float* normal, float* rgb, void* stream) {
-  if (!mlp_ok(mlp) || n < 0 || (n && (!feature || !grad || !normal || !rgb))) return DSU_EINVAL;
-  if (n == 0) return DSU_OK;
-  texture_fwd_kernel<true><<<dsu_capped_blocks(n, 256, 2048), 256, 0, (hipStream_t)stream>>>(
-      *mlp, nullptr, ShadeIn{feature, grad}, normal, n, rgb);
-  DSU_CHECK_LAUNCH();
-  return DSU_OK;
+  return dsu_texture_fwd_shaded_m(mlp, feature, grad, n, normal, rgb, nullptr, stream);
 }
 
 int64_t dsu_texture_bwd_workspace_bytes(int64_t n) {
@@ -1052,6 +1163,15 @@ int dsu_texture_bwd_shaded_partials(const dsu_tex_mlp* mlp, const float* feature
                                     int64_t n, int64_t tail_rows, float* d_grad, float* d_feature,
                                     void* workspace, int64_t workspace_bytes,
                                     dsu_partial_reduce* red, void* stream) {
+  return dsu_texture_bwd_shaded_partials_m(mlp, feature, grad, rgb, d_rgb, d_normal, n, tail_rows, d_grad,
+                                           d_feature, nullptr, workspace, workspace_bytes, red, stream);
+}
+
+int dsu_texture_bwd_shaded_partials_m(const dsu_tex_mlp* mlp, const float* feature, const float* grad,
+                                      const float* rgb, const float* d_rgb, const float* d_normal,
+                                      int64_t n, int64_t tail_rows, float* d_grad, float* d_feature,
+                                      const uint32_t* h1_mask, void* workspace, int64_t workspace_bytes,
+                                      dsu_partial_reduce* red, void* stream) {
   if (!mlp_ok(mlp) || n < 0 || !red) return DSU_EINVAL;
   if (tail_rows < 0 || (n && (!feature || !grad || !rgb || !d_rgb || !d_grad || !d_feature)))
     return DSU_EINVAL;
@@ -1061,10 +1181,17 @@ int dsu_texture_bwd_shaded_partials(const dsu_tex_mlp* mlp, const float* feature
   hipStream_t s = (hipStream_t)stream;
   const int blocks = dsu_onewave_blocks(n, 256, TEX_MAX_BLOCKS);
   const size_t shm = (size_t)BWD_LDS_F * sizeof(float);
-  DSU_ENSURE_DYN_LDS(texture_bwd_kernel<true>, shm);
-  texture_bwd_kernel<true><<<blocks, 256, shm, s>>>(*mlp, nullptr, ShadeIn{feature, grad},
-                                                   ShadeOut{d_normal, d_grad, d_feature, tail_rows}, rgb, d_rgb,
-                                                   n, nullptr, (float*)workspace);
+  if (h1_mask) {
+    DSU_ENSURE_DYN_LDS((texture_bwd_kernel<true, true>), shm);
+    texture_bwd_kernel<true, true><<<blocks, 256, shm, s>>>(*mlp, nullptr, ShadeIn{feature, grad},
+                                                           ShadeOut{d_normal, d_grad, d_feature, tail_rows}, rgb,
+                                                           d_rgb, n, nullptr, (float*)workspace, h1_mask);
+  } else {
+    DSU_ENSURE_DYN_LDS(texture_bwd_kernel<true>, shm);
+    texture_bwd_kernel<true><<<blocks, 256, shm, s>>>(*mlp, nullptr, ShadeIn{feature, grad},
+                                                     ShadeOut{d_normal, d_grad, d_feature, tail_rows}, rgb, d_rgb,
+                                                     n, nullptr, (float*)workspace);
+  }
   DSU_CHECK_LAUNCH();
   red->partials = (const float*)workspace;
   red->nblocks = blocks;

@@ -502,13 +502,19 @@ def texture_bwd(params, tex_in, rgb, d_rgb):
     return d_in, g
 
 
-def texture_fwd_shaded(params, feature, grad):
-    """shade_prep_fwd + texture_fwd in one launch: returns (normal (n,3), rgb (n,3))."""
+def texture_fwd_shaded(params, feature, grad, with_mask=False):
+    """shade_prep_fwd + texture_fwd in one launch: returns (normal (n,3), rgb (n,3)) and, with_mask,
+    the ReLU pattern of hidden layer 1 ((n,2) int32 words) for texture_bwd_shaded_partials(h1_mask=)."""
     feature, grad = _f32c(feature), _f32c(grad)
     n = feature.shape[0]
     normal = torch.empty((n, 3), dtype=torch.float32, device=feature.device)
     rgb = torch.empty((n, 3), dtype=torch.float32, device=feature.device)
     m = _tex_struct(params)
+    if with_mask:
+        mask = torch.empty((n, 2), dtype=torch.int32, device=feature.device)
+        check(lib().dsu_texture_fwd_shaded_m(C.byref(m), ptr(feature), ptr(grad), n, ptr(normal), ptr(rgb),
+                                             ptr(mask), stream()), "dsu_texture_fwd_shaded_m")
+        return normal, rgb, mask
     check(lib().dsu_texture_fwd_shaded(C.byref(m), ptr(feature), ptr(grad), n, ptr(normal), ptr(rgb),
                                        stream()), "dsu_texture_fwd_shaded")
     return normal, rgb
@@ -553,10 +559,11 @@ class DeferredSum:
         self.record, self.keep = record, keep
 
 
-def texture_bwd_shaded_partials(params, feature, grad, rgb, d_rgb, d_normal, tail_rows=0):
+def texture_bwd_shaded_partials(params, feature, grad, rgb, d_rgb, d_normal, tail_rows=0, h1_mask=None):
     """texture_bwd_shaded WITHOUT the final sum: returns (d_grad, d_feature, g_flat, deferred) where
     g_flat (zeros now) is the contiguous gradient block the deferred sum will be added to by the
-    launch it is handed to (sdf_fd_bwd(..., extra=deferred))."""
+    launch it is handed to (sdf_fd_bwd(..., extra=deferred)).  h1_mask: texture_fwd_shaded(with_mask=True)'s
+    pattern (the recompute of layer 1 then runs as bf16 x 3)."""
     from ._lib import PartialReduce
     feature, grad, rgb, d_rgb = _f32c(feature), _f32c(grad), _f32c(rgb), _f32c(d_rgb)
     n = rgb.shape[0]
@@ -569,10 +576,11 @@ def texture_bwd_shaded_partials(params, feature, grad, rgb, d_rgb, d_normal, tai
     m = _tex_struct(params)
     dn = None if d_normal is None else _f32c(d_normal)
     rec = PartialReduce()
-    check(lib().dsu_texture_bwd_shaded_partials(C.byref(m), ptr(feature), ptr(grad), ptr(rgb),
-                                                ptr(d_rgb), ptr(dn), n, int(tail_rows), ptr(d_grad),
-                                                ptr(d_feat), ptr(ws), wbytes, C.byref(rec), stream()),
-          "dsu_texture_bwd_shaded_partials")
+    check(lib().dsu_texture_bwd_shaded_partials_m(C.byref(m), ptr(feature), ptr(grad), ptr(rgb),
+                                                  ptr(d_rgb), ptr(dn), n, int(tail_rows), ptr(d_grad),
+                                                  ptr(d_feat), ptr(h1_mask, torch.int32), ptr(ws), wbytes,
+                                                  C.byref(rec), stream()),
+          "dsu_texture_bwd_shaded_partials_m")
     tmap = torch.from_numpy(texture_partial_map()).to(dev)
     rec.map, rec.base = tmap.data_ptr(), flat.data_ptr()
     return d_grad, d_feat, flat, DeferredSum(rec, (ws, tmap, flat))

@@ -432,6 +432,18 @@ int dsu_texture_bwd_shaded_partials(const dsu_tex_mlp* mlp, const float* feature
                                     int64_t n, int64_t tail_rows, float* d_grad, float* d_feature,
                                     void* workspace, int64_t workspace_bytes,
                                     dsu_partial_reduce* red, void* stream);
+/* The pair with the ReLU pattern of hidden layer 1 handed from the forward to the backward
+ * (h1_mask: (n, 2) uint32, word h of a sample = its hidden units 32 T + (r & 3) + 8 (r >> 2) + 4 h,
+ * bit 16 T + r): the backward then recomputes layer 1 with three bf16 products per f32 product
+ * (2^-16 relative on the activations) while the masks stay the forward's, bit for bit.  NULL mask =
+ * the calls above (exact f32 recompute). */
+int dsu_texture_fwd_shaded_m(const dsu_tex_mlp* mlp, const float* feature, const float* grad,
+                             int64_t n, float* normal, float* rgb, uint32_t* h1_mask, void* stream);
+int dsu_texture_bwd_shaded_partials_m(const dsu_tex_mlp* mlp, const float* feature, const float* grad,
+                                      const float* rgb, const float* d_rgb, const float* d_normal,
+                                      int64_t n, int64_t tail_rows, float* d_grad, float* d_feature,
+                                      const uint32_t* h1_mask, void* workspace, int64_t workspace_bytes,
+                                      dsu_partial_reduce* red, void* stream);
 
 /* OrthoNeuSSystem.preprocess_data (systems/neus_ortho.py:26-82) for n sampled (view, y, x)
  * triples (int64, drawn by the caller): c2w gather, get_ortho_rays (models/ray_utils.py:36-58),

@@ -203,6 +203,53 @@ def test_texture_mlp_kernels_match_torch(dev, n):
         assert float((got - p.grad).abs().max()) < 2e-4 * scale, (tuple(p.shape), scale)
 
 
+@pytest.mark.parametrize("n", [1, 97, 4096 + 33, 262144 + 37])
+def test_texture_backward_with_the_forwards_relu_pattern(dev, n):
+    """dsu_texture_fwd_shaded_m hands the ReLU pattern of hidden layer 1 to the backward
+    (dsu_texture_bwd_shaded_partials_m), whose recompute of that layer then runs as bf16 x 3: the
+    pattern is the exact forward's (bit for bit against a torch forward away from |pre| < 1e-6), and
+    every gradient stays within the bf16 x 3 bound (2e-4 of its largest entry here; measured ~1e-5
+    rel-L2) of the exact-recompute path — what the NSR step driver runs."""
+    g = torch.Generator().manual_seed(1000 + n)
+    mk = lambda *s: torch.randn(*s, generator=g).to(dev)
+    params = [mk(64, 16) * 0.3, mk(64) * 0.1, mk(64, 64) * 0.15, mk(64) * 0.1, mk(3, 64) * 0.2, mk(3) * 0.1]
+    feat, grad = mk(n, 13) * 0.5, mk(n, 3)
+    d_rgb, d_nrm = mk(n, 3), mk(n, 3) * 0.1
+    normal, rgb = ops.texture_fwd_shaded(params, feat, grad)
+    normal2, rgb2, mask = ops.texture_fwd_shaded(params, feat, grad, with_mask=True)
+    assert torch.equal(rgb, rgb2) and torch.equal(normal, normal2)
+    # the pattern against a torch forward
+    x = torch.cat([feat, torch.nn.functional.normalize(grad, dim=-1)], -1)
+    h0 = torch.relu(torch.nn.functional.linear(x, params[0], params[1]))
+    pre1 = torch.nn.functional.linear(h0, params[2], params[3])
+    unit = torch.arange(64, device=dev)
+    hh, T, low = (unit >> 2) & 1, unit >> 5, unit & 31
+    r = (low & 3) + 4 * (low >> 3)                       # unit = 32 T + (r & 3) + 8 (r >> 2) + 4 h
+    bits = (mask[:, hh].long() >> (16 * T + r)) & 1      # (n, 64)
+    clear = pre1.abs() > 1e-5
+    assert torch.equal(bits[clear] == 1, (pre1 > 0)[clear])
+    a = ops.texture_bwd_shaded_partials(params, feat, grad, rgb, d_rgb, d_nrm, 8)
+    b = ops.texture_bwd_shaded_partials(params, feat, grad, rgb, d_rgb, d_nrm, 8, h1_mask=mask)
+    for k in range(2):
+        tol = 2e-4 * float(a[k].abs().max()) + 1e-12
+        assert float((a[k] - b[k]).abs().max()) <= tol, k
+    assert not bool(b[1][n:].any())                      # tail rows zeroed
+    # the deferred parameter sums (carried out here by the reduction the scatter launch would do)
+    ga = ops.texture_bwd_shaded(params, feat, grad, rgb, d_rgb, d_nrm, 0)[2]
+    from drawingspinup_amd.ops import texture_partial_map
+    tmap = torch.from_numpy(texture_partial_map()).to(dev).long()
+    rec = b[3].record
+    nb, stride, npart = int(rec.nblocks), int(rec.stride), int(rec.n)
+    ws = b[3].keep[0][:nb * stride].view(nb, stride)[:, :npart].sum(0)
+    flat = torch.zeros(sum(t.numel() for t in params), device=dev)
+    flat.index_add_(0, tmap[tmap >= 0], ws[tmap >= 0])
+    off = 0
+    for t, gx in zip(params, ga):
+        got = flat[off:off + t.numel()].view_as(t)
+        off += t.numel()
+        assert float((got - gx).abs().max()) <= 2e-4 * float(gx.abs().max()) + 1e-12, tuple(t.shape)
+
+
 def test_texture_autograd_function_in_model(dev):
     from drawingspinup_amd.nsr.model import DEFAULT_MODEL_CONFIG, VolumeRadiance
     tex = VolumeRadiance(DEFAULT_MODEL_CONFIG.texture).to(dev)
