@@ -1139,6 +1139,23 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_mfma_kernel(
 // <NL, true, true>, the tail sharing included.  tests/test_gpu_hashgrid.py compares it with the general
 // kernel's cache-less form (no tail sharing there): MLP gradients bit-identical where the ranges are
 // whole iterations, equal to float summation order elsewhere.
+// gW0 of the OFFSET evaluations as bf16 x 3 on v_mfma_f32_32x32x16_bf16 (K = 16 points per MFMA): ablating
+// its 64 f32 MFMAs per evaluation took 46 us off the kernel although they run beside the other half's
+// VALU work (profiles/round6_pipe_ablation.txt).  Operands staged TRANSPOSED per wave:
+//   dPre^T [hi|mid][64 units][PT_ROW] bf16 — the hi / mid fragments the dIn product splits anyway —,
+//   In'^T  [hi|mid][32 input columns][PT_ROW] (rows nobody writes stay zero for the launch),
+// PT_ROW = 40 (80-byte rows: the 16-byte fragments of 16 lanes fall on 16 different bank quads).
+// 12 MFMAs of 32 clocks per point half instead of 32 of 64.  (-DDSU_PIPE_GW0_F32: the f32 form, A/B.)
+constexpr int PT_ROW = 40;
+constexpr int PT_IMGD = 2 * 64 * PT_ROW, PT_IMGI = 2 * 32 * PT_ROW;      // bf16 elements
+constexpr int PT_IMGO = 2 * 32 * PT_ROW;                                  // dOut^T of the centre evaluation (gW1)
+#ifdef DSU_PIPE_GW0_F32
+constexpr int PIPE_IMG_F = 0;
+#else
+constexpr int PIPE_IMG_F = (PT_IMGD + PT_IMGI + PT_IMGO) / 2;             // floats per wave (5120)
+#endif
+constexpr int PIPE_LDS_F = W1P_F + 4 * STAGE_F + 4 * PIPE_IMG_F;
+
 template <int NL, int ACT>
 __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
     dsu_sdf_mlp mlp, const float* __restrict__ pts, int64_t n, float radius, float eps, float eps2,
@@ -1192,6 +1209,12 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
   load_w1perm(w1perm, b1s, mlp);
   // In' and dOut rows: the columns nobody writes (masked levels, padding) stay zero for the launch
   for (int t = lane; t < 2 * 32 * SIN_ROW; t += 64) sin_[t] = 0.0f;
+#ifndef DSU_PIPE_GW0_F32
+  __bf16* imgD = reinterpret_cast<__bf16*>(lds + W1P_F + 4 * STAGE_F + wave * PIPE_IMG_F);
+  __bf16* imgI = imgD + PT_IMGD;
+  __bf16* imgO = imgI + PT_IMGI;
+  for (int t = lane; t < (PT_IMGI + PT_IMGO) / 2; t += 64) reinterpret_cast<uint32_t*>(imgI)[t] = 0u;
+#endif
   __syncthreads();
 
   f32x16 gw0[2], gw1[2];
@@ -1303,8 +1326,13 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
       constexpr int tb = K / 4, u = K % 4;
       if (u == 0 && tb + 1 < 4) ld(tb + 1, q[(tb + 1) & 1]);
       const float* d = q[tb & 1] + 3 * u;
+#if !(defined(DSU_PIPE_ABL) && (DSU_PIPE_ABL & 8))
       acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[0], d[2], acc[0], 0, 0, 0);
       acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(d[1], d[2], acc[1], 0, 0, 0);
+#else
+      acc[0][K & 15] += d[0] * d[2];                 // (timing ablation: the staged operands stay live)
+      acc[1][K & 15] += d[1] * d[2];
+#endif
       filler(kc);
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -1318,7 +1346,11 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
     step(std::integral_constant<int, 14>{}); step(std::integral_constant<int, 15>{});
   };
   auto store_din = [&](int e, const f32x16& din, int64_t pi, int64_t r1) {
+#if defined(DSU_PIPE_ABL) && (DSU_PIPE_ABL & 2)
+    if (pi < r1 && din[0] == 12345.678f) {        // (timing ablation: no dIn stores)
+#else
     if (pi < r1) {
+#endif
 #pragma unroll
       for (int r = 0; r < 16; r += 2) {
         const int la = ((r & 3) + 8 * (r >> 2)) / 2;      // this register pair's level for h = 0
@@ -1330,10 +1362,57 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
     }
   };
 
+#ifndef DSU_PIPE_GW0_F32
+  // hi / mid fragments of dPre (registers 8 g + t of tile T = units 32 T + (t & 3) + 8 (2 g + (t >> 2)) + 4 h
+  // of the point in column l31) -> the transposed image, two-byte stores at compile-time offsets
+  auto stage_dpre_T = [&](int T, int g, const bf16x8& bh, const bf16x8& bm) {
+    __bf16* base = imgD + 4 * h * PT_ROW + l31;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int u = 32 * T + (t & 3) + 8 * (2 * g + (t >> 2));
+      base[u * PT_ROW] = bh[t];
+      base[(64 + u) * PT_ROW] = bm[t];
+    }
+  };
+  // the lane's own inputs -> rows (input columns) of In'^T: features at their column, (x, y, z, 1) at 2 NL ..
+  auto stage_in_T = [&](const float (&in)[2 * KPA]) {
+    __bf16* base = imgI + l31;
+#pragma unroll
+    for (int j = 0; j < 2 * KPA; ++j) {
+      const int row = j < 2 * ACT ? j : 2 * NL + (j - 2 * ACT);
+      const __bf16 hi = (__bf16)in[j];
+      base[row * PT_ROW] = hi;
+      base[(32 + row) * PT_ROW] = (__bf16)(in[j] - (float)hi);
+    }
+  };
+  // acc[Ti][unit][column] += dPre^T . In' over the 32 staged points; a quarter of the filler's 16 pieces
+  // behind each group of three MFMAs, fenced as in gemm_points_with
+  auto gemm_T_with = [&](f32x16 (&acc)[2], const __bf16* imgB, auto&& filler) {
+    auto frag = [&](const __bf16* img, int row, int ks) {
+      return *reinterpret_cast<const bf16x8*>(img + row * PT_ROW + 16 * ks + 8 * h);
+    };
+    auto step = [&](auto sc) {
+      constexpr int S = decltype(sc)::value;
+      constexpr int ks = S >> 1, Ti = S & 1;
+      const bf16x8 bh = frag(imgB, l31, ks), bm = frag(imgB + 32 * PT_ROW, l31, ks);
+      const bf16x8 ah = frag(imgD, 32 * Ti + l31, ks), am = frag(imgD + 64 * PT_ROW, 32 * Ti + l31, ks);
+      acc[Ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[Ti], 0, 0, 0);
+      acc[Ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bm, acc[Ti], 0, 0, 0);
+      acc[Ti] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, bh, acc[Ti], 0, 0, 0);
+      filler(std::integral_constant<int, 4 * S + 0>{});
+      filler(std::integral_constant<int, 4 * S + 1>{});
+      filler(std::integral_constant<int, 4 * S + 2>{});
+      filler(std::integral_constant<int, 4 * S + 3>{});
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    step(std::integral_constant<int, 0>{}); step(std::integral_constant<int, 1>{});
+    step(std::integral_constant<int, 2>{}); step(std::integral_constant<int, 3>{});
+  };
+#endif
   const int64_t per = ((n + gridDim.x - 1) / gridDim.x + 31) / 32 * 32;
   const int64_t r0 = blockIdx.x * per;
   const int64_t r1 = r0 + per < n ? r0 + per : n;
-#ifdef DSU_PIPE_ABL   // (timing ablation, variant build: prologue + epilogue only)
+#if defined(DSU_PIPE_ABL) && (DSU_PIPE_ABL & 1)   // (timing ablation, variant build: prologue + epilogue only)
   for (int64_t bbase = r1; bbase < r1; bbase += blockDim.x) {
 #else
   for (int64_t bbase = r0; bbase < r1; bbase += blockDim.x) {
@@ -1451,9 +1530,56 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
               dpre[4 * qd + 3] = fmaf(w.w, dv, dpre[4 * qd + 3]);
             }
           }
+#ifdef DSU_PIPE_GW0_F32
           din_tile(T, dpre, Hh[T], din);
           stage_rows(sd, T, dpre);
+#else
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            dpre[r] *= 1.0f - __builtin_amdgcn_exp2f(Hh[T][r] * -144.26950408889634f);
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            bf16x8 bh, bm;
+            bf16_split8(&dpre[8 * g], bh, bm);
+            din = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_hi[T][g], bh, din, 0, 0, 0);
+            din = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_hi[T][g], bm, din, 0, 0, 0);
+            din = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_mid[T][g], bh, din, 0, 0, 0);
+            stage_dpre_T(T, g, bh, bm);
+          }
+#endif
         }
+#ifndef DSU_PIPE_GW0_F32
+        // the centre's two contractions over the points as bf16 x 3 as well: gW0 from dPre^T / In'^T, then
+        // gW1[unit][o'] from the hidden activations (split here) and dOut^T (13 rows of a 32-row image)
+        if (h == half) {
+          stage_in_T(in);
+#pragma unroll
+          for (int o = 0; o < NOUT; ++o) {
+            const __bf16 hi = (__bf16)dout[o];
+            imgO[o * PT_ROW + l31] = hi;
+            imgO[(32 + o) * PT_ROW + l31] = (__bf16)(dout[o] - (float)hi);
+          }
+        }
+        __builtin_amdgcn_wave_barrier();
+        gemm_T_with(gw0, imgI, [](auto) {});
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int T = 0; T < 2; ++T)
+#pragma unroll
+          for (int g = 0; g < 2; ++g) {
+            float hv[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) hv[t] = Hh[T][8 * g + t];
+            bf16x8 bh, bm;
+            bf16_split8(hv, bh, bm);
+            stage_dpre_T(T, g, bh, bm);
+          }
+        __builtin_amdgcn_wave_barrier();
+        gemm_T_with(gw1, imgO, [](auto) {});
+        __builtin_amdgcn_wave_barrier();
+        store_din(0, din, wave_first + half * 32 + l31, r1);
+      }
+#else
         if (h == half) {
           stage_in(in);
 #pragma unroll
@@ -1482,6 +1608,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
         __builtin_amdgcn_wave_barrier();
         store_din(0, din, wave_first + half * 32 + l31, r1);
       }
+#endif
       if (e + e_step < 7) handover();
       e += e_step;
     }
@@ -1566,14 +1693,37 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
       for (int T = 0; T < 2; ++T) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) dp0[T][r] = w1o0[T][r] * d0h0;
+#ifdef DSU_PIPE_GW0_F32
         din_tile(T, dp0[T], H0[T], din0);
         stage_rows(sd, T, dp0[T]);
+#else
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          dp0[T][r] *= 1.0f - __builtin_amdgcn_exp2f(H0[T][r] * -144.26950408889634f);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+          bf16x8 bh, bm;
+          bf16_split8(&dp0[T][8 * g], bh, bm);
+          din0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_hi[T][g], bh, din0, 0, 0, 0);
+          din0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_hi[T][g], bm, din0, 0, 0, 0);
+          din0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_mid[T][g], bh, din0, 0, 0, 0);
+          stage_dpre_T(T, g, bh, bm);
+        }
+#endif
       }
+#ifdef DSU_PIPE_GW0_F32
       if (h == 0) stage_in(in);
+#else
+      if (h == 0) stage_in_T(in);
+#endif
       __builtin_amdgcn_sched_barrier(0);
       // P4: gW0 over half 0's points  ||  Softplus, column-0 sums, dPre x sigmoid of half 1: two
       // hidden units behind the two MFMAs of every point pair
+#ifdef DSU_PIPE_GW0_F32
       gemm_points_with(gw0, sin_, [&](auto kc) {
+#else
+      gemm_T_with(gw0, imgI, [&](auto kc) {
+#endif
         constexpr int K = decltype(kc)::value;
 #pragma unroll
         for (int v = 2 * K; v < 2 * K + 2; ++v) {
@@ -1596,16 +1746,27 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
           din1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_hi[T][g], bh, din1, 0, 0, 0);
           din1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_hi[T][g], bm, din1, 0, 0, 0);
           din1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0t_mid[T][g], bh, din1, 0, 0, 0);
+#ifndef DSU_PIPE_GW0_F32
+          if (live1) stage_dpre_T(T, g, bh, bm);          // (behind P4's reads of the image: in-order LDS queue)
+#endif
         }
       store_din(e, din0, wave_first + l31, r1);
       const int en = e + e_step < 7 ? e + e_step : 6;    // next evaluation (clamped: unused at the end)
       if (live1) {
+#ifdef DSU_PIPE_GW0_F32
 #pragma unroll
         for (int T = 0; T < 2; ++T) stage_rows(sd, T, dp1[T]);
         if (h == 1) stage_in(in);
+#else
+        if (h == 1) stage_in_T(in);
+#endif
         __builtin_amdgcn_sched_barrier(0);
         // P6: gW0 over half 1's points  ||  half 1's dIn out, the next evaluation's inputs
+#ifdef DSU_PIPE_GW0_F32
         gemm_points_with(gw0, sin_, [&](auto kc) {
+#else
+        gemm_T_with(gw0, imgI, [&](auto kc) {
+#endif
           constexpr int K = decltype(kc)::value;
           if (K == 1) store_din(e, din1, wave_first + 32 + l31, r1);
           if (K == 3) {
@@ -1634,6 +1795,11 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
     }
   }
 
+#if defined(DSU_PIPE_ABL) && (DSU_PIPE_ABL & 4)
+  partials[(size_t)blockIdx.x * PART_STRIDE + threadIdx.x] =      // (timing ablation: no reduction)
+      gw0[0][0] + gw0[1][1] + gw1[0][2] + gw1[1][3] + gw1c0[0][4] + gw1c0[1][5] + gb1[0];
+  return;
+#endif
   // ---- workgroup reduction of the parameter-gradient tiles -> one partial vector per workgroup
   __syncthreads();
   float* red = lds + W1P_F;                     // [4 waves][PART_STRIDE] (fits: 4*4160 floats)
@@ -1677,11 +1843,13 @@ bool launch_bwd_pipe_one(uint32_t active, int blocks, size_t shm, hipStream_t s,
   static bool lds_ok = false;
   if (!lds_ok) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(sdf_fd_bwd_pipe_kernel<NL, ACT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)
+                            hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)(PIPE_LDS_F * sizeof(float))) != hipSuccess)
       return false;
     lds_ok = true;
   }
-  sdf_fd_bwd_pipe_kernel<NL, ACT><<<dim3(blocks), dim3(256), shm, s>>>(
+  (void)shm;
+  sdf_fd_bwd_pipe_kernel<NL, ACT><<<dim3(blocks), dim3(256), PIPE_LDS_F * sizeof(float), s>>>(
       mlp, pts, n, radius, eps, eps2, d_sdf, d_grad, d_feature, d_laplace, partials, enc, dinbuf, perm);
   return true;
 }

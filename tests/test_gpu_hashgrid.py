@@ -190,7 +190,8 @@ def test_sdf_fd_bwd_pipelined_kernel_equals_the_general_kernel(dev, active, n):
     reached by the call WITHOUT a cache, which re-gathers the same f16 features; in that form it
     does not share the last partial iteration of a workgroup's range between the waves, so:
       * where every range is whole 256-point iterations (n = 256 k up to 256 workgroups, or a
-        multiple of 256 * 256) the MLP gradients of the two are bit-identical;
+        multiple of 256 * 256) g_b1 of the two is bit-identical (the weight gradients: bf16 x 3
+        products in the pipelined kernel, 6e-5 of the largest entry);
       * otherwise (fewer points than workgroups, a last partial iteration of <= 64 / <= 128 points
         whose evaluations the waves share, a lone second half) the same per-point terms are summed
         by different waves: equal to float summation order (measured <= 1.1e-5 of the largest
@@ -207,11 +208,16 @@ def test_sdf_fd_bwd_pipelined_kernel_equals_the_general_kernel(dev, active, n):
     gt0, gm0 = ops.sdf_fd_bwd(CFG, tab, mlp, pts, radius, eps, active, *d)
     gt1, gm1 = ops.sdf_fd_bwd(CFG, tab, mlp, pts, radius, eps, active, *d, enc_cache=fwd[4])
     whole = n % 256 == 0 and (n <= 256 * 256 or n % (256 * 256) == 0)
-    for a_, b_ in zip(gm0, gm1):
-        if whole:
+    for k, (a_, b_) in enumerate(zip(gm0, gm1)):
+        # (g_w0, g_b0, g_w1: the contractions over the points run as bf16 x 3 in the pipelined
+        # kernel — 2^-16 per product; g_b1 comes from identical operations)
+        if whole and k == 3:
             assert torch.equal(a_, b_)
         else:
-            assert float((a_ - b_).abs().max()) <= 3e-5 * float(a_.abs().max())
+            # a bf16 x 3 product is good to ~2^-16 of ITSELF; with a handful of points an entry is a sum of
+            # seven evaluations' terms of alternating sign (+-0.5 d_grad / eps), larger than the entry
+            tol = 3e-4 if n < 1000 else 6e-5
+            assert float((a_ - b_).abs().max()) <= tol * float(a_.abs().max()), (k, n, active)
     # (the same entries are touched; an entry whose float atomics cancel to exactly 0.0 in one order
     # and to a rounding residue in the other is covered by the bound on the difference)
     mism = (gt0 != 0) ^ (gt1 != 0)
