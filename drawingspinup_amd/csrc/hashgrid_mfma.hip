@@ -1188,6 +1188,30 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
       const int t = tt < ACT ? tt : NL + (tt - ACT);
       w0a[T][tt] = w0p<NL>(mlp, 32 * T + l31, 2 * t + h);
     }
+  // Layer 0 of the recompute as bf16 x 3 when its 2 KPA inputs fit one 16-deep MFMA (ACT <= 6, the
+  // optimisation's schedule): an ablation priced the 2 x KPA f32 MFMAs per point half at 51 us of the kernel.
+  // A fragments: W0'[unit 32 T + l31][input 8 h + t] hi / mid (inputs in the order of `in`).
+#ifdef DSU_PIPE_L0_F32
+  constexpr bool L0BF = false;
+#else
+  constexpr bool L0BF = 2 * KPA <= 16;
+#endif
+  bf16x8 w0b_hi[2], w0b_mid[2];
+  if constexpr (L0BF) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+      float w[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int j = 8 * h + t, tt = j >> 1;
+        const bool real = j < 2 * KPA;
+        const int t_ = tt < ACT ? tt : NL + (tt - ACT);
+        const float v = w0p<NL>(mlp, 32 * T + l31, real ? 2 * t_ + (j & 1) : 0);
+        w[t] = real ? v : 0.0f;
+      }
+      bf16_split8(w, w0b_hi[T], w0b_mid[T]);
+    }
+  }
   float w1o0[2][16];
 #pragma unroll
   for (int T = 0; T < 2; ++T)
@@ -1240,7 +1264,46 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
       for (int r = 0; r < 16; ++r) acc[T][r] = 0.0f;
 #pragma unroll
       for (int tt = 0; tt < KPA; ++tt)
+#if defined(DSU_PIPE_ABL) && (DSU_PIPE_ABL & 16)
+        acc[T][tt & 15] += w0a[T][tt] * b[tt];        // (timing ablation: no layer-0 MFMAs)
+#else
         acc[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0a[T][tt], b[tt], acc[T], 0, 0, 0);
+#endif
+    }
+  };
+  // B fragments of layer 0 for both point halves from the lane's own inputs: packed bf16 hi / mid pairs,
+  // one permlane32 swap per dword (the lane of half h' holds inputs 8 h' .. 8 h' + 7 of the column's point)
+  typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+  auto l0_operands = [&](const float (&in)[2 * KPA], bf16x8& bh0, bf16x8& bm0, bf16x8& bh1, bf16x8& bm1) {
+    uint32_t ph[8], pm[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const float x0 = 2 * q < 2 * KPA ? in[2 * q < 2 * KPA ? 2 * q : 0] : 0.0f;
+      const float x1 = 2 * q + 1 < 2 * KPA ? in[2 * q + 1 < 2 * KPA ? 2 * q + 1 : 0] : 0.0f;
+      const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
+      const __bf16 m0 = (__bf16)(x0 - (float)h0), m1 = (__bf16)(x1 - (float)h1);
+      ph[q] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
+      pm[q] = (uint32_t)__builtin_bit_cast(uint16_t, m0) | ((uint32_t)__builtin_bit_cast(uint16_t, m1) << 16);
+    }
+    u32x4 a0, a1, c0, c1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      auto r = __builtin_amdgcn_permlane32_swap(ph[q], ph[q + 4], false, false);
+      a0[q] = r[0]; a1[q] = r[1];
+      auto r2 = __builtin_amdgcn_permlane32_swap(pm[q], pm[q + 4], false, false);
+      c0[q] = r2[0]; c1[q] = r2[1];
+    }
+    bh0 = __builtin_bit_cast(bf16x8, a0); bh1 = __builtin_bit_cast(bf16x8, a1);
+    bm0 = __builtin_bit_cast(bf16x8, c0); bm1 = __builtin_bit_cast(bf16x8, c1);
+  };
+  auto l0_bf = [&](const bf16x8& bh, const bf16x8& bm, f32x16 (&acc)[2]) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[T][r] = 0.0f;
+      acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0b_hi[T], bh, acc[T], 0, 0, 0);
+      acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0b_hi[T], bm, acc[T], 0, 0, 0);
+      acc[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0b_mid[T], bh, acc[T], 0, 0, 0);
     }
   };
   auto softplus2 = [&](f32x16 (&acc)[2]) {
@@ -1477,6 +1540,9 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
     };
 
     int e = e_start;
+#if defined(DSU_PIPE_ABL) && (DSU_PIPE_ABL & 32)
+    if (e == 0) { if (e + e_step < 7) handover(); e += e_step; }   // (timing ablation: no centre evaluation)
+#endif
     if (e == 0) {
       // ------------------------------------------------ centre evaluation: 13 upstream gradients
       float in[2 * KPA];
@@ -1494,8 +1560,13 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
 #pragma unroll
       for (int o = 0; o < NOUT; ++o) gb1[o] += dout[o];
       float b0[KPA], b1[KPA];
+      bf16x8 cbh0, cbm0, cbh1, cbm1;
+      if constexpr (L0BF) {
+        l0_operands(in, cbh0, cbm0, cbh1, cbm1);
+      } else {
 #pragma unroll
-      for (int tt = 0; tt < KPA; ++tt) swap_halves(in[2 * tt], in[2 * tt + 1], b0[tt], b1[tt]);
+        for (int tt = 0; tt < KPA; ++tt) swap_halves(in[2 * tt], in[2 * tt + 1], b0[tt], b1[tt]);
+      }
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         if (half == 1 && !live1) break;
@@ -1506,7 +1577,8 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
           d[o] = (h == half) ? dout[o] : other;
         }
         f32x16 Hh[2];
-        l0_half(half ? b1 : b0, Hh);
+        if constexpr (L0BF) l0_bf(half ? cbh1 : cbh0, half ? cbm1 : cbm0, Hh);
+        else l0_half(half ? b1 : b0, Hh);
         softplus2(Hh);
         f32x16 din;
 #pragma unroll
@@ -1660,12 +1732,18 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
       const float d0h0 = h == 0 ? dout0 : other0;       // gradient of the point this lane column holds
       const float d0h1 = h == 1 ? dout0 : other0;       //   in half 0 / half 1
       float b0[KPA], b1[KPA];
+      bf16x8 obh0, obm0, obh1, obm1;
+      if constexpr (L0BF) {
+        l0_operands(in, obh0, obm0, obh1, obm1);
+      } else {
 #pragma unroll
-      for (int tt = 0; tt < KPA; ++tt) swap_halves(in[2 * tt], in[2 * tt + 1], b0[tt], b1[tt]);
+        for (int tt = 0; tt < KPA; ++tt) swap_halves(in[2 * tt], in[2 * tt + 1], b0[tt], b1[tt]);
+      }
       f32x16 H0[2], H1[2], din0, din1;
       float dp0[2][16], dp1[2][16];
       // P1: layer 0 of half 0
-      l0_half(b0, H0);
+      if constexpr (L0BF) l0_bf(obh0, obm0, H0);
+      else l0_half(b0, H0);
       __builtin_amdgcn_sched_barrier(0);
       // P2: layer 0 of half 1  ||  Softplus of half 0 (+ its column-0 sums of gW1), a few hidden units
       // behind every MFMA; the fences keep the interleave the source spells out
@@ -1673,11 +1751,31 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
       for (int T = 0; T < 2; ++T)
 #pragma unroll
         for (int r = 0; r < 16; ++r) H1[T][r] = 0.0f;
+      if constexpr (L0BF) {
+#pragma unroll
+        for (int mi = 0; mi < 6; ++mi) {
+          constexpr int NM = 6;
+          const int T = mi / 3, term = mi % 3;
+          H1[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 2 ? w0b_mid[T] : w0b_hi[T],
+                                                         term == 1 ? obm1 : obh1, H1[T], 0, 0, 0);
+#pragma unroll
+          for (int v = 0; v < 32; ++v)
+            if (v * NM / 32 == mi) {
+              H0[v >> 4][v & 15] = softplus100(H0[v >> 4][v & 15]);
+              gw1c0[v >> 4][v & 15] = fmaf(H0[v >> 4][v & 15], d0h0, gw1c0[v >> 4][v & 15]);
+            }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
 #pragma unroll
       for (int mi = 0; mi < 2 * KPA; ++mi) {
         constexpr int NM = 2 * KPA;
         const int T = mi / KPA, tt = mi % KPA;
+#if defined(DSU_PIPE_ABL) && (DSU_PIPE_ABL & 16)
+        H1[T][tt & 15] += w0a[T][tt] * b1[tt];
+#else
         H1[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0a[T][tt], b1[tt], H1[T], 0, 0, 0);
+#endif
 #pragma unroll
         for (int v = 0; v < 32; ++v)
           if (v * NM / 32 == mi) {
@@ -1685,6 +1783,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
             gw1c0[v >> 4][v & 15] = fmaf(H0[v >> 4][v & 15], d0h0, gw1c0[v >> 4][v & 15]);
           }
         __builtin_amdgcn_sched_barrier(0);
+      }
       }
       // P3: dPre / sigmoid / dIn of half 0, rows to LDS
 #pragma unroll

@@ -174,19 +174,26 @@ def test_sdf_fd_bwd_from_the_feature_cache_vs_float64_autograd(dev):
     gt = gt.cpu().numpy().reshape(-1, 2)
     ref_t = tab64.grad.numpy()
     assert np.array_equal(ref_t != 0, gt != 0)
-    np.testing.assert_allclose(gt, ref_t, rtol=1e-4, atol=1e-5 * np.abs(ref_t).max())
+    # the pipelined kernel recomputes layer 0 and forms dIn / the contractions over the points with three
+    # bf16 products per f32 product (2^-16 each): measured against float64 (tools/sdf_bwd_accuracy.py)
+    # rel-L2 9e-6 (table), 1.2e-5 / 1.8e-5 (W0, b0), 9e-6 (W1); largest element error 2.8e-5 of the
+    # largest entry (the all-f32 MLP part: 5e-6 / 7e-6 / 5e-6 / 8e-6, 1.4e-5)
+    np.testing.assert_allclose(gt, ref_t, rtol=1e-4, atol=4e-5 * np.abs(ref_t).max())
+    assert np.linalg.norm(gt - ref_t) <= 3e-5 * np.linalg.norm(ref_t)
     for got, ref in zip(gm, mlp64):
         r = ref.grad.numpy()
         np.testing.assert_allclose(got.cpu().numpy(), r, rtol=1e-4,
-                                   atol=1e-5 * max(np.abs(r).max(), 1.0))
+                                   atol=5e-5 * max(np.abs(r).max(), 1.0))
+        assert np.linalg.norm(got.cpu().numpy() - r) <= 5e-5 * np.linalg.norm(r)
 
 
 @pytest.mark.parametrize("active", [4, 5, 6, 7])
 @pytest.mark.parametrize("n", [1, 33, 256, 256 * 9, 64 * 256 + 5, 256 * 96 + 40, 256 * 256 * 2,
                                256 * 288 + 17, 70001])
 def test_sdf_fd_bwd_pipelined_kernel_equals_the_general_kernel(dev, active, n):
-    """sdf_fd_bwd_pipe_kernel (backward from the feature cache, 4..7 active levels) performs the
-    general kernel's operations in the general kernel's order per value.  The general kernel is
+    """sdf_fd_bwd_pipe_kernel (backward from the feature cache, 4..7 active levels) against the general
+    kernel (exact f32 MLP part): the pipelined kernel forms layer 0 of its recompute (4..6 levels), dIn and
+    the contractions over the points with three bf16 products per f32 product.  The general kernel is
     reached by the call WITHOUT a cache, which re-gathers the same f16 features; in that form it
     does not share the last partial iteration of a workgroup's range between the waves, so:
       * where every range is whole 256-point iterations (n = 256 k up to 256 workgroups, or a
@@ -216,13 +223,13 @@ def test_sdf_fd_bwd_pipelined_kernel_equals_the_general_kernel(dev, active, n):
         else:
             # a bf16 x 3 product is good to ~2^-16 of ITSELF; with a handful of points an entry is a sum of
             # seven evaluations' terms of alternating sign (+-0.5 d_grad / eps), larger than the entry
-            tol = 3e-4 if n < 1000 else 6e-5
+            tol = 5e-4 if n < 1000 else 1e-4
             assert float((a_ - b_).abs().max()) <= tol * float(a_.abs().max()), (k, n, active)
     # (the same entries are touched; an entry whose float atomics cancel to exactly 0.0 in one order
     # and to a rounding residue in the other is covered by the bound on the difference)
     mism = (gt0 != 0) ^ (gt1 != 0)
     assert int(mism.sum()) <= 8
-    assert float((gt0 - gt1).abs().max()) <= 2e-6 * float(gt0.abs().max())
+    assert float((gt0 - gt1).abs().max()) <= (5e-4 if n < 1000 else 1e-4) * float(gt0.abs().max())
 
 
 def test_sdf_fd_bwd_points_outside_the_box(dev):
@@ -270,11 +277,13 @@ def test_sdf_fd_feature_cache_round_trip(dev):
          torch.randn(n, 13, generator=g).to(dev), (torch.randn(n, generator=g) * 1e-3).to(dev)]
     gt0, gm0 = ops.sdf_fd_bwd(CFG, tab, mlp, pts, radius, eps, active, *d)
     gt1, gm1 = ops.sdf_fd_bwd(CFG, tab, mlp, pts, radius, eps, active, *d, enc_cache=cached[4])
+    # (the backward from the cache is the pipelined kernel for 4..7 levels: three bf16 products per f32
+    # product in its recompute of layer 0 and its point contractions — tools/sdf_bwd_accuracy.py)
     scale = float(gt0.abs().max())
-    assert float((gt0 - gt1).abs().max()) < 1e-5 * scale
-    assert torch.equal(gt0 != 0, gt1 != 0)
+    assert float((gt0 - gt1).abs().max()) < 5e-5 * scale
+    assert int(((gt0 != 0) ^ (gt1 != 0)).sum()) <= 8
     for a_, b_ in zip(gm0, gm1):
-        assert float((a_ - b_).abs().max()) < 1e-5 * (float(a_.abs().max()) + 1e-12)
+        assert float((a_ - b_).abs().max()) < 1e-4 * (float(a_.abs().max()) + 1e-12)
 
 
 @pytest.mark.parametrize("active", [4, 5, 6, 7])

@@ -1,5 +1,5 @@
 #!/bin/bash
-# geometry backward, pipelined MLP part: gW0 of the offset evaluations as bf16 x 3 (default) vs f32 (pf32)
+# geometry backward, pipelined MLP part: layer 0 of the recompute as bf16 x 3 (default) vs f32 (pf32: -DDSU_PIPE_L0_F32)
 set -u
 export PYTHONPATH=$(pwd) TMPDIR=/tmp
 O=gpurun_out/${1:-r6_pipegw0}; mkdir -p $O
