@@ -2382,7 +2382,11 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
         const int l15 = lane & 15;
         const bool starts = ((l15 == 0) | (key_prev != key)) & flush;
         const int n_flush = __popcll(__ballot(flush)), n_start = __popcll(__ballot(starts));
+#if defined(DSU_SC_ABL) && (DSU_SC_ABL & 4)
+        if (false) {                                                   // (timing ablation: no run merge)
+#else
         if (lev < merge_levels && 4 * n_start <= 3 * n_flush) {      // uniform
+#endif
           // neighbour keys with all lanes active (a DPP move under the EXEC mask of a
           // short-circuit reads disabled source lanes as 0)
           int ee = ((l15 == 15) | (key_next != key)) ? 1 : 0;   // run ends at this lane
@@ -2406,8 +2410,12 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
 #pragma unroll
             for (int c = 0; c < 8; ++c) {
               const int t = base + (c & 1) + ((c >> 1) & 1) * ddx + ((c >> 2) & 1) * ddxy;
+#if defined(DSU_SC_ABL) && (DSU_SC_ABL & 1)
+              if (v[2 * c] == 12345.678f) tile[2 * t] = gc_fix(v[2 * c + 1]) + (unsigned long long)t;   // (timing ablation: no LDS atomics)
+#else
               atomicAdd(&tile[2 * t], gc_fix(v[2 * c]));
               atomicAdd(&tile[2 * t + 1], gc_fix(v[2 * c + 1]));
+#endif
             }
           }
           continue;
@@ -2444,8 +2452,12 @@ __global__ __launch_bounds__(SC_THREADS) void sdf_fd_scatter_kernel(
             const int y = rr / ddx, x = rr - y * ddx;
             const uint32_t g = l_off + grid_index(l_hashed, hsize, l_res, (uint32_t)(x0 + x),
                                                   (uint32_t)(y0 + y), (uint32_t)(z0 + z));
+#if !(defined(DSU_SC_ABL) && (DSU_SC_ABL & 2))
             unsafeAtomicAdd(gtable + (size_t)g * 2, gc_unfix(a0));
             unsafeAtomicAdd(gtable + (size_t)g * 2 + 1, gc_unfix(a1));
+#else
+            if (g == 0xffffffffu) gtable[0] = gc_unfix(a0) + gc_unfix(a1);      // (timing ablation: no global atomics)
+#endif
             tile[2 * t] = 0ull;
             tile[2 * t + 1] = 0ull;
           }
