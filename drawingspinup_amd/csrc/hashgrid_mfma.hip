@@ -1212,6 +1212,27 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
       bf16_split8(w, w0b_hi[T], w0b_mid[T]);
     }
   }
+  // the centre evaluation's dPre = W1^T . dOut (13 upstream gradients per point) as bf16 x 3 as well:
+  // A fragments W1[o = 8 h + t][unit 32 T + l31] hi / mid (outputs 13..15: zero)
+#ifdef DSU_PIPE_DPRE_VALU
+  constexpr bool DPBF = false;
+#else
+  constexpr bool DPBF = true;
+#endif
+  bf16x8 w1t_hi[2], w1t_mid[2];
+  if constexpr (DPBF) {
+#pragma unroll
+    for (int T = 0; T < 2; ++T) {
+      float w[8];
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int o = 8 * h + t;
+        const float v = mlp.w1[(o < NOUT ? o : 0) * 64 + 32 * T + l31];
+        w[t] = o < NOUT ? v : 0.0f;
+      }
+      bf16_split8(w, w1t_hi[T], w1t_mid[T]);
+    }
+  }
   float w1o0[2][16];
 #pragma unroll
   for (int T = 0; T < 2; ++T)
@@ -1274,12 +1295,13 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
   // B fragments of layer 0 for both point halves from the lane's own inputs: packed bf16 hi / mid pairs,
   // one permlane32 swap per dword (the lane of half h' holds inputs 8 h' .. 8 h' + 7 of the column's point)
   typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-  auto l0_operands = [&](const float (&in)[2 * KPA], bf16x8& bh0, bf16x8& bm0, bf16x8& bh1, bf16x8& bm1) {
+  auto pack_operands = [&](const float* in, auto nc, bf16x8& bh0, bf16x8& bm0, bf16x8& bh1, bf16x8& bm1) {
+    constexpr int NV = decltype(nc)::value;            // values per point (<= 16)
     uint32_t ph[8], pm[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
-      const float x0 = 2 * q < 2 * KPA ? in[2 * q < 2 * KPA ? 2 * q : 0] : 0.0f;
-      const float x1 = 2 * q + 1 < 2 * KPA ? in[2 * q + 1 < 2 * KPA ? 2 * q + 1 : 0] : 0.0f;
+      const float x0 = 2 * q < NV ? in[2 * q < NV ? 2 * q : 0] : 0.0f;
+      const float x1 = 2 * q + 1 < NV ? in[2 * q + 1 < NV ? 2 * q + 1 : 0] : 0.0f;
       const __bf16 h0 = (__bf16)x0, h1 = (__bf16)x1;
       const __bf16 m0 = (__bf16)(x0 - (float)h0), m1 = (__bf16)(x1 - (float)h1);
       ph[q] = (uint32_t)__builtin_bit_cast(uint16_t, h0) | ((uint32_t)__builtin_bit_cast(uint16_t, h1) << 16);
@@ -1562,19 +1584,23 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
       float b0[KPA], b1[KPA];
       bf16x8 cbh0, cbm0, cbh1, cbm1;
       if constexpr (L0BF) {
-        l0_operands(in, cbh0, cbm0, cbh1, cbm1);
+        pack_operands(in, std::integral_constant<int, (2 * KPA <= 16 ? 2 * KPA : 16)>{}, cbh0, cbm0, cbh1, cbm1);
       } else {
 #pragma unroll
         for (int tt = 0; tt < KPA; ++tt) swap_halves(in[2 * tt], in[2 * tt + 1], b0[tt], b1[tt]);
       }
+      bf16x8 dbh0, dbm0, dbh1, dbm1;           // dOut of the column's point, both halves (B fragments)
+      if constexpr (DPBF) pack_operands(dout, std::integral_constant<int, NOUT>{}, dbh0, dbm0, dbh1, dbm1);
 #pragma unroll
       for (int half = 0; half < 2; ++half) {
         if (half == 1 && !live1) break;
         float d[NOUT];
+        if constexpr (!DPBF) {
 #pragma unroll
-        for (int o = 0; o < NOUT; ++o) {
-          const float other = partner32(dout[o], h);
-          d[o] = (h == half) ? dout[o] : other;
+          for (int o = 0; o < NOUT; ++o) {
+            const float other = partner32(dout[o], h);
+            d[o] = (h == half) ? dout[o] : other;
+          }
         }
         f32x16 Hh[2];
         if constexpr (L0BF) l0_bf(half ? cbh1 : cbh0, half ? cbm1 : cbm0, Hh);
@@ -1586,6 +1612,17 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
 #pragma unroll
         for (int T = 0; T < 2; ++T) {
           float dpre[16];
+          if constexpr (DPBF) {
+            f32x16 dacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dacc[r] = 0.0f;
+            const bf16x8 bh = half ? dbh1 : dbh0, bm = half ? dbm1 : dbm0;
+            dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1t_hi[T], bh, dacc, 0, 0, 0);
+            dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1t_hi[T], bm, dacc, 0, 0, 0);
+            dacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1t_mid[T], bh, dacc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) dpre[r] = dacc[r];
+          } else {
 #pragma unroll
           for (int r = 0; r < 16; ++r) dpre[r] = w1o0[T][r] * d[0];
           const float* wp = w1perm + h * NOUT * 32 + T * 16;
@@ -1605,6 +1642,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
               dpre[4 * qd + 2] = fmaf(w.z, dv, dpre[4 * qd + 2]);
               dpre[4 * qd + 3] = fmaf(w.w, dv, dpre[4 * qd + 3]);
             }
+          }
           }
 #ifdef DSU_PIPE_GW0_F32
           din_tile(T, dpre, Hh[T], din);
@@ -1738,7 +1776,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
       float b0[KPA], b1[KPA];
       bf16x8 obh0, obm0, obh1, obm1;
       if constexpr (L0BF) {
-        l0_operands(in, obh0, obm0, obh1, obm1);
+        pack_operands(in, std::integral_constant<int, (2 * KPA <= 16 ? 2 * KPA : 16)>{}, obh0, obm0, obh1, obm1);
       } else {
 #pragma unroll
         for (int tt = 0; tt < KPA; ++tt) swap_halves(in[2 * tt], in[2 * tt + 1], b0[tt], b1[tt]);
