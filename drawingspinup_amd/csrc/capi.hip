@@ -16,9 +16,9 @@ const char* dsu_strerror(int code) {
 int dsu_abi_version(void) { return 1; }
 
 int32_t dsu_onewave_grid_cap_value = 0;     // 0 = one workgroup per CU (256)
-int32_t dsu_scatter_grid_cap_value = 0;     // 0 = one scatter workgroup per CU (256)
+int32_t dsu_scatter_grid_cap_value = 0;     // 0 = the resident count (three 256-thread workgroups per CU: 768)
 int dsu_set_scatter_grid_cap(int32_t workgroups) {
-  if (workgroups < 0 || workgroups > 256) return DSU_EINVAL;
+  if (workgroups < 0 || workgroups > 4096) return DSU_EINVAL;
   dsu_scatter_grid_cap_value = workgroups;
   return DSU_OK;
 }

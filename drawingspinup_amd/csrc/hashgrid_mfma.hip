@@ -2011,25 +2011,33 @@ bool launch_bwd_pipe(uint32_t active, int blocks, size_t shm, hipStream_t s, con
 }
 
 // ---------------------------------------------------------------------------- K2: scatter
-// Table gradients from dinbuf (SPLIT path).  One point per thread, 512 threads (8 waves) per
-// workgroup, one LEVEL at a time for the workgroup's 512 points (so the 4096-slot cache only ever
+// Table gradients from dinbuf (SPLIT path).  One point per thread, SC_THREADS threads per
+// workgroup, one LEVEL at a time for the workgroup's SC_THREADS points (so the 4096-slot cache only ever
 // holds one level's entries and is flushed per level), all 7 evaluations of that level back to
 // back.  Same segmented DPP merge, per-wave queue and fixed-point cache as the fused kernel.
 // Sizes (variant builds override them: -DDSU_SC_THREADS / -DDSU_SC_LOG2 / -DDSU_SC_QCAP).  With the
 // samples in Morton order a workgroup's points of one level touch a compact block of entries, so a
 // small cache is enough and what matters is how many waves a CU holds to hide the returning LDS
 // atomics: LDS bytes per workgroup = 20 * slots + 12 * QCAP * waves.
+// Round 6: 256 threads, 1024 slots, 512-triple queues = 45 KB per workgroup, THREE workgroups per CU
+// (768 resident) instead of one 512-thread workgroup with 150 KB: pair 0.394 -> 0.362 ms in the
+// optimisation (same-box A/B of five shapes, profiles/round6_scatter_shapes_ab.txt: 512 / 2^12 / 704 /
+// 256 = 0.394, 256 / 2^11 / 512 / 512 = 0.380, 256 / 2^10 / 512 / 768 = 0.362, 256 / 2^9 / 512 / 1024 =
+// 0.397, 128 / 2^10 / 512 / 1024 = 0.401).  Items are 256 points x one level: their boxes of cells are
+// about half as large, so the smaller dense tile still takes most items, and a CU's three workgroups
+// hide each other's barriers and returning atomics (and leave LDS to other kernels when several
+// drawings share the GPU).
 #ifndef DSU_SC_THREADS
-#define DSU_SC_THREADS 512
+#define DSU_SC_THREADS 256
 #endif
 #ifndef DSU_SC_LOG2
-#define DSU_SC_LOG2 12
+#define DSU_SC_LOG2 10
 #endif
 #ifndef DSU_SC_QCAP
-#define DSU_SC_QCAP 704
+#define DSU_SC_QCAP 512
 #endif
 #ifndef DSU_SC_MAXBLOCKS
-#define DSU_SC_MAXBLOCKS 256
+#define DSU_SC_MAXBLOCKS 768
 #endif
 constexpr int SC_MAXBLOCKS = DSU_SC_MAXBLOCKS;                // resident workgroups (256 CUs x per-CU count)
 constexpr int SC_THREADS = DSU_SC_THREADS;
@@ -2729,9 +2737,8 @@ int dsu_sdf_fd_bwd_sorted_fold(const dsu_hashgrid_cfg* cfg, const void* table_f1
     const size_t shm2 = (size_t)SC_LDS_TOTAL * sizeof(float);
     float2* dinbuf = reinterpret_cast<float2*>((char*)workspace +
                                                (size_t)blocks * PART_STRIDE * sizeof(float));
-    // (150 KB of LDS per workgroup: one per CU, and no other LDS-using kernel beside it on that CU;
-    // dsu_set_scatter_grid_cap launches fewer when other drawings share the GPU — the items are
-    // handed out dynamically, so any count works)
+    // (dsu_set_scatter_grid_cap launches fewer workgroups — the items are handed out dynamically, so
+    // any count works; measured neutral with drawings in flight)
     int sblocks = dsu_capped_blocks(n, SC_THREADS, SC_MAXBLOCKS);
     if (dsu_scatter_grid_cap_value > 0 && sblocks > dsu_scatter_grid_cap_value) sblocks = dsu_scatter_grid_cap_value;
     DSU_DISPATCH_NL(cfg->n_levels, {

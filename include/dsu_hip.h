@@ -41,8 +41,8 @@ int dsu_abi_version(void);
  * drawings in flight on one GPU fewer workgroups leave CUs to the other drawings' kernels while such
  * a kernel runs (bench.py --inflight: 128).  Process-wide; workspaces stay sized for 256. */
 int dsu_set_onewave_grid_cap(int32_t workgroups);
-/* The same for the table-gradient scatter of the geometry backward (150 KB of LDS per workgroup: one
- * per CU, no other LDS-using kernel beside it). */
+/* The same for the table-gradient scatter of the geometry backward (0 = its resident count: three
+ * 256-thread workgroups of 45 KB LDS per CU). */
 int dsu_set_scatter_grid_cap(int32_t workgroups);
 
 /* ------------------------------------------------------------------------------------
