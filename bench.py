@@ -62,7 +62,7 @@ def parse(argv=None):
                          "default: 4.2 s / inflight)")
     ap.add_argument("--onewave-grid", type=int, default=None,
                     help="workgroups of the NSR step's two one-wave-per-SIMD kernels (dsu_set_onewave_grid_cap); "
-                         "default: 256 with one drawing at a time, 128 with several in flight")
+                         "default: 256 with one drawing at a time, 192 with several in flight")
     ap.add_argument("--scatter-grid", type=int, default=None,
                     help="workgroups of the geometry backward's scatter kernel (dsu_set_scatter_grid_cap); default 256")
     ap.add_argument("--fit-priority", type=int, default=0,
@@ -368,7 +368,7 @@ def _inflight_loop(args, ddist, rank, dev, timer, pipes, inputs, stage_t, sub_t,
         return (t0, t1, t2, t3, t4), views, frames, dict(pipe.substage_seconds)
 
     grid_cap = getattr(args, "onewave_grid", None)
-    grid_cap = 128 if grid_cap is None else int(grid_cap)
+    grid_cap = 192 if grid_cap is None else int(grid_cap)
     if on_gpu:
         from drawingspinup_amd import _lib as dsu_lib
         dsu_lib.check(dsu_lib.lib().dsu_set_onewave_grid_cap(grid_cap), "dsu_set_onewave_grid_cap")

@@ -39,7 +39,7 @@ int dsu_abi_version(void);
  * backward, the texture backward: 450-510 registers per lane, nothing else fits beside them on a
  * SIMD).  0 / 256 = one workgroup per CU (a single optimisation alone on the GPU); with several
  * drawings in flight on one GPU fewer workgroups leave CUs to the other drawings' kernels while such
- * a kernel runs (bench.py --inflight: 128).  Process-wide; workspaces stay sized for 256. */
+ * a kernel runs (bench.py --inflight: 192).  Process-wide; workspaces stay sized for 256. */
 int dsu_set_onewave_grid_cap(int32_t workgroups);
 /* The same for the table-gradient scatter of the geometry backward (0 = its resident count: three
  * 256-thread workgroups of 45 KB LDS per CU). */
