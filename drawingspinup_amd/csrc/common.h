@@ -7,6 +7,20 @@
 
 #define DSU_WAVE 64
 
+// max(x, 0) as ONE v_max_f32.  fmaxf() is llvm.maxnum, and in IEEE mode the backend quiets a possible
+// signalling NaN first (`v_max_f32 v, v, v`) whenever it cannot see where the value came from — an
+// MFMA accumulator, for one: a second VALU slot per ReLU / Softplus in kernels bound by exactly those
+// slots.  Same result for every non-NaN input (DSU_RELU_FMAXF: the library form, A/B builds).
+__device__ __forceinline__ float dsu_relu(float x) {
+#ifdef DSU_RELU_FMAXF
+  return fmaxf(x, 0.0f);
+#else
+  float r;
+  asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(x));
+  return r;
+#endif
+}
+
 #define DSU_CHECK_LAUNCH()                                   \
   do {                                                       \
     hipError_t e__ = hipGetLastError();                      \

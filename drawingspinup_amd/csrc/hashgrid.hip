@@ -274,6 +274,10 @@ __device__ __forceinline__ void mlp_stream_sgpr(const dsu_sdf_mlp& mlp, const fl
 #ifndef DSU_FWD_JB
 #define DSU_FWD_JB 2
 #endif
+// 1: the forward's offset evaluations in packed-f32 pairs (0: one evaluation per instruction, rounds 5-6a)
+#ifndef DSU_FWD_PK
+#define DSU_FWD_PK 1
+#endif
 
 // points of the export's lattice formed in the kernel (dsu_sdf_fwd_lattice): x-slabs from x0
 struct SdfLattice {
@@ -732,6 +736,78 @@ void sdf_fd_fwd_shared_kernel(
       }
     }
     // ---- MLP: groups of hidden units outer, evaluations inner
+#if DSU_FWD_PK
+    // The six offset evaluations as three (+eps, -eps) pairs in packed-f32 arithmetic (v_pk_fma_f32 /
+    // v_pk_mul_f32 / v_pk_add_f32: two IEEE operations per lane and issue slot, the scalar weight
+    // broadcast to both halves): the same operations in the same order per evaluation (k ascending
+    // for the pre-activations, j ascending for the outputs), so the same bits — the kernel is bound
+    // by VALU issue slots (~16 500 per wave and pass, two thirds of them here).
+    constexpr int KIN = 3 + 2 * ACT;
+    float in0[KIN];
+    f32x2 inp[3][KIN];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) in0[a] = q[0][a] * 2.0f + -1.0f;
+#pragma unroll
+    for (int l = 0; l < ACT; ++l) {
+      in0[3 + 2 * l] = __low2float(f[0][l]);
+      in0[4 + 2 * l] = __high2float(f[0][l]);
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+        inp[t][a] = f32x2{q[2 * t + 1][a] * 2.0f + -1.0f, q[2 * t + 2][a] * 2.0f + -1.0f};
+#pragma unroll
+      for (int l = 0; l < ACT; ++l) {
+        inp[t][3 + 2 * l] = f32x2{__low2float(f[2 * t + 1][l]), __low2float(f[2 * t + 2][l])};
+        inp[t][4 + 2 * l] = f32x2{__high2float(f[2 * t + 1][l]), __high2float(f[2 * t + 2][l])};
+      }
+    }
+    constexpr int NO0 = FEAT ? NOUT : 1;
+    float o0[NO0], s[7];
+    f32x2 sp[3];
+#pragma unroll
+    for (int o = 0; o < NO0; ++o) o0[o] = b1[o];
+#pragma unroll
+    for (int t = 0; t < 3; ++t) sp[t] = splat2(b1[0]);
+#pragma unroll 1
+    for (int j = 0; j < HID; j += DSU_FWD_JB) {
+      {
+        float h[DSU_FWD_JB];
+#pragma unroll
+        for (int r = 0; r < DSU_FWD_JB; ++r) {
+          float acc = b0[j + r];
+#pragma unroll
+          for (int k = 0; k < KIN; ++k) acc = fmaf(w0[(j + r) * DIN + k], in0[k], acc);
+          h[r] = softplus100(acc);
+        }
+#pragma unroll
+        for (int o = 0; o < NO0; ++o)
+#pragma unroll
+          for (int r = 0; r < DSU_FWD_JB; ++r) o0[o] = fmaf(w1[o * HID + j + r], h[r], o0[o]);
+      }
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        f32x2 h[DSU_FWD_JB];
+#pragma unroll
+        for (int r = 0; r < DSU_FWD_JB; ++r) {
+          f32x2 acc = splat2(b0[j + r]);
+#pragma unroll
+          for (int k = 0; k < KIN; ++k)
+            acc = __builtin_elementwise_fma(splat2(w0[(j + r) * DIN + k]), inp[t][k], acc);
+          h[r] = softplus100_pair(acc);
+        }
+#pragma unroll
+        for (int r = 0; r < DSU_FWD_JB; ++r)
+          sp[t] = __builtin_elementwise_fma(splat2(w1[j + r]), h[r], sp[t]);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 3; ++t) {
+      s[2 * t + 1] = sp[t].x;
+      s[2 * t + 2] = sp[t].y;
+    }
+#else
     float xin[7][3];
 #pragma unroll
     for (int e = 0; e < 7; ++e)
@@ -782,6 +858,7 @@ void sdf_fd_fwd_shared_kernel(
         }
       }
     }
+#endif
     s[0] = o0[0];
     if (regular) {
       if (FEAT) {

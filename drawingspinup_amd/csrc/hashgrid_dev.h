@@ -96,7 +96,20 @@ __device__ __forceinline__ float softplus100(float x) {
   // threshold branch does; the explicit `bx > 20 ? x : ...` form compiled to one exec-mask branch
   // region per hidden unit (32 per lane per evaluation: 3x the instruction stream of the layer).
   const float t = __builtin_amdgcn_exp2f(fabsf(x) * -144.26950408889634f);   // exp(-|100 x|)
-  return fmaxf(x, 0.0f) + __builtin_amdgcn_logf(1.0f + t) * 0.0069314718055994531f;  // ln2 / 100
+  return dsu_relu(x) + __builtin_amdgcn_logf(1.0f + t) * 0.0069314718055994531f;  // ln2 / 100
+}
+// Two values per lane in packed-f32 instructions (v_pk_mul_f32 / v_pk_add_f32; exp2 / log2 / max
+// have no packed form): per value the same operations in the same order as softplus100 — the
+// multiplication by 144.27 commutes with |.| and the sign bit for bit — hence the same result.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 softplus100_pair(f32x2 x) {
+  const f32x2 y = x * splat2(144.26950408889634f);
+  const f32x2 t = {__builtin_amdgcn_exp2f(-fabsf(y.x)), __builtin_amdgcn_exp2f(-fabsf(y.y))};
+  const f32x2 u = splat2(1.0f) + t;
+  const f32x2 lg = {__builtin_amdgcn_logf(u.x), __builtin_amdgcn_logf(u.y)};
+  const f32x2 mx = {dsu_relu(x.x), dsu_relu(x.y)};
+  return mx + lg * splat2(0.0069314718055994531f);
 }
 __device__ __forceinline__ float softplus100_grad(float x) {
   // sigmoid(100 x) = 1 / (1 + exp(-100 x)); exp2(+large) = inf -> rcp(inf) = 0

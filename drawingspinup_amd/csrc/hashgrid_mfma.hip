@@ -52,6 +52,19 @@ namespace {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
+// Softplus of two neighbouring accumulator values in packed-f32 instructions (softplus100_pair: same
+// bits as softplus100); DSU_PIPE_SP_SCALAR keeps the one-value form for A/B builds
+__device__ __forceinline__ void softplus_inplace2(f32x16& acc, int r) {
+#ifdef DSU_PIPE_SP_SCALAR
+  acc[r] = softplus100(acc[r]);
+  acc[r + 1] = softplus100(acc[r + 1]);
+#else
+  const f32x2 h = softplus100_pair(f32x2{acc[r], acc[r + 1]});
+  acc[r] = h.x;
+  acc[r + 1] = h.y;
+#endif
+}
+
 // x = hi + mid + O(2^-16 |x|) with hi, mid in bf16 (round to nearest even both times): the operands
 // of the "bf16 x 3" products a b ~ a_hi b_hi + a_hi b_mid + a_mid b_hi (relative error ~2^-15 per
 // product, f32 accumulation) on v_mfma_f32_32x32x16_bf16 — 16x the rate of the f32 MFMA, used for the
@@ -1332,7 +1345,7 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
 #pragma unroll
     for (int T = 0; T < 2; ++T)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[T][r] = softplus100(acc[T][r]);
+      for (int r = 0; r < 16; r += 2) softplus_inplace2(acc[T], r);
   };
   // dPre -> sigmoid factor -> dIn MFMAs of one hidden tile (bf16 x 3, as in the general kernel)
   auto din_tile = [&](int T, float (&dpre)[16], const f32x16& H, f32x16& din) {
@@ -1801,10 +1814,11 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
           H1[T] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(term == 2 ? w0b_mid[T] : w0b_hi[T],
                                                          term == 1 ? obm1 : obh1, H1[T], 0, 0, 0);
 #pragma unroll
-          for (int v = 0; v < 32; ++v)
+          for (int v = 0; v < 32; v += 2)
             if (v * NM / 32 == mi) {
-              H0[v >> 4][v & 15] = softplus100(H0[v >> 4][v & 15]);
+              softplus_inplace2(H0[v >> 4], v & 15);
               gw1c0[v >> 4][v & 15] = fmaf(H0[v >> 4][v & 15], d0h0, gw1c0[v >> 4][v & 15]);
+              gw1c0[v >> 4][(v & 15) + 1] = fmaf(H0[v >> 4][(v & 15) + 1], d0h0, gw1c0[v >> 4][(v & 15) + 1]);
             }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -1819,10 +1833,11 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
         H1[T] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0a[T][tt], b1[tt], H1[T], 0, 0, 0);
 #endif
 #pragma unroll
-        for (int v = 0; v < 32; ++v)
+        for (int v = 0; v < 32; v += 2)
           if (v * NM / 32 == mi) {
-            H0[v >> 4][v & 15] = softplus100(H0[v >> 4][v & 15]);
+            softplus_inplace2(H0[v >> 4], v & 15);
             gw1c0[v >> 4][v & 15] = fmaf(H0[v >> 4][v & 15], d0h0, gw1c0[v >> 4][v & 15]);
+            gw1c0[v >> 4][(v & 15) + 1] = fmaf(H0[v >> 4][(v & 15) + 1], d0h0, gw1c0[v >> 4][(v & 15) + 1]);
           }
         __builtin_amdgcn_sched_barrier(0);
       }
@@ -1866,10 +1881,10 @@ __global__ __launch_bounds__(256) void sdf_fd_bwd_pipe_kernel(
       gemm_T_with(gw0, imgI, [&](auto kc) {
 #endif
         constexpr int K = decltype(kc)::value;
+        softplus_inplace2(H1[(2 * K) >> 4], (2 * K) & 15);
 #pragma unroll
         for (int v = 2 * K; v < 2 * K + 2; ++v) {
           const int T = v >> 4, r = v & 15;
-          H1[T][r] = softplus100(H1[T][r]);
           gw1c0[T][r] = fmaf(H1[T][r], d0h1, gw1c0[T][r]);
           dp1[T][r] = (w1o0[T][r] * d0h1) *
                       (1.0f - __builtin_amdgcn_exp2f(H1[T][r] * -144.26950408889634f));
