@@ -16,6 +16,7 @@
 //             (x*1) ^ (y*2654435761) ^ (z*805459861)   (uint32), both taken mod size_l
 //   feature:  acc = fma((f16)weight, table[index], acc) in binary16 for c = 0..7 (f16 FMA,
 //             one rounding per step), exactly tcnn's half-precision accumulation.
+#define DSU_RELU_ONE_VMAX       // no matrix instructions in this file (common.h: dsu_relu)
 #include "hashgrid_dev.h"
 #include <utility>
 

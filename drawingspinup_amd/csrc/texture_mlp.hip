@@ -155,7 +155,7 @@ __device__ __forceinline__ void forward_half(const float* lds, const float* in, 
   for (int T = 0; T < 2; ++T)
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      H0[T][r] = dsu_relu(H0[T][r]);
+      H0[T][r] = fmaxf(H0[T][r], 0.0f);
       H1[T][r] = 0.0f;
     }
   // layer 1: H1^T = W1 . H0^T ; register (T, r) of H0 is the k-pair (feat_of(T,r,0), +4).
@@ -218,7 +218,7 @@ __device__ __forceinline__ void forward_half(const float* lds, const float* in, 
 #pragma unroll
   for (int T = 0; T < 2; ++T)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) H1[T][r] = dsu_relu(H1[T][r]);
+    for (int r = 0; r < 16; ++r) H1[T][r] = fmaxf(H1[T][r], 0.0f);
 }
 
 // partial dot products of the 3 outputs over the 32 hidden units this lane holds (sample l31 of

@@ -59,3 +59,22 @@ def test_dominant_nsr_kernels_have_no_scratch():
     assert md["sspill"] <= 96, md
     md, _ = ks["sdf_fd_bwd_mfma_kernel<10,0,1>"]
     assert md["sspill"] <= 96, md
+
+
+def test_asm_valu_statements_stay_out_of_files_with_matrix_instructions():
+    """An asm statement that reads an MFMA accumulator gets none of the MFMA -> VALU wait states the
+    compiler inserts for its own instructions (round 6: the texture forward's ReLU as `asm("v_max_f32")`
+    composited colours 0.12 off).  dsu_relu's asm form is opt-in per file (DSU_RELU_ONE_VMAX), and a
+    file that opts in, or carries a VALU asm statement of its own, has no matrix instruction."""
+    import re
+    for f in sorted(os.listdir(isa.CSRC)):
+        if not f.endswith((".hip", ".h")):
+            continue
+        src = open(os.path.join(isa.CSRC, f)).read()
+        valu_asm = re.search(r'asm\s*(volatile)?\s*\(\s*"v_', src) is not None and f != "common.h"
+        if "#define DSU_RELU_ONE_VMAX" in src or valu_asm:
+            assert "__builtin_amdgcn_mfma" not in src, f
+            for inc in re.findall(r'#include "([^"]+)"', src):
+                p = os.path.join(isa.CSRC, inc)
+                if os.path.exists(p):
+                    assert "__builtin_amdgcn_mfma" not in open(p).read(), (f, inc)

@@ -2,7 +2,8 @@
 a GPU.  For every kernel: registers, spills, scratch, LDS (from the `amdhsa.kernels` metadata,
 parsed per kernel block) and instruction counts that have pointed at real problems before
 ("pitfalls"): v_accvgpr_mov per MFMA (accumulators copied around conditional MFMAs),
-exec-mask branch regions (conditional loads), scratch traffic, v_readlane/v_writelane (SGPR spills).
+exec-mask branch regions (conditional loads), scratch traffic, v_readlane/v_writelane (SGPR spills),
+`v_max_f32 v, v, v` (fmaxf quieting a possible sNaN: a second VALU slot per ReLU).
 
     python tools/isa_stats.py [file.hip ...] [--filter substring] [--loops]
 """
@@ -81,7 +82,7 @@ def main():
     a = ap.parse_args()
     files = a.files or sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
     print(f"{'kernel':46s} {'vgpr':>4s} {'agpr':>4s} {'vsp':>3s} {'ssp':>3s} {'scr':>4s} {'lds':>6s} "
-          f"{'instr':>6s} {'mfma':>4s} {'accmov':>6s} {'brreg':>5s} {'scrop':>5s} {'lane':>4s} {'nop':>4s}")
+          f"{'instr':>6s} {'mfma':>4s} {'accmov':>6s} {'brreg':>5s} {'scrop':>5s} {'lane':>4s} {'nop':>4s} {'quiet':>5s}")
     for f in files:
         txt = compile_asm(f)
         md = metadata(txt)
@@ -101,14 +102,17 @@ def main():
                 if mi:
                     c[mi.group(1)] += 1
                     depth[cur_depth] += 1
+                    # v_max_f32 v, v, v: fmaxf()'s quieting of a possible sNaN ahead of the real max
+                    if re.match(r"\s+v_max_f32_e32 (v\d+), (v\d+), \2\s*$", ln):
+                        c["_quiet"] += 1
             m = md.get(name, {})
             mfma = sum(v for k, v in c.items() if k.startswith("v_mfma"))
             scr = sum(v for k, v in c.items() if k.startswith("scratch_"))
             lane = c["v_readlane_b32"] + c["v_writelane_b32"]
             print(f"{short[:46]:46s} {m.get('vgpr', 0):4d} {m.get('agpr', 0):4d} {m.get('vspill', 0):3d} "
                   f"{m.get('sspill', 0):3d} {m.get('scratch', 0):4d} {m.get('lds', 0):6d} "
-                  f"{sum(c.values()):6d} {mfma:4d} {c['v_accvgpr_mov_b32']:6d} "
-                  f"{c['s_cbranch_execz']:5d} {scr:5d} {lane:4d} {c['s_nop']:4d}")
+                  f"{sum(c.values()) - c['_quiet']:6d} {mfma:4d} {c['v_accvgpr_mov_b32']:6d} "
+                  f"{c['s_cbranch_execz']:5d} {scr:5d} {lane:4d} {c['s_nop']:4d} {c['_quiet']:5d}")
             if a.loops:
                 print("      instructions by loop depth:", dict(sorted(depth.items())))
 
