@@ -444,6 +444,19 @@ def _inflight_loop(args, ddist, rank, dev, timer, pipes, inputs, stage_t, sub_t,
         _sync(dev)
         timer.enabled = False
         rows = timer.summary()
+        # diagnostic (DSU_ALONE_REPEAT=n): the same drawing alone n more times, the allocator's cache dropped before the
+        # last one — tells a per-process placement effect from a per-drawing one (the two modes of `alone`)
+        for rep in range(int(os.environ.get("DSU_ALONE_REPEAT", "0"))):
+            print("[alone %d] %s" % (rep, [(r["kernel"], round(r["avg_launch_ms"], 4)) for r in rows[:3]]), file=sys.stderr)
+            if rep == int(os.environ["DSU_ALONE_REPEAT"]) - 1 and on_gpu:
+                torch.cuda.empty_cache()
+            timer.fam, timer._calls, nsr_system.native_timing["totals"] = {}, {}, {}
+            timer.enabled = True
+            one(pipes[0], streams[0], 0, True)
+            _sync(dev)
+            timer.enabled = False
+            rows = timer.summary()
+            print("[alone %d'] %s" % (rep, [(r["kernel"], round(r["avg_launch_ms"], 4)) for r in rows[:3]]), file=sys.stderr)
         info["alone"] = [{k: r[k] for k in ("kernel", "launches", "avg_launch_ms", "achieved", "peak", "unit", "frac")
                           if k in r} | ({"bound_actual_frac": r["bound_actual"]["frac"]} if "bound_actual" in r else {})
                          for r in rows[:3]]
@@ -619,6 +632,13 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
 
     inflight = len(pipes)
     flight = None
+    if torch.device(dev).type == "cuda":
+        # side stream of the NSR step driver: high priority with drawings in flight (the optimisation keeps its precedence
+        # over the other drawings' launches), normal with one drawing at a time (include/dsu_hip.h: streams of non-default
+        # priority put every fourth and later drawing of a process into a 0.8 s slower mode)
+        from drawingspinup_amd import _lib as dsu_lib_
+        dsu_lib_.check(dsu_lib_.lib().dsu_set_nsr_side_stream_priority(2 if inflight == 1 else 1),
+                       "dsu_set_nsr_side_stream_priority")
     if inflight == 1:
         elapsed, last = _timed_loop(args, ddist, dev, timer, one_drawing)
     else:

@@ -22,6 +22,12 @@ int dsu_set_scatter_grid_cap(int32_t workgroups) {
   dsu_scatter_grid_cap_value = workgroups;
   return DSU_OK;
 }
+int32_t dsu_nsr_side_priority_value = DSU_NSR_SIDE_PRIO_DEFAULT;   // 1 high, 2 normal, 0 low (nsr_driver.hip)
+int dsu_set_nsr_side_stream_priority(int32_t level) {
+  if (level < 0 || level > 2) return DSU_EINVAL;
+  dsu_nsr_side_priority_value = level;
+  return DSU_OK;
+}
 int dsu_set_onewave_grid_cap(int32_t workgroups) {
   if (workgroups < 0 || workgroups > 256) return DSU_EINVAL;
   dsu_onewave_grid_cap_value = workgroups;

@@ -53,6 +53,11 @@ static inline bool dsu_ab_is(const char*, const char*) { return false; }
 
 // Workgroups of the two one-wave-per-SIMD kernels of the NSR step (dsu_set_onewave_grid_cap, capi.hip)
 extern "C" int32_t dsu_onewave_grid_cap_value;
+// Priority of the NSR driver's side stream (dsu_set_nsr_side_stream_priority, capi.hip; nsr_driver.hip has the story)
+#ifndef DSU_NSR_SIDE_PRIO_DEFAULT
+#define DSU_NSR_SIDE_PRIO_DEFAULT 1
+#endif
+extern "C" int32_t dsu_nsr_side_priority_value;
 extern "C" int32_t dsu_scatter_grid_cap_value;
 static inline int dsu_onewave_blocks(int64_t n, int threads, int max_blocks) {
   int cap = dsu_onewave_grid_cap_value;

@@ -20,6 +20,16 @@
 // through pinned memory.  All device memory is the caller's: one workspace carved here.
 #include "common.h"
 #include "adamw_dev.h"
+// Priority of the driver's side stream (march + packing of the next step's samples): 1 high, 2 normal, 0 low —
+// process-wide, dsu_set_nsr_side_stream_priority (default high).  Found at the end of round 6: a driver is created per
+// drawing, and from the fourth side stream of a process on a stream of NON-DEFAULT priority (high or low alike) puts the
+// whole drawing into a slow mode — every kernel of the main stream 10-100 % longer (geometry forward 116 -> 135 us, texture
+// forward 50 -> 90, table update 26 -> 52, the march itself 357 -> 331), the optimisation 2.31 -> 3.11 s; at normal
+// priority 10 of 10 drawings fast, 6 of 15 slow otherwise (profiles/round6_side_stream_priority.txt; it lives in the
+// runtime's queues for such streams, not in this code).  One drawing at a time therefore wants NORMAL (bench.py
+// --inflight 1 sets it).  With three drawings in flight the bench line measured 0.317 / 0.337 at normal against
+// 0.341 / 0.347 at high (different boxes; the optimisation loses its precedence over the other drawings' diffusion
+// launches: 5.7 vs 4.8 s per drawing in the stage, the diffusion 1.8 vs 2.4): the in-flight default stays high.
 
 #include <math.h>
 #include <string.h>
@@ -587,7 +597,8 @@ int dsu_nsr_driver_create(const dsu_nsr_driver_cfg* cfg, dsu_nsr_driver** out) {
     }
   }
   int lo = 0, hi = 0;
-  d->side_high_priority = dsu_ab_int("DSU_NSR_SIDE_PRIO", 1) != 0;
+  const int side_prio = dsu_ab_int("DSU_NSR_SIDE_PRIO", dsu_nsr_side_priority_value);   // 1 high, 2 normal, 0 low
+  d->side_high_priority = side_prio == 1;
   // 0 since round 4: with 16-ray marching waves and the shorter step the packing right behind the
   // march measured 1.148 against 1.161 ms per step for "behind the geometry forward" (five
   // interleaved pairs, same box) — and the main queue loses one event record per step
@@ -596,7 +607,7 @@ int dsu_nsr_driver_create(const dsu_nsr_driver_cfg* cfg, dsu_nsr_driver** out) {
   d->tex_masks = dsu_ab_int("DSU_NSR_TEX_MASKS", 1) != 0;   // (variant builds: 0 = exact f32 recompute, for A/B)
   bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
             hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking,
-                                        d->side_high_priority ? hi : lo) == hipSuccess;
+                                        side_prio == 1 ? hi : (side_prio == 2 ? 0 : lo)) == hipSuccess;
   for (int p = 0; p < 3; ++p)
     ok = ok && hipEventCreateWithFlags(&d->ready[p], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->gate, hipEventDisableTiming) == hipSuccess &&

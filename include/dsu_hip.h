@@ -44,6 +44,12 @@ int dsu_set_onewave_grid_cap(int32_t workgroups);
 /* The same for the table-gradient scatter of the geometry backward (0 = its resident count: three
  * 256-thread workgroups of 45 KB LDS per CU). */
 int dsu_set_scatter_grid_cap(int32_t workgroups);
+/* Priority of the side stream on which the NSR step driver marches and packs the next step's samples
+ * (dsu_nsr_driver_create reads it): 1 = high (default: what several drawings in flight measured best
+ * with), 2 = normal (one drawing at a time: streams of non-default priority put every fourth and later
+ * drawing of a process into a 0.8 s slower mode, profiles/round6_side_stream_priority.txt), 0 = low.
+ * Process-wide. */
+int dsu_set_nsr_side_stream_priority(int32_t level);
 
 /* ------------------------------------------------------------------------------------
  * Multi-resolution hash grid (replaces tiny-cuda-nn `tcnn.Encoding(3, {otype:HashGrid})`
