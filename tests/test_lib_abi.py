@@ -57,6 +57,18 @@ def test_argument_validation_without_gpu():
     assert lib.dsu_ric_offsets(0, 4, None, None) == -1
 
 
+def test_process_wide_knobs_validate_their_ranges():
+    """include/dsu_hip.h: the grid caps of the NSR step's kernels and the priority of the step driver's side stream
+    (1 high = the default, 2 normal, 0 low) — all restored to their defaults here."""
+    from drawingspinup_amd import _lib
+    lib = _lib.lib()
+    assert lib.dsu_set_onewave_grid_cap(257) == -1 and lib.dsu_set_onewave_grid_cap(-1) == -1
+    assert lib.dsu_set_onewave_grid_cap(192) == 0 and lib.dsu_set_onewave_grid_cap(0) == 0
+    assert lib.dsu_set_scatter_grid_cap(4097) == -1 and lib.dsu_set_scatter_grid_cap(0) == 0
+    for level, rc in ((-1, -1), (3, -1), (0, 0), (2, 0), (1, 0)):
+        assert lib.dsu_set_nsr_side_stream_priority(level) == rc, level
+
+
 def test_style_training_host_side_sizes():
     """Host-only planning of the training kernels: workspace of the sliced weight gradient and
     the sampling-table size; argument checks return before any launch."""
