@@ -57,6 +57,12 @@ def parse(argv=None):
     ap.add_argument("--inflight", type=int, default=3,
                     help="--config drawing: drawings in flight per GPU (one Python thread + one stream + "
                          "one DrawingPipeline each); 1 = one drawing at a time, as in rounds 1-5")
+    ap.add_argument("--side-priority", type=int, default=None, choices=(0, 1, 2),
+                    help="priority of the NSR step driver's side stream: 1 high, 2 normal, 0 low (default: high with "
+                         "drawings in flight, normal with one drawing at a time; profiles/round6_side_stream_priority.txt)")
+    ap.add_argument("--side-pool", type=int, default=0, choices=(0, 1),
+                    help="1: step drivers hand their side stream on to the next driver (one stream per drawing in flight "
+                         "instead of one per drawing; not measured yet, default off)")
     ap.add_argument("--inflight-skew", type=float, default=None,
                     help="seconds between the starts of the workers' first drawings of a region (stage skew; "
                          "default: 4.2 s / inflight)")
@@ -637,8 +643,11 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
         # over the other drawings' launches), normal with one drawing at a time (include/dsu_hip.h: streams of non-default
         # priority put every fourth and later drawing of a process into a 0.8 s slower mode)
         from drawingspinup_amd import _lib as dsu_lib_
-        dsu_lib_.check(dsu_lib_.lib().dsu_set_nsr_side_stream_priority(2 if inflight == 1 else 1),
-                       "dsu_set_nsr_side_stream_priority")
+        side_prio = getattr(args, "side_priority", None)
+        side_prio = (2 if inflight == 1 else 1) if side_prio is None else int(side_prio)
+        dsu_lib_.check(dsu_lib_.lib().dsu_set_nsr_side_stream_priority(side_prio), "dsu_set_nsr_side_stream_priority")
+        dsu_lib_.check(dsu_lib_.lib().dsu_set_nsr_side_stream_pooling(int(getattr(args, "side_pool", 0) or 0)),
+                       "dsu_set_nsr_side_stream_pooling")
     if inflight == 1:
         elapsed, last = _timed_loop(args, ddist, dev, timer, one_drawing)
     else:

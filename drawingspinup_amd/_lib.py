@@ -157,6 +157,7 @@ _PROTOS = {
     "dsu_set_onewave_grid_cap": [c_i32],
     "dsu_set_scatter_grid_cap": [c_i32],
     "dsu_set_nsr_side_stream_priority": [c_i32],
+    "dsu_set_nsr_side_stream_pooling": [c_i32],
     "dsu_volume_band_distance_workspace_bytes": [c_i32, c_i32, c_i32],
     "dsu_volume_band_distance": [P, c_i32, c_i32, c_i32, c_i32, P, P, P, P, P, c_i64, P],
     "dsu_mc_cube_index": [P, c_i32, c_i32, c_i32, C.c_double, P, P],

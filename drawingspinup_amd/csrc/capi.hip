@@ -28,6 +28,12 @@ int dsu_set_nsr_side_stream_priority(int32_t level) {
   dsu_nsr_side_priority_value = level;
   return DSU_OK;
 }
+int32_t dsu_nsr_side_pool_value = 0;   // 1: side streams handed from one step driver to the next (nsr_driver.hip)
+int dsu_set_nsr_side_stream_pooling(int32_t on) {
+  if (on < 0 || on > 1) return DSU_EINVAL;
+  dsu_nsr_side_pool_value = on;
+  return DSU_OK;
+}
 int dsu_set_onewave_grid_cap(int32_t workgroups) {
   if (workgroups < 0 || workgroups > 256) return DSU_EINVAL;
   dsu_onewave_grid_cap_value = workgroups;

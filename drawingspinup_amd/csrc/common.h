@@ -58,6 +58,7 @@ extern "C" int32_t dsu_onewave_grid_cap_value;
 #define DSU_NSR_SIDE_PRIO_DEFAULT 1
 #endif
 extern "C" int32_t dsu_nsr_side_priority_value;
+extern "C" int32_t dsu_nsr_side_pool_value;
 extern "C" int32_t dsu_scatter_grid_cap_value;
 static inline int dsu_onewave_blocks(int64_t n, int threads, int max_blocks) {
   int cap = dsu_onewave_grid_cap_value;

@@ -34,6 +34,7 @@
 #include <math.h>
 #include <string.h>
 
+#include <mutex>
 #include <vector>
 
 namespace {
@@ -360,6 +361,31 @@ bool cfg_ok(const dsu_nsr_driver_cfg& c) {
          (c.sort_bits == 0 || (c.sort_bits >= 4 && c.sort_bits <= 7)) && c.grid.n_levels <= DSU_MAX_LEVELS;
 }
 
+// Side streams handed from one driver to the next (dsu_set_nsr_side_stream_pooling, OFF by default: not measured on
+// the GPU yet).  A driver lives for one drawing; with the pool a process creates as many side streams as it has
+// drawings in flight instead of one per drawing — the slow mode of profiles/round6_side_stream_priority.txt starts
+// with the fourth stream of non-default priority a process creates.  Keyed by device and priority level; a stream
+// enters the pool drained (dsu_nsr_driver_destroy synchronises it first).
+struct PooledSide { int device, level; hipStream_t stream; };
+std::mutex side_pool_mu;
+std::vector<PooledSide> side_pool;
+
+hipStream_t side_pool_take(int device, int level) {
+  std::lock_guard<std::mutex> g(side_pool_mu);
+  for (size_t i = 0; i < side_pool.size(); ++i)
+    if (side_pool[i].device == device && side_pool[i].level == level) {
+      hipStream_t s = side_pool[i].stream;
+      side_pool.erase(side_pool.begin() + (long)i);
+      return s;
+    }
+  return nullptr;
+}
+
+void side_pool_give(int device, int level, hipStream_t s) {
+  std::lock_guard<std::mutex> g(side_pool_mu);
+  side_pool.push_back({device, level, s});
+}
+
 }  // namespace
 
 struct dsu_nsr_driver {
@@ -375,6 +401,7 @@ struct dsu_nsr_driver {
   bool fold = true;                 // DSU_NSR_FOLD (variant builds)
   bool tex_masks = true;            // DSU_NSR_TEX_MASKS (variant builds)
   bool side_high_priority = true;   // DSU_NSR_SIDE_PRIO
+  int side_level = 1, side_device = 0;   // (what the side stream was made with: the pool's key)
   int pack_gate = 0;                // DSU_NSR_PACK_GATE: 0 with the march, 1 behind this step's geometry
                                     // forward (own event), 2 behind the MLP part of this step's backward
   int32_t* host_stats = nullptr;                       // pinned, 3 x int32[2]
@@ -605,9 +632,13 @@ int dsu_nsr_driver_create(const dsu_nsr_driver_cfg* cfg, dsu_nsr_driver** out) {
   d->pack_gate = dsu_ab_int("DSU_NSR_PACK_GATE", 0);
   d->fold = dsu_ab_int("DSU_NSR_FOLD", 1) != 0;
   d->tex_masks = dsu_ab_int("DSU_NSR_TEX_MASKS", 1) != 0;   // (variant builds: 0 = exact f32 recompute, for A/B)
-  bool ok = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
-            hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking,
-                                        side_prio == 1 ? hi : (side_prio == 2 ? 0 : lo)) == hipSuccess;
+  d->side_level = side_prio;
+  bool ok = hipGetDevice(&d->side_device) == hipSuccess;
+  if (ok && dsu_nsr_side_pool_value) d->side = side_pool_take(d->side_device, side_prio);
+  ok = ok && (d->side != nullptr ||
+              (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+               hipStreamCreateWithPriority(&d->side, hipStreamNonBlocking,
+                                           side_prio == 1 ? hi : (side_prio == 2 ? 0 : lo)) == hipSuccess));
   for (int p = 0; p < 3; ++p)
     ok = ok && hipEventCreateWithFlags(&d->ready[p], hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&d->gate, hipEventDisableTiming) == hipSuccess &&
@@ -625,7 +656,8 @@ void dsu_nsr_driver_destroy(dsu_nsr_driver* d) {
   if (!d) return;
   if (d->side) {
     (void)hipStreamSynchronize(d->side);
-    (void)hipStreamDestroy(d->side);
+    if (dsu_nsr_side_pool_value) side_pool_give(d->side_device, d->side_level, d->side);
+    else (void)hipStreamDestroy(d->side);
   }
   for (int p = 0; p < 3; ++p)
     if (d->ready[p]) (void)hipEventDestroy(d->ready[p]);

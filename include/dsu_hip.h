@@ -50,6 +50,11 @@ int dsu_set_scatter_grid_cap(int32_t workgroups);
  * drawing of a process into a 0.8 s slower mode, profiles/round6_side_stream_priority.txt), 0 = low.
  * Process-wide. */
 int dsu_set_nsr_side_stream_priority(int32_t level);
+/* 1: a destroyed step driver hands its (drained) side stream to the next driver created on the same
+ * device with the same priority, so that a process creates as many side streams as it has drawings
+ * in flight instead of one per drawing.  0 (default): one stream per driver.  Prepared at the end of
+ * round 6 for the A/B "high priority without the slow mode"; not measured on the GPU yet.  Process-wide. */
+int dsu_set_nsr_side_stream_pooling(int32_t on);
 
 /* ------------------------------------------------------------------------------------
  * Multi-resolution hash grid (replaces tiny-cuda-nn `tcnn.Encoding(3, {otype:HashGrid})`

@@ -67,6 +67,8 @@ def test_process_wide_knobs_validate_their_ranges():
     assert lib.dsu_set_scatter_grid_cap(4097) == -1 and lib.dsu_set_scatter_grid_cap(0) == 0
     for level, rc in ((-1, -1), (3, -1), (0, 0), (2, 0), (1, 0)):
         assert lib.dsu_set_nsr_side_stream_priority(level) == rc, level
+    assert lib.dsu_set_nsr_side_stream_pooling(2) == -1 and lib.dsu_set_nsr_side_stream_pooling(1) == 0
+    assert lib.dsu_set_nsr_side_stream_pooling(0) == 0
 
 
 def test_style_training_host_side_sizes():
