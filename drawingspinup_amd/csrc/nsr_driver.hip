@@ -361,8 +361,8 @@ bool cfg_ok(const dsu_nsr_driver_cfg& c) {
          (c.sort_bits == 0 || (c.sort_bits >= 4 && c.sort_bits <= 7)) && c.grid.n_levels <= DSU_MAX_LEVELS;
 }
 
-// Side streams handed from one driver to the next (dsu_set_nsr_side_stream_pooling, OFF by default: not measured on
-// the GPU yet).  A driver lives for one drawing; with the pool a process creates as many side streams as it has
+// Side streams handed from one driver to the next (dsu_set_nsr_side_stream_pooling, OFF by default: six of six
+// back-to-back reconstructions fast at high priority with it, the bench line with drawings in flight not measured yet).  A driver lives for one drawing; with the pool a process creates as many side streams as it has
 // drawings in flight instead of one per drawing — the slow mode of profiles/round6_side_stream_priority.txt starts
 // with the fourth stream of non-default priority a process creates.  Keyed by device and priority level; a stream
 // enters the pool drained (dsu_nsr_driver_destroy synchronises it first).

@@ -53,7 +53,8 @@ int dsu_set_nsr_side_stream_priority(int32_t level);
 /* 1: a destroyed step driver hands its (drained) side stream to the next driver created on the same
  * device with the same priority, so that a process creates as many side streams as it has drawings
  * in flight instead of one per drawing.  0 (default): one stream per driver.  Prepared at the end of
- * round 6 for the A/B "high priority without the slow mode"; not measured on the GPU yet.  Process-wide. */
+ * round 6: six of six back-to-back reconstructions fast at high priority with it (un-pooled: slow from
+ * the fourth on); the bench line with drawings in flight is not measured with it yet.  Process-wide. */
 int dsu_set_nsr_side_stream_pooling(int32_t on);
 
 /* ------------------------------------------------------------------------------------
