@@ -195,10 +195,10 @@ class KernelTimer:
                 # pair (+ 64-bit LDS atomics in its scatter half), not the table traffic
                 tf = flops[name] / (ms * 1e-3) / 1e12
                 rows[-1]["bound_actual"] = {
-                    "bound": "f32 MLP arithmetic (v_mfma_f32_32x32x2_f32 / v_fma_f32)",
+                    "bound": "f32 MLP arithmetic (MFMA f32 / bf16 x 3 with f32 accumulation, VALU f32; priced at the f32 MFMA peak)",
                     "achieved": tf, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
                     "frac": tf / F32_MFMA_PEAK_TF,
-                    "note": ("MLP part at one wave per SIMD (458 VGPRs) + scatter on 64-bit LDS atomics"
+                    "note": ("MLP part at one wave per SIMD (460-480 VGPRs) + scatter on 64-bit LDS atomics"
                              if name == "sdf_fd_bwd" else
                              "level-outer gathers (shared corners) + VALU MLP, 3-4 waves per SIMD")}
         rows.sort(key=lambda r: -r["total_ms"])
