@@ -446,6 +446,9 @@ def _inflight_loop(args, ddist, rank, dev, timer, pipes, inputs, stage_t, sub_t,
         if on_gpu:
             dsu_lib.lib().dsu_set_onewave_grid_cap(0)          # alone: one workgroup per CU
             dsu_lib.lib().dsu_set_scatter_grid_cap(0)
+            # ... and the side stream at normal priority, as for one drawing at a time (DSU_ALONE_SIDE_PRIO overrides):
+            # at the in-flight priority this drawing lands in either mode of profiles/round6_side_stream_priority.txt
+            dsu_lib.lib().dsu_set_nsr_side_stream_priority(int(os.environ.get("DSU_ALONE_SIDE_PRIO", "2")))
         one(pipes[0], streams[0], 0, True)
         _sync(dev)
         timer.enabled = False
@@ -705,7 +708,8 @@ def bench_drawing(args, ddist, rank, world, dev, timer, pipe=None):
         roof["note_in_flight"] = ("avg_launch_ms / achieved / frac are HIP-event intervals inside the timed region, "
                                   "where %d drawings share the GPU: an interval contains the co-running kernels' "
                                   "share of the machine; roofline.alone = the same families with one drawing alone "
-                                  "on the GPU (one more drawing after the clock)" % inflight)
+                                  "on the GPU (one more drawing after the clock, one workgroup per CU for the one-wave kernels, "
+                                  "side stream at normal priority as for one drawing at a time)" % inflight)
         roof["alone"] = flight.get("alone")
         lead = next((r for r in (roof["alone"] or []) if r.get("kernel") == roof.get("kernel")), None)
         if lead:                                  # the leading family alone, next to the shared-machine figures
